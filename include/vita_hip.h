@@ -1,0 +1,160 @@
+/* vita_hip.h — C ABI of libvita_hip.so, the MI355X (gfx950) hot path of VITA inference.
+ *
+ * The reference (VITA-MLLM/VITA @ 2024-10-22) is 100 % Python and has no FFI of its own:
+ * its drop-in boundary is the `vita.model` Python API (vita/model/builder.py:14-24,306;
+ * vita/model/language_model/vita_mixtral.py:249-415; vita/model/multimodal_encoder/builder.py:12,44;
+ * vita/model/multimodal_projector/builder.py:154).  This header is the boundary we add
+ * beneath it: the entry points a maintainer binds with ctypes from those Python classes
+ * (see INTEGRATION.md).  Each function names the reference computation it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked host;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - activations are fp32, large weights bf16 (uint16 storage), small vectors fp32;
+ *   - return 0 on success, VH_E_* (<0) on error; vh_last_error() describes the last one;
+ *   - no entry point allocates device memory; engines take a caller-provided workspace
+ *     whose size comes from the matching *_workspace_bytes().
+ */
+#ifndef VITA_HIP_H
+#define VITA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_OK 0
+#define VH_E_SHAPE (-1)
+#define VH_E_ARG (-2)
+#define VH_E_HIP (-3)
+#define VH_E_COMM (-4)
+
+#define VH_ACT_NONE 0
+#define VH_ACT_GELU 1 /* erf GELU (nn.GELU default) */
+#define VH_ACT_RELU 2
+#define VH_ACT_SILU 3
+
+int vh_version(void);
+const char* vh_last_error(void);
+
+/* ---- generic operators --------------------------------------------------------------
+ * vh_gemm: C = epilogue(A W^T).  Replaces every nn.Linear / conv-as-GEMM on the path:
+ * InternViT qkv/proj/fc1/fc2 (internvit/modeling_intern_vit.py:144,175,213-217), the
+ * mlp2x_gelu projector (multimodal_projector/builder.py:164-168), Whale linears and convs
+ * (whale/module/component/subsampling.py:28-43, module/layer/attention.py:145-147,370-419,
+ * adapter.py:93-136) and the Mixtral prefill projections + expert GEMMs (HF
+ * modeling_mixtral.py MixtralAttention / MixtralExperts).
+ *   A fp32 [*, lda]; logical row m reads source row a_rowidx[m] (or m) + segrow[k/seglen],
+ *   column k%seglen; rows outside [0,a_rows) read as zero.  K = nseg*seglen, K%64==0.
+ *   W bf16 [N][ldw]; W_up != NULL selects the gated form silu(A W^T) * (A W_up^T).
+ *   group_off != NULL: grouped GEMM over `ngroups` row ranges, W advancing w_group_stride.
+ *   epilogue: (+bias[n]) -> act -> (*scale[n]) -> (+resid[orow,n]) -> C[orow,n],
+ *   orow = c_rowidx[m] or m.                                                            */
+typedef struct {
+    const float* A; long lda; int a_rows; const int* a_rowidx;
+    int nseg; int seglen; int segrow[16];
+    const uint16_t* W; const uint16_t* W_up; long ldw; long w_group_stride;
+    const int* group_off; int ngroups;
+    float* C; long ldc; const int* c_rowidx;
+    const float* bias; const float* scale; const float* resid; long ldr;
+    int M, N, K, act;
+} vh_gemm_args;
+int vh_gemm(const vh_gemm_args* args, void* stream);
+
+/* vh_attention: softmax(scale * Q K^T [+ (Q+v) P^T]) V with causal / pad / chunk masks.
+ * Replaces InternAttention._naive_attn (modeling_intern_vit.py:158-177), Whale
+ * MultiHeadedAttention.forward score/softmax/PV (attention.py:380-416) and HF
+ * eager_attention_forward for the Mixtral prefill.  head_dim 64 or 128.               */
+typedef struct {
+    const float* Q; long ldq; long hsq;
+    const float* K; long ldk; long hsk;
+    const float* V; long ldv; long hsv;
+    const float* P; long ldp; long hsp;
+    const float* bias_u; const float* bias_v;
+    float* O; long ldo;
+    long bsq, bsk, bso;
+    int B, Hq, Hkv, Sq, Sk, d;
+    int causal, q_off, klen, chunk, left;
+    float scale;
+} vh_attn_args;
+int vh_attention(const vh_attn_args* args, void* stream);
+
+/* nn.LayerNorm over the last dim (+ optional act, then * post_scale). */
+int vh_layernorm(const float* x, long ldx, float* y, long ldy, const float* w, const float* b, int rows, int cols,
+                 float eps, int act, float post_scale, void* stream);
+/* MixtralRMSNorm (HF modeling_mixtral.py:134-148). */
+int vh_rmsnorm(const float* x, float* y, const float* w, int rows, int cols, float eps, void* stream);
+int vh_add(float* x, const float* y, long n, void* stream);
+int vh_cast_bf16_f32(const uint16_t* in, float* out, long n, void* stream);
+
+/* InternViT front/back (modeling_intern_vit.py:68-122; internvit_encoder.py:35-79). */
+int vh_vit_patchify(const float* pix, float* out, int n, int img, int patch, int kpad, void* stream);
+int vh_vit_assemble(const float* patches, const uint16_t* cls, const uint16_t* pos, float* x, int n, int ntok,
+                    int hid, void* stream);
+int vh_vit_pixel_shuffle(const float* x, float* out, int n, int grid, int hid, float mul, void* stream);
+
+/* Whale GlobalCMVN + first Conv2d + ReLU, channels-last (cmvn.py:29-32; subsampling.py:28-31). */
+int vh_audio_conv1(const float* feats, const float* mean, const float* istd, const uint16_t* w, const float* b,
+                   float* out, int T, int F, int C, void* stream);
+
+/* embed_tokens gather + image/audio splice (vita_arch.py:237-321); kind 0 text,1 image,2 audio. */
+int vh_embed_splice(const int* src_kind, const int* src_idx, const uint16_t* embed, const float* img_feats,
+                    const float* aud_feats, float* out, int S, int H, void* stream);
+
+/* ---- Mixtral engine: prefill + greedy decode (HF MixtralModel/GenerationMixin as driven by
+ * vita_mixtral.py:101-215,291-382 and video_audio_demo.py:257-270) ---------------------- */
+typedef struct {
+    int hidden, n_layers, n_q_heads, n_kv_heads, head_dim, inter, n_experts, top_k, vocab;
+    float rms_eps;
+    int max_ctx;          /* KV-cache capacity in tokens */
+    int max_prefill;      /* largest S accepted by vh_mixtral_prefill */
+    int max_new;          /* capacity of the generated-token buffer */
+    int tp_rank, tp_world;/* n_q_heads / n_kv_heads / inter above are THIS RANK's slices */
+    int nsplit;           /* decode split-KV factor, 0 = auto */
+} vh_mixtral_cfg;
+
+typedef struct {
+    const float* attn_norm;    /* [hidden] fp32 */
+    const uint16_t* wqkv;      /* [(nq+2nkv)*head_dim][hidden]  q rows, then k rows, then v rows */
+    const uint16_t* wo;        /* [hidden][nq*head_dim] */
+    const float* ffn_norm;     /* [hidden] */
+    const uint16_t* wrouter;   /* [n_experts][hidden]   block_sparse_moe.gate */
+    const uint16_t* w1;        /* [n_experts][inter][hidden]  gate proj (experts.N.w1) */
+    const uint16_t* w3;        /* [n_experts][inter][hidden]  up proj   (experts.N.w3) */
+    const uint16_t* w2;        /* [n_experts][hidden][inter]  down proj (experts.N.w2) */
+} vh_mixtral_layer;
+
+typedef struct vh_mixtral vh_mixtral_t;
+
+size_t vh_mixtral_workspace_bytes(const vh_mixtral_cfg* cfg);
+/* `layers` is a host array of cfg->n_layers entries (copied). rope tables: fp32 [max_ctx][head_dim/2]. */
+vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_layer* layers, const uint16_t* embed,
+                                const float* final_norm, const uint16_t* lm_head, const float* rope_cos,
+                                const float* rope_sin, void* workspace, size_t workspace_bytes);
+void vh_mixtral_destroy(vh_mixtral_t* m);
+
+/* Tensor-parallel all-reduce hook (sum, fp32, in place).  Either the built-in RCCL path or a
+ * caller-supplied callback (e.g. torch.distributed).  Unused when tp_world == 1. */
+typedef int (*vh_allreduce_fn)(void* user, float* buf, long count, void* stream);
+int vh_mixtral_set_allreduce(vh_mixtral_t* m, vh_allreduce_fn fn, void* user);
+int vh_rccl_unique_id(void* out_128_bytes /* host */);
+int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* unique_id_128_bytes /* host */);
+
+/* Prefill S embedded tokens at positions [pos0, pos0+S); leaves the first generated token in
+ * out_tokens[0] (greedy) and the engine ready to decode.  If logits_out != NULL the fp32
+ * logits of the last position are copied there ([vocab]).  hidden_dbg (nullable): fp32
+ * [n_layers][S][hidden] receives the residual stream after every layer.                   */
+int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, float* logits_out, float* hidden_dbg,
+                       void* stream);
+/* Run n_steps greedy decode steps back to back with no host interaction. */
+int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
+/* Device pointers into the engine state (for the host loop and the tests). */
+const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */
+const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[2]: {pos, n_generated}    */
+const float* vh_mixtral_logits(const vh_mixtral_t* m);   /* fp32[vocab] of the last step  */
+int vh_mixtral_reset(vh_mixtral_t* m, void* stream);     /* n_generated = 0, pos = 0      */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

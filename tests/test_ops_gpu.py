@@ -1,0 +1,328 @@
+"""GPU parity of every generic C-ABI operator against plain numpy (the per-kernel oracle):
+fp32 references on the same bf16-rounded weights.  Tolerances: the split-bf16 GEMM carries the
+activation to 2^-17, so |err| <= ~2e-5 * sum|a*w| in the worst case; stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, to_np
+from vita_amd.checkpoint import round_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _w(rng, *shape, std=0.05):
+    return round_bf16(rng.standard_normal(shape, dtype=np.float32) * std)
+
+
+def _dev(x, dev, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev).to(dtype)
+
+
+def gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+ACTS = {None: lambda x: x, "gelu": gelu, "relu": lambda x: np.maximum(x, 0), "silu": lambda x: x / (1 + np.exp(-x))}
+
+
+# ---------------------------------------------------------------------------------------------
+def test_mfma_layout_probe(dev):
+    """A = I-like pattern with an ASYMMETRIC W catches row/col swaps of the MFMA fragment maps."""
+    from vita_amd import ops
+    M, N, K = 64, 128, 64
+    a = np.zeros((M, K), np.float32)
+    a[np.arange(M), np.arange(M) % K] = 1.0
+    w = round_bf16((np.arange(N)[:, None] * 0.5 + np.arange(K)[None, :] * 0.001953125).astype(np.float32))
+    got = to_np(ops.gemm(_dev(a, dev), _dev(w, dev, torch.bfloat16)))
+    assert_close("mfma_layout", got, a.astype(np.float64) @ w.T.astype(np.float64), atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (7, 100, 128), (64, 128, 64), (130, 257, 192), (450, 6144, 4096),
+                                   (1025, 3072, 1024)])
+def test_gemm_plain(dev, M, N, K):
+    from vita_amd import ops
+    rng = np.random.default_rng(M * 7 + N)
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = _w(rng, N, K)
+    got = to_np(ops.gemm(_dev(a, dev), _dev(w, dev, torch.bfloat16)))
+    ref = a.astype(np.float64) @ w.T.astype(np.float64)
+    assert_close(f"gemm {M}x{N}x{K}", got, ref, atol=2e-5 * np.sqrt(K), rtol=2e-5)
+
+
+@pytest.mark.parametrize("act", [None, "gelu", "relu", "silu"])
+def test_gemm_epilogue(dev, act):
+    from vita_amd import ops
+    rng = np.random.default_rng(3)
+    M, N, K = 77, 200, 128
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = _w(rng, N, K)
+    bias, scale = _w(rng, N, std=0.5), _w(rng, N, std=1.0)
+    resid = rng.standard_normal((M, N), dtype=np.float32)
+    got = to_np(ops.gemm(_dev(a, dev), _dev(w, dev, torch.bfloat16), bias=_dev(bias, dev), act=act,
+                         scale=_dev(scale, dev), resid=_dev(resid, dev)))
+    ref = ACTS[act](a.astype(np.float64) @ w.T + bias) * scale + resid
+    assert_close(f"gemm epilogue {act}", got, ref, atol=1e-4, rtol=1e-5)
+
+
+def test_gemm_inplace_residual(dev):
+    """out aliases resid (the x += proj(...) pattern)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(4)
+    M, N, K = 90, 128, 64
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = _w(rng, N, K)
+    x = rng.standard_normal((M, N), dtype=np.float32)
+    xd = _dev(x, dev)
+    ops.gemm(_dev(a, dev), _dev(w, dev, torch.bfloat16), resid=xd, out=xd)
+    assert_close("gemm inplace resid", to_np(xd), x + a.astype(np.float64) @ w.T, atol=1e-4)
+
+
+def test_gemm_segments_conv(dev):
+    """conv2d 3x3 stride 2 over a channels-last map expressed as row-offset segments
+    (whale subsampling conv2: subsampling.py:28-43)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(5)
+    T1, F1, Cin, Cout = 13, 9, 64, 96
+    x = rng.standard_normal((T1, F1, Cin), dtype=np.float32)
+    wt = _w(rng, Cout, Cin, 3, 3)  # torch layout [Cout, Cin, kh, kw]
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    ref = np.zeros((T2, F2, Cout))
+    for t in range(T2):
+        for f in range(F2):
+            patch = x[2 * t:2 * t + 3, 2 * f:2 * f + 3, :]  # [kh, kw, Cin]
+            ref[t, f] = np.einsum("hwc,ochw->o", patch.astype(np.float64), wt.astype(np.float64))
+    wp = np.ascontiguousarray(wt.transpose(0, 2, 3, 1).reshape(Cout, 9 * Cin))  # [Cout, (kh,kw,cin)]
+    rowidx = np.array([(2 * t) * F1 + 2 * f for t in range(T2) for f in range(F2)], np.int32)
+    segrow = [kh * F1 + kw for kh in range(3) for kw in range(3)]
+    got = to_np(ops.gemm(_dev(x.reshape(T1 * F1, Cin), dev), _dev(wp, dev, torch.bfloat16),
+                         a_rowidx=_dev(rowidx, dev, torch.int32), segrow=segrow, seglen=Cin))
+    assert_close("gemm conv segments", got, ref.reshape(T2 * F2, Cout), atol=1e-4)
+
+
+def test_gemm_segments_zero_pad(dev):
+    """conv1d k=5 s=2 with right zero padding via out-of-range rows (whale adapter.py:107-127)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(6)
+    T, Cin, Cout, k = 11, 64, 80, 5
+    x = rng.standard_normal((T, Cin), dtype=np.float32)
+    wt = _w(rng, Cout, Cin, k)
+    xp = np.concatenate([x, np.zeros((k - 1, Cin), np.float32)])
+    To = (T + k - 1 - k) // 2 + 1
+    ref = np.stack([np.einsum("kc,ock->o", xp[2 * t:2 * t + k].astype(np.float64), wt.astype(np.float64))
+                    for t in range(To)])
+    wp = np.ascontiguousarray(wt.transpose(0, 2, 1).reshape(Cout, k * Cin))
+    rowidx = (2 * np.arange(To)).astype(np.int32)
+    got = to_np(ops.gemm(_dev(x, dev), _dev(wp, dev, torch.bfloat16), a_rowidx=_dev(rowidx, dev, torch.int32),
+                         segrow=list(range(k)), seglen=Cin))  # rows >= T read as zero
+    assert_close("gemm conv1d zero pad", got, ref, atol=1e-4)
+
+
+def test_gemm_grouped_glu_and_scatter(dev):
+    """The top-2 MoE pair: grouped gate/up GEMM with SiLU*up, then grouped down GEMM scattered to
+    (token, slot) rows — HF MixtralExperts (modeling_mixtral.py:57-93)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(7)
+    S, H, I, E = 150, 128, 192, 4
+    x = rng.standard_normal((S, H), dtype=np.float32)
+    w1, w3, w2 = _w(rng, E, I, H), _w(rng, E, I, H), _w(rng, E, H, I)
+    ids = np.stack([rng.permutation(E)[:2] for _ in range(S)]).astype(np.int32)
+    ids[:10] = [[2, 0]] * 10  # skew: expert 1 may get few rows
+    flat = ids.reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    goff = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=E))]).astype(np.int32)
+    stok, sslot = (order // 2).astype(np.int32), order.astype(np.int32)
+    h = ops.gemm(_dev(x, dev), _dev(w1, dev, torch.bfloat16), w_up=_dev(w3, dev, torch.bfloat16),
+                 a_rowidx=_dev(stok, dev, torch.int32), group_off=_dev(goff, dev, torch.int32), ngroups=E,
+                 w_group_stride=I * H, m=2 * S)
+    href = np.zeros((2 * S, I))
+    for p, slot in enumerate(order):
+        e, t = flat[slot], slot // 2
+        g, u = x[t].astype(np.float64) @ w1[e].T, x[t].astype(np.float64) @ w3[e].T
+        href[p] = g / (1 + np.exp(-g)) * u
+    assert_close("grouped GLU", to_np(h), href, atol=2e-4)
+    y = torch.zeros((2 * S, H), dtype=torch.float32, device=dev)
+    ops.gemm(h, _dev(w2, dev, torch.bfloat16), group_off=_dev(goff, dev, torch.int32), ngroups=E,
+             w_group_stride=H * I, c_rowidx=_dev(sslot, dev, torch.int32), out=y)
+    yref = np.zeros((2 * S, H))
+    hn = to_np(h).astype(np.float64)
+    for p, slot in enumerate(order):
+        yref[slot] = hn[p] @ w2[flat[slot]].T
+    assert_close("grouped down + scatter", to_np(y), yref, atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, scale, mask=None, p=None, bu=None, bv=None):
+    """q [H,Sq,d], k/v [Hkv,Sk,d]; mask [Sq,Sk] True = visible."""
+    H, Sq, d = q.shape
+    g = H // k.shape[0]
+    out = np.zeros((Sq, H * d))
+    for h in range(H):
+        if p is None:
+            s = q[h].astype(np.float64) @ k[h // g].T
+        else:
+            s = (q[h] + bu[h]).astype(np.float64) @ k[h // g].T + (q[h] + bv[h]).astype(np.float64) @ p[h].T
+        s = s * scale
+        if mask is not None:
+            s = np.where(mask, s, -np.inf)
+        m = np.max(s, axis=-1, keepdims=True)
+        m = np.where(np.isfinite(m), m, 0.0)
+        e = np.exp(s - m)
+        den = e.sum(-1, keepdims=True)
+        pr = np.where(den > 0, e / np.where(den > 0, den, 1), 0.0)
+        out[:, h * d:(h + 1) * d] = pr @ v[h // g]
+    return out
+
+
+def test_attention_vit_like(dev):
+    """non-causal, 2 images x 3 heads x 64, N=77 (tails in both q and key tiles), packed qkv rows."""
+    from vita_amd import ops
+    rng = np.random.default_rng(8)
+    B, H, N, d = 2, 3, 77, 64
+    qkv = rng.standard_normal((B * N, 3 * H * d), dtype=np.float32)
+    t = _dev(qkv, dev)
+    out = torch.empty((B * N, H * d), dtype=torch.float32, device=dev)
+    ops.attention(t, t[:, H * d:], t[:, 2 * H * d:], out, B=B, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=3 * H * d, hsq=d,
+                  ldk=3 * H * d, hsk=d, ldv=3 * H * d, hsv=d, ldo=H * d, bsq=N * 3 * H * d, bsk=N * 3 * H * d,
+                  bso=N * H * d, scale=d ** -0.5)
+    for b in range(B):
+        r = qkv[b * N:(b + 1) * N].reshape(N, 3, H, d).transpose(1, 2, 0, 3)
+        ref = _attn_ref(r[0], r[1], r[2], d ** -0.5)
+        assert_close(f"attn vit b{b}", to_np(out[b * N:(b + 1) * N]), ref, atol=2e-5)
+
+
+def test_attention_big_scores(dev):
+    """large score range exercises the online-softmax rescale branch (running max jumps)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(9)
+    H, N, d = 2, 130, 64
+    q = rng.standard_normal((N, H * d), dtype=np.float32) * 3
+    k = rng.standard_normal((N, H * d), dtype=np.float32) * 3
+    k[97] *= 4.0  # spike late in the key order
+    v = rng.standard_normal((N, H * d), dtype=np.float32)
+    out = torch.empty((N, H * d), dtype=torch.float32, device=dev)
+    ops.attention(_dev(q, dev), _dev(k, dev), _dev(v, dev), out, B=1, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=H * d, hsq=d,
+                  ldk=H * d, hsk=d, ldv=H * d, hsv=d, ldo=H * d, scale=d ** -0.5)
+    sp = lambda x: x.reshape(N, H, d).transpose(1, 0, 2)
+    assert_close("attn big scores", to_np(out), _attn_ref(sp(q), sp(k), sp(v), d ** -0.5), atol=5e-5)
+
+
+@pytest.mark.parametrize("Sq,pos0", [(70, 0), (33, 45), (1, 99)])
+def test_attention_causal_gqa(dev, Sq, pos0):
+    """Mixtral prefill shape: 4 q-heads / 2 kv-heads x 128, K/V in cache layout [nkv][max_ctx][128]."""
+    from vita_amd import ops
+    rng = np.random.default_rng(10 + Sq)
+    nq, nkv, d, max_ctx = 4, 2, 128, 160
+    Sk = pos0 + Sq
+    q = rng.standard_normal((Sq, nq * d), dtype=np.float32)
+    kc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
+    vc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
+    out = torch.empty((Sq, nq * d), dtype=torch.float32, device=dev)
+    ops.attention(_dev(q, dev), _dev(kc, dev), _dev(vc, dev), out, B=1, Hq=nq, Hkv=nkv, Sq=Sq, Sk=Sk, d=d, ldq=nq * d,
+                  hsq=d, ldk=d, hsk=max_ctx * d, ldv=d, hsv=max_ctx * d, ldo=nq * d, scale=d ** -0.5, causal=True,
+                  q_off=pos0)
+    mask = np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]
+    ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), kc[:, :Sk], vc[:, :Sk], d ** -0.5, mask)
+    assert_close(f"attn causal gqa Sq={Sq} pos0={pos0}", to_np(out), ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("klen,chunk,left", [(87, 0, -1), (60, 0, -1), (87, 16, 2), (87, 7, -1)])
+def test_attention_relpos_masks(dev, klen, chunk, left):
+    """Whale rel-pos scores ((q+u)k^T + (q+v)p^T)/sqrt(d), no rel-shift, pad + chunk masks
+    (attention.py:380-409, utils.py:88-103)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(11)
+    H, T, d = 2, 87, 64
+    q, k, v, p = (rng.standard_normal((T, H * d), dtype=np.float32) for _ in range(4))
+    bu, bv = rng.standard_normal((H, d), dtype=np.float32), rng.standard_normal((H, d), dtype=np.float32)
+    out = torch.empty((T, H * d), dtype=torch.float32, device=dev)
+    ops.attention(_dev(q, dev), _dev(k, dev), _dev(v, dev), out, B=1, Hq=H, Hkv=H, Sq=T, Sk=T, d=d, ldq=H * d, hsq=d,
+                  ldk=H * d, hsk=d, ldv=H * d, hsv=d, ldo=H * d, scale=d ** -0.5, klen=klen, chunk=chunk, left=left,
+                  p=_dev(p, dev), ldp=H * d, hsp=d, bias_u=_dev(bu, dev), bias_v=_dev(bv, dev))
+    mask = np.broadcast_to(np.arange(T)[None, :] < klen, (T, T)).copy()
+    if chunk > 0:
+        for i in range(T):
+            start = 0 if left < 0 else max((i // chunk - left) * chunk, 0)
+            end = min((i // chunk + 1) * chunk, T)
+            mask[i, :start] = False
+            mask[i, end:] = False
+    sp = lambda x: x.reshape(T, H, d).transpose(1, 0, 2)
+    ref = _attn_ref(sp(q), sp(k), sp(v), d ** -0.5, mask, sp(p), bu[:, None, :], bv[:, None, :])
+    assert_close(f"attn relpos klen={klen} chunk={chunk}", to_np(out), ref, atol=5e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cols", [128, 1024, 2048, 4096])
+def test_layernorm_rmsnorm(dev, cols):
+    from vita_amd import ops
+    rng = np.random.default_rng(12)
+    rows = 37
+    x = rng.standard_normal((rows, cols), dtype=np.float32) * 2 + 0.5
+    w, b = _w(rng, cols, std=1.0), _w(rng, cols, std=0.5)
+    x64 = x.astype(np.float64)
+    mu, var = x64.mean(-1, keepdims=True), x64.var(-1, keepdims=True)
+    ref = (x64 - mu) / np.sqrt(var + 1e-5) * w + b
+    assert_close("layernorm", to_np(ops.layernorm(_dev(x, dev), _dev(w, dev), _dev(b, dev), 1e-5)), ref, atol=2e-5)
+    assert_close("layernorm relu*32", to_np(ops.layernorm(_dev(x, dev), _dev(w, dev), _dev(b, dev), 1e-5, act="relu",
+                                                          post_scale=32.0)), np.maximum(ref, 0) * 32.0, atol=5e-4)
+    rref = x64 / np.sqrt((x64 ** 2).mean(-1, keepdims=True) + 1e-5) * w
+    assert_close("rmsnorm", to_np(ops.rmsnorm(_dev(x, dev), _dev(w, dev), 1e-5)), rref, atol=2e-5)
+
+
+def test_vit_front_back(dev):
+    """patchify (conv 14x14/14 as GEMM rows), CLS/pos assemble, pixel shuffle vs torch-free numpy
+    restatements of modeling_intern_vit.py:109-121 and internvit_encoder.py:42-53."""
+    from vita_amd import ops
+    rng = np.random.default_rng(13)
+    n, img, P, C = 2, 56, 14, 32
+    g = img // P
+    pix = rng.standard_normal((n, 3, img, img), dtype=np.float32)
+    kpad = 640
+    got = to_np(ops.vit_patchify(_dev(pix, dev), P, kpad))
+    ref = pix.reshape(n, 3, g, P, g, P).transpose(0, 2, 4, 1, 3, 5).reshape(n * g * g, 3 * P * P)
+    assert_close("patchify", got[:, :3 * P * P], ref, atol=0)
+    assert np.all(got[:, 3 * P * P:] == 0)
+    patches = rng.standard_normal((n * g * g, C), dtype=np.float32)
+    cls, pos = _w(rng, C, std=1.0), _w(rng, g * g + 1, C, std=1.0)
+    x = to_np(ops.vit_assemble(_dev(patches, dev), _dev(cls, dev, torch.bfloat16), _dev(pos, dev, torch.bfloat16), n,
+                               g * g + 1, C)).reshape(n, g * g + 1, C)
+    xref = np.concatenate([np.broadcast_to(cls, (n, 1, C)), patches.reshape(n, g * g, C)], 1) + pos[None]
+    assert_close("assemble", x, xref, atol=1e-6)
+    # pixel shuffle reference = the reference's view/permute chain
+    f = (xref[:, 1:] * 0.5).reshape(n, g, g, C).astype(np.float32)
+    t = f.reshape(n, g, g // 2, 2 * C).transpose(0, 2, 1, 3).reshape(n, g // 2, g // 2, 4 * C).transpose(0, 2, 1, 3)
+    got = to_np(ops.vit_pixel_shuffle(_dev(xref.reshape(-1, C).astype(np.float32), dev), n, g, C, 0.5))
+    assert_close("pixel_shuffle", got, t.reshape(n, (g // 2) ** 2, 4 * C), atol=1e-6)
+
+
+def test_audio_conv1(dev):
+    from vita_amd import ops
+    rng = np.random.default_rng(14)
+    T, F, C = 41, 80, 48
+    feats = rng.standard_normal((T, F), dtype=np.float32) * 3 + 10
+    mean, istd = rng.standard_normal(F).astype(np.float32) + 10, (rng.random(F).astype(np.float32) + 0.5)
+    w, b = _w(rng, C, 1, 3, 3, std=0.3), _w(rng, C, std=0.3)
+    out, T1, F1 = ops.audio_conv1(_dev(feats, dev), _dev(mean, dev), _dev(istd, dev),
+                                  _dev(w.reshape(C, 9), dev, torch.bfloat16), _dev(b, dev))
+    xn = ((feats - mean) * istd).astype(np.float64)
+    ref = np.zeros((T1, F1, C))
+    for t in range(T1):
+        for f in range(F1):
+            ref[t, f] = np.einsum("hw,chw->c", xn[2 * t:2 * t + 3, 2 * f:2 * f + 3], w[:, 0].astype(np.float64)) + b
+    assert_close("audio conv1", to_np(out).reshape(T1, F1, C), np.maximum(ref, 0), atol=1e-4)
+
+
+def test_embed_splice(dev):
+    from vita_amd import ops
+    rng = np.random.default_rng(15)
+    H, V = 256, 50
+    emb = _w(rng, V, H, std=1.0)
+    img = rng.standard_normal((8, H), dtype=np.float32)
+    aud = rng.standard_normal((5, H), dtype=np.float32)
+    kind = np.array([0, 0, 1, 1, 1, 0, 2, 2, 0], np.int32)
+    idx = np.array([3, 49, 0, 1, 7, 10, 4, 0, 0], np.int32)
+    got = to_np(ops.embed_splice(_dev(kind, dev, torch.int32), _dev(idx, dev, torch.int32),
+                                 _dev(emb, dev, torch.bfloat16), _dev(img, dev), _dev(aud, dev), H))
+    ref = np.stack([(emb, img, aud)[k][i] for k, i in zip(kind, idx)])
+    assert_close("embed_splice", got, ref, atol=0)

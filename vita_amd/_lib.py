@@ -1,0 +1,124 @@
+"""ctypes binding of libvita_hip.so (include/vita_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not export a
+declared symbol, importing an operator raises.  Build it with `python __graft_entry__.py`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvita_hip.so")
+
+VH_ACT_NONE, VH_ACT_GELU, VH_ACT_RELU, VH_ACT_SILU = 0, 1, 2, 3
+
+c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_long), ("a_rows", c_int), ("a_rowidx", c_void_p),
+        ("nseg", c_int), ("seglen", c_int), ("segrow", c_int * 16),
+        ("W", c_void_p), ("W_up", c_void_p), ("ldw", c_long), ("w_group_stride", c_long),
+        ("group_off", c_void_p), ("ngroups", c_int),
+        ("C", c_void_p), ("ldc", c_long), ("c_rowidx", c_void_p),
+        ("bias", c_void_p), ("scale", c_void_p), ("resid", c_void_p), ("ldr", c_long),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("act", c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("ldq", c_long), ("hsq", c_long),
+        ("K", c_void_p), ("ldk", c_long), ("hsk", c_long),
+        ("V", c_void_p), ("ldv", c_long), ("hsv", c_long),
+        ("P", c_void_p), ("ldp", c_long), ("hsp", c_long),
+        ("bias_u", c_void_p), ("bias_v", c_void_p),
+        ("O", c_void_p), ("ldo", c_long),
+        ("bsq", c_long), ("bsk", c_long), ("bso", c_long),
+        ("B", c_int), ("Hq", c_int), ("Hkv", c_int), ("Sq", c_int), ("Sk", c_int), ("d", c_int),
+        ("causal", c_int), ("q_off", c_int), ("klen", c_int), ("chunk", c_int), ("left", c_int),
+        ("scale", c_float),
+    ]
+
+
+class MixtralCfg(C.Structure):
+    _fields_ = [
+        ("hidden", c_int), ("n_layers", c_int), ("n_q_heads", c_int), ("n_kv_heads", c_int),
+        ("head_dim", c_int), ("inter", c_int), ("n_experts", c_int), ("top_k", c_int), ("vocab", c_int),
+        ("rms_eps", c_float), ("max_ctx", c_int), ("max_prefill", c_int), ("max_new", c_int),
+        ("tp_rank", c_int), ("tp_world", c_int), ("nsplit", c_int),
+    ]
+
+
+class MixtralLayer(C.Structure):
+    _fields_ = [
+        ("attn_norm", c_void_p), ("wqkv", c_void_p), ("wo", c_void_p), ("ffn_norm", c_void_p),
+        ("wrouter", c_void_p), ("w1", c_void_p), ("w3", c_void_p), ("w2", c_void_p),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
+
+# every symbol include/vita_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "vh_version": (c_int, []),
+    "vh_last_error": (C.c_char_p, []),
+    "vh_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "vh_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "vh_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
+                             c_float, c_void_p]),
+    "vh_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "vh_add": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "vh_cast_bf16_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "vh_vit_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vh_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vh_vit_pixel_shuffle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "vh_audio_conv1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_void_p]),
+    "vh_embed_splice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vh_mixtral_workspace_bytes": (c_size_t, [C.POINTER(MixtralCfg)]),
+    "vh_mixtral_create": (c_void_p, [C.POINTER(MixtralCfg), C.POINTER(MixtralLayer), c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_size_t]),
+    "vh_mixtral_destroy": (None, [c_void_p]),
+    "vh_mixtral_set_allreduce": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
+    "vh_rccl_unique_id": (c_int, [c_void_p]),
+    "vh_mixtral_init_rccl": (c_int, [c_void_p, c_void_p]),
+    "vh_mixtral_prefill": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vh_mixtral_decode": (c_int, [c_void_p, c_int, c_void_p]),
+    "vh_mixtral_tokens": (c_void_p, [c_void_p]),
+    "vh_mixtral_counters": (c_void_p, [c_void_p]),
+    "vh_mixtral_logits": (c_void_p, [c_void_p]),
+    "vh_mixtral_reset": (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class VitaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitaHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py`). "
+            "There is no CPU fallback for the vita_amd hot path.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise VitaHipError(f"libvita_hip.so does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().vh_last_error()
+        raise VitaHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

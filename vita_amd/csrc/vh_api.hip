@@ -1,0 +1,434 @@
+// vh_api.hip — the C ABI (include/vita_hip.h): argument checking, error reporting, and the
+// Mixtral engine that owns the layer loop for prefill and greedy decode so that one host call
+// enqueues a whole forward (HF MixtralModel.forward + GenerationMixin greedy loop, as driven
+// by vita/model/language_model/vita_mixtral.py:101-215 and video_audio_demo.py:257-270).
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/vita_hip.h"
+#include "vh_kernels.h"
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int check_launch(const char* what, int rc) {
+    if (rc != 0) return fail(VH_E_SHAPE, "%s: unsupported shape/arguments", what);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VH_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return VH_OK;
+}
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+extern "C" {
+
+int vh_version(void) { return 100; }
+const char* vh_last_error(void) { return g_err; }
+
+int vh_gemm(const vh_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->W || !a->C) return fail(VH_E_ARG, "vh_gemm: null pointer");
+    VhGemmArgs g;
+    g.A = a->A; g.lda = a->lda; g.a_rows = a->a_rows; g.a_rowidx = a->a_rowidx;
+    g.nseg = a->nseg; g.seglen = a->seglen;
+    for (int i = 0; i < 16; ++i) g.segrow[i] = a->segrow[i];
+    g.W = a->W; g.W_up = a->W_up; g.ldw = a->ldw; g.w_group_stride = a->w_group_stride;
+    g.group_off = a->group_off; g.ngroups = a->ngroups;
+    g.C = a->C; g.ldc = a->ldc; g.c_rowidx = a->c_rowidx;
+    g.bias = a->bias; g.scale = a->scale; g.resid = a->resid; g.ldr = a->ldr;
+    g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act;
+    if ((a->lda % 4) != 0 || (a->ldw % 8) != 0) return fail(VH_E_SHAPE, "vh_gemm: lda%%4 / ldw%%8 alignment");
+    return check_launch("vh_gemm", vhk_gemm(S(stream), g));
+}
+
+int vh_attention(const vh_attn_args* a, void* stream) {
+    if (!a || !a->Q || !a->K || !a->V || !a->O) return fail(VH_E_ARG, "vh_attention: null pointer");
+    VhAttnArgs g;
+    g.Q = a->Q; g.ldq = a->ldq; g.hsq = a->hsq; g.K = a->K; g.ldk = a->ldk; g.hsk = a->hsk;
+    g.V = a->V; g.ldv = a->ldv; g.hsv = a->hsv; g.P = a->P; g.ldp = a->ldp; g.hsp = a->hsp;
+    g.bias_u = a->bias_u; g.bias_v = a->bias_v; g.O = a->O; g.ldo = a->ldo;
+    g.bsq = a->bsq; g.bsk = a->bsk; g.bso = a->bso;
+    g.B = a->B; g.Hq = a->Hq; g.Hkv = a->Hkv; g.Sq = a->Sq; g.Sk = a->Sk; g.d = a->d;
+    g.causal = a->causal; g.q_off = a->q_off; g.klen = a->klen; g.chunk = a->chunk; g.left = a->left;
+    g.scale = a->scale;
+    if (a->P && (!a->bias_u || !a->bias_v)) return fail(VH_E_ARG, "vh_attention: rel-pos needs bias_u/bias_v");
+    if ((a->ldk % 2) || (a->ldv % 2) || (a->hsk % 2) || (a->hsv % 2) || (a->bsk % 2))
+        return fail(VH_E_SHAPE, "vh_attention: K/V strides must be even (8-byte loads)");
+    return check_launch("vh_attention", vhk_attn(S(stream), g));
+}
+
+int vh_layernorm(const float* x, long ldx, float* y, long ldy, const float* w, const float* b, int rows, int cols,
+                 float eps, int act, float post_scale, void* stream) {
+    return check_launch("vh_layernorm", vhk_layernorm(S(stream), x, ldx, y, ldy, w, b, rows, cols, eps, act, post_scale));
+}
+int vh_rmsnorm(const float* x, float* y, const float* w, int rows, int cols, float eps, void* stream) {
+    return check_launch("vh_rmsnorm", vhk_rmsnorm(S(stream), x, y, w, rows, cols, eps));
+}
+int vh_add(float* x, const float* y, long n, void* stream) { return check_launch("vh_add", vhk_add(S(stream), x, y, n)); }
+int vh_cast_bf16_f32(const uint16_t* in, float* out, long n, void* stream) {
+    return check_launch("vh_cast_bf16_f32", vhk_cast_bf16_f32(S(stream), in, out, n));
+}
+int vh_vit_patchify(const float* pix, float* out, int n, int img, int patch, int kpad, void* stream) {
+    return check_launch("vh_vit_patchify", vhk_vit_patchify(S(stream), pix, out, n, img, patch, kpad));
+}
+int vh_vit_assemble(const float* patches, const uint16_t* cls, const uint16_t* pos, float* x, int n, int ntok,
+                    int hid, void* stream) {
+    return check_launch("vh_vit_assemble", vhk_vit_assemble(S(stream), patches, cls, pos, x, n, ntok, hid));
+}
+int vh_vit_pixel_shuffle(const float* x, float* out, int n, int grid, int hid, float mul, void* stream) {
+    return check_launch("vh_vit_pixel_shuffle", vhk_vit_pixel_shuffle(S(stream), x, out, n, grid, hid, mul));
+}
+int vh_audio_conv1(const float* feats, const float* mean, const float* istd, const uint16_t* w, const float* b,
+                   float* out, int T, int F, int C, void* stream) {
+    return check_launch("vh_audio_conv1", vhk_audio_conv1(S(stream), feats, mean, istd, w, b, out, T, F, C));
+}
+int vh_embed_splice(const int* src_kind, const int* src_idx, const uint16_t* embed, const float* img_feats,
+                    const float* aud_feats, float* out, int Sn, int H, void* stream) {
+    return check_launch("vh_embed_splice",
+                        vhk_embed_splice(S(stream), src_kind, src_idx, embed, img_feats, aud_feats, out, Sn, H));
+}
+
+}  // extern "C"
+
+// =========================================================================================
+// Mixtral engine
+// =========================================================================================
+namespace {
+
+// RCCL is resolved at run time (same librccl torch already mapped) so libvita_hip.so has no
+// link-time dependency on it and loads on a single-GPU box without RCCL in the path.
+struct Id128 { char b[128]; };  // ncclUniqueId is passed BY VALUE (128 bytes)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+bool load_rccl() {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }
+    if (!h) for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return false;
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) return false;
+    g_rccl.lib = h;
+    return true;
+}
+
+inline size_t al(size_t n) { return (n + 255) & ~size_t(255); }
+
+struct Carver {
+    char* base; size_t off;
+    template <typename T> T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += al(count * sizeof(T));
+        return p;
+    }
+};
+
+}  // namespace
+
+struct vh_mixtral {
+    vh_mixtral_cfg c;
+    std::vector<vh_mixtral_layer> L;
+    const uint16_t* embed; const float* final_norm; const uint16_t* lm_head;
+    const float* rope_cos; const float* rope_sin;
+    int nq, nkv, hd, H, I, E, V, nqkv, nsplit, lm_grid;
+    // state
+    float *kcache, *vcache;  // [layer][nkv][max_ctx][hd]
+    float *xa, *xb, *delta_attn, *delta_moe, *qkv, *part_o, *part_ml, *hbuf, *logits, *blk_val;
+    int *blk_idx, *route, *counters, *out_tokens;
+    // prefill scratch
+    float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
+    int *pids, *pgoff, *pstok, *psslot;
+    // tensor parallel
+    vh_allreduce_fn ar_fn; void* ar_user; void* rccl_comm;
+
+    size_t carve(void* ws) {
+        Carver cv{reinterpret_cast<char*>(ws), 0};
+        const size_t Sm = (size_t)c.max_prefill;
+        kcache = cv.take<float>((size_t)c.n_layers * nkv * c.max_ctx * hd);
+        vcache = cv.take<float>((size_t)c.n_layers * nkv * c.max_ctx * hd);
+        xa = cv.take<float>(H); xb = cv.take<float>(H);
+        delta_attn = cv.take<float>(H); delta_moe = cv.take<float>(H);
+        qkv = cv.take<float>(nqkv);
+        part_o = cv.take<float>((size_t)nq * nsplit * hd);
+        part_ml = cv.take<float>((size_t)nq * nsplit * 2);
+        hbuf = cv.take<float>((size_t)2 * I);
+        logits = cv.take<float>(V);
+        blk_val = cv.take<float>(lm_grid);
+        blk_idx = cv.take<int>(lm_grid);
+        route = cv.take<int>(4);
+        counters = cv.take<int>(2);
+        out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
+        px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
+        pqkv = cv.take<float>(Sm * nqkv);
+        pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
+        ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(2 * Sm * H);
+        ptmp = cv.take<float>(Sm * H);
+        pwts = cv.take<float>(2 * Sm);
+        pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
+        pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
+        return cv.off;
+    }
+    void derive() {
+        nq = c.n_q_heads; nkv = c.n_kv_heads; hd = c.head_dim; H = c.hidden; I = c.inter; E = c.n_experts;
+        V = c.vocab; nqkv = (nq + 2 * nkv) * hd;
+        nsplit = c.nsplit > 0 ? c.nsplit : (c.max_ctx >= 1024 ? 8 : (c.max_ctx >= 256 ? 4 : 2));
+        lm_grid = (V + 7) / 8;
+        if (lm_grid > 1024) lm_grid = 1024;
+    }
+    int allreduce(float* buf, long count, hipStream_t st) {
+        if (c.tp_world <= 1) return 0;
+        if (!ar_fn) return -1;
+        return ar_fn(ar_user, buf, count, st);
+    }
+};
+
+namespace {
+int cfg_ok(const vh_mixtral_cfg* c) {
+    if (!c) return fail(VH_E_ARG, "null cfg");
+    if (c->head_dim != 128) return fail(VH_E_SHAPE, "head_dim must be 128 (got %d)", c->head_dim);
+    if (c->top_k != 2) return fail(VH_E_SHAPE, "top_k must be 2");
+    if (c->n_experts < 2 || c->n_experts > 8) return fail(VH_E_SHAPE, "n_experts must be in [2,8]");
+    if (c->hidden % 64 || c->inter % 64) return fail(VH_E_SHAPE, "hidden and inter must be multiples of 64");
+    if (c->hidden > 14336 || c->inter > 14336 || c->n_q_heads * c->head_dim > 14336)
+        return fail(VH_E_SHAPE, "dimension above the GEMV register budget (14336)");
+    if (c->n_q_heads % c->n_kv_heads || c->n_q_heads / c->n_kv_heads > 4)
+        return fail(VH_E_SHAPE, "GQA group must divide and be <= 4");
+    if (c->max_ctx < 1 || c->max_prefill < 1 || c->n_layers < 1) return fail(VH_E_SHAPE, "bad sizes");
+    return VH_OK;
+}
+int rccl_allreduce_cb(void* user, float* buf, long count, void* stream) {
+    vh_mixtral* m = reinterpret_cast<vh_mixtral*>(user);
+    const int rc = g_rccl.AllReduce(buf, buf, (size_t)count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, m->rccl_comm,
+                                    reinterpret_cast<hipStream_t>(stream));
+    return rc == 0 ? 0 : -1;
+}
+}  // namespace
+
+extern "C" {
+
+size_t vh_mixtral_workspace_bytes(const vh_mixtral_cfg* cfg) {
+    if (cfg_ok(cfg) != VH_OK) return 0;
+    vh_mixtral tmp{};
+    tmp.c = *cfg;
+    tmp.derive();
+    return tmp.carve(nullptr);
+}
+
+vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_layer* layers, const uint16_t* embed,
+                                const float* final_norm, const uint16_t* lm_head, const float* rope_cos,
+                                const float* rope_sin, void* workspace, size_t workspace_bytes) {
+    if (cfg_ok(cfg) != VH_OK) return nullptr;
+    if (!layers || !embed || !final_norm || !lm_head || !rope_cos || !rope_sin || !workspace) {
+        fail(VH_E_ARG, "vh_mixtral_create: null pointer");
+        return nullptr;
+    }
+    vh_mixtral* m = new vh_mixtral{};
+    m->c = *cfg;
+    m->derive();
+    m->L.assign(layers, layers + cfg->n_layers);
+    m->embed = embed; m->final_norm = final_norm; m->lm_head = lm_head;
+    m->rope_cos = rope_cos; m->rope_sin = rope_sin;
+    m->ar_fn = nullptr; m->ar_user = nullptr; m->rccl_comm = nullptr;
+    const size_t need = m->carve(workspace);
+    if (need > workspace_bytes) {
+        fail(VH_E_ARG, "vh_mixtral_create: workspace too small (%zu < %zu)", workspace_bytes, need);
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+
+void vh_mixtral_destroy(vh_mixtral_t* m) {
+    if (!m) return;
+    if (m->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->rccl_comm);
+    delete m;
+}
+
+int vh_mixtral_set_allreduce(vh_mixtral_t* m, vh_allreduce_fn fn, void* user) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    m->ar_fn = fn; m->ar_user = user;
+    return VH_OK;
+}
+
+int vh_rccl_unique_id(void* out) {
+    if (!load_rccl()) return fail(VH_E_COMM, "librccl.so not loadable: %s", dlerror());
+    const int rc = g_rccl.GetUniqueId(out);
+    return rc == 0 ? VH_OK : fail(VH_E_COMM, "ncclGetUniqueId failed (%d)", rc);
+}
+
+int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* uid) {
+    if (!m || !uid) return fail(VH_E_ARG, "null argument");
+    if (!load_rccl()) return fail(VH_E_COMM, "librccl.so not loadable");
+    Id128 id;
+    memcpy(id.b, uid, 128);
+    void* comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, m->c.tp_world, id, m->c.tp_rank);
+    if (rc != 0) return fail(VH_E_COMM, "ncclCommInitRank failed (%d)", rc);
+    m->rccl_comm = comm;
+    m->ar_fn = rccl_allreduce_cb; m->ar_user = m;
+    return VH_OK;
+}
+
+const int* vh_mixtral_tokens(const vh_mixtral_t* m) { return m ? m->out_tokens : nullptr; }
+const int* vh_mixtral_counters(const vh_mixtral_t* m) { return m ? m->counters : nullptr; }
+const float* vh_mixtral_logits(const vh_mixtral_t* m) { return m ? m->logits : nullptr; }
+
+int vh_mixtral_reset(vh_mixtral_t* m, void* stream) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    if (hipMemsetAsync(m->counters, 0, 2 * sizeof(int), S(stream)) != hipSuccess)
+        return fail(VH_E_HIP, "reset memset failed");
+    return VH_OK;
+}
+
+#define VH_TRY(expr, what)                                               \
+    do {                                                                 \
+        if ((expr) != 0) return fail(VH_E_SHAPE, "%s: launch rejected", what); \
+    } while (0)
+
+int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, float* logits_out, float* hidden_dbg,
+                       void* stream) {
+    if (!m || !embeds) return fail(VH_E_ARG, "vh_mixtral_prefill: null pointer");
+    if (Sn < 1 || Sn > m->c.max_prefill) return fail(VH_E_SHAPE, "prefill length %d outside [1,%d]", Sn, m->c.max_prefill);
+    if (pos0 < 0 || pos0 + Sn >= m->c.max_ctx) return fail(VH_E_SHAPE, "prefill exceeds KV capacity %d", m->c.max_ctx);
+    hipStream_t st = S(stream);
+    const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
+    const bool tp = m->c.tp_world > 1;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (hipMemcpyAsync(m->px, embeds, (size_t)Sn * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(VH_E_HIP, "prefill: embed copy failed");
+
+    for (int l = 0; l < m->c.n_layers; ++l) {
+        const vh_mixtral_layer& w = m->L[l];
+        float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.attn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
+        {
+            VhGemmArgs g{};
+            g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.nseg = 1; g.seglen = H;
+            g.W = w.wqkv; g.ldw = H; g.C = m->pqkv; g.ldc = m->nqkv; g.M = Sn; g.N = m->nqkv; g.K = H;
+            VH_TRY(vhk_gemm(st, g), "qkv gemm");
+        }
+        VH_TRY(vhk_rope_kv(st, m->pqkv, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
+                           m->c.max_ctx), "rope");
+        {
+            VhAttnArgs a{};
+            a.Q = m->pq; a.ldq = (long)nq * hd; a.hsq = hd;
+            a.K = kc; a.ldk = hd; a.hsk = (long)m->c.max_ctx * hd;
+            a.V = vc; a.ldv = hd; a.hsv = (long)m->c.max_ctx * hd;
+            a.O = m->pattn; a.ldo = (long)nq * hd;
+            a.B = 1; a.Hq = nq; a.Hkv = nkv; a.Sq = Sn; a.Sk = pos0 + Sn; a.d = hd;
+            a.causal = 1; a.q_off = pos0; a.klen = pos0 + Sn; a.chunk = 0; a.left = -1; a.scale = scale;
+            VH_TRY(vhk_attn(st, a), "attention");
+        }
+        {
+            VhGemmArgs g{};
+            g.A = m->pattn; g.lda = (long)nq * hd; g.a_rows = Sn; g.nseg = 1; g.seglen = nq * hd;
+            g.W = w.wo; g.ldw = (long)nq * hd; g.M = Sn; g.N = H; g.K = nq * hd;
+            if (tp) { g.C = m->ptmp; g.ldc = H; }
+            else { g.C = m->px; g.ldc = H; g.resid = m->px; g.ldr = H; }
+            VH_TRY(vhk_gemm(st, g), "o gemm");
+            if (tp) {
+                if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+            }
+        }
+        VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.ffn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
+        VH_TRY(vhk_moe_route(st, m->pxn, w.wrouter, Sn, H, E, m->pids, m->pwts), "route");
+        VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
+        {
+            VhGemmArgs g{};
+            g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.a_rowidx = m->pstok; g.nseg = 1; g.seglen = H;
+            g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
+            g.group_off = m->pgoff; g.ngroups = E;
+            g.C = m->ph; g.ldc = I; g.M = 2 * Sn; g.N = I; g.K = H;
+            VH_TRY(vhk_gemm(st, g), "gate/up gemm");
+        }
+        {
+            VhGemmArgs g{};
+            g.A = m->ph; g.lda = I; g.a_rows = 2 * Sn; g.nseg = 1; g.seglen = I;
+            g.W = w.w2; g.ldw = I; g.w_group_stride = (long)H * I;
+            g.group_off = m->pgoff; g.ngroups = E;
+            g.C = m->py; g.ldc = H; g.c_rowidx = m->psslot; g.M = 2 * Sn; g.N = H; g.K = I;
+            VH_TRY(vhk_gemm(st, g), "down gemm");
+        }
+        if (tp) {
+            if (hipMemsetAsync(m->ptmp, 0, (size_t)Sn * H * sizeof(float), st) != hipSuccess)
+                return fail(VH_E_HIP, "memset failed");
+            VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H), "combine");
+            if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+            VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+        } else {
+            VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H), "combine");
+        }
+        if (hidden_dbg)
+            hipMemcpyAsync(hidden_dbg + (size_t)l * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
+                           hipMemcpyDeviceToDevice, st);
+    }
+    // logits of the last position only (the reference computes all S rows and uses the last:
+    // vita_mixtral.py:171-172 + HF greedy argmax(logits[:, -1]))
+    VH_TRY(vhk_dec_lmhead(st, m->px + (size_t)(Sn - 1) * H, nullptr, m->final_norm, m->c.rms_eps, m->lm_head, m->V, H,
+                          m->logits, m->blk_val, m->blk_idx, m->lm_grid), "lm_head");
+    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters, m->counters + 1,
+                          m->out_tokens, m->c.max_new, /*mode=*/0, /*set_pos=*/pos0 + Sn), "select");
+    if (logits_out)
+        hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VH_E_HIP, "prefill: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
+int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    hipStream_t st = S(stream);
+    const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float eps = m->c.rms_eps;
+    for (int step = 0; step < n_steps; ++step) {
+        for (int l = 0; l < m->c.n_layers; ++l) {
+            const vh_mixtral_layer& w = m->L[l];
+            float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
+            float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
+            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
+                               m->qkv), "dec qkv");
+            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml, nq,
+                                nkv, m->c.max_ctx, m->nsplit, scale), "dec attn");
+            VH_TRY(vhk_dec_oproj(st, m->part_o, m->part_ml, m->nsplit, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
+            if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+            VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
+                                  m->route, m->hbuf, 0), "dec gateup");
+            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe), "dec down");
+            if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        }
+        VH_TRY(vhk_dec_lmhead(st, m->xa, m->delta_moe, m->final_norm, eps, m->lm_head, m->V, H, m->logits, m->blk_val,
+                              m->blk_idx, m->lm_grid), "dec lm_head");
+        VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters,
+                              m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VH_E_HIP, "decode: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
+}  // extern "C"

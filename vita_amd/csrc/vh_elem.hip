@@ -1,0 +1,387 @@
+// vh_elem.hip — HBM-bound row / index kernels around the GEMMs (SURVEY §2.4 K1-K3, K8,
+// K11-K13, K18-K20, K22, K25).  All fp32 activations; small parameters (norm weights,
+// biases) are fp32 arrays holding bf16-representable values, large tables are bf16.
+#include "vh_common.h"
+#include "vh_kernels.h"
+
+namespace {
+
+// ---- LayerNorm / RMSNorm: one wave per row, row cached in registers -------------------
+// torch.nn.LayerNorm semantics (biased variance).  Optional activation and post-scale
+// fuse Whale's embed tail  Linear -> LN -> ReLU -> x*sqrt(d)  (transformer.py:312-318,
+// attention.py:108-111) and the adapter's LN -> GELU (adapter.py:128-133).
+#define LN_MAXV 16  // float4 per lane -> cols <= 4096
+template <bool RMS>
+__global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                   long ldy, const float* __restrict__ w,
+                                                   const float* __restrict__ b, int rows, int cols, float eps,
+                                                   int act, float post_scale) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) { v[i] = xp[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mean = 0.f;
+    if (!RMS) mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, bq = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + bq * bq) + (cq * cq + d * d);
+        }
+    }
+    const float inv = rsqrtf(wave_sum(q) / (float)cols + eps);
+    float4* yp = reinterpret_cast<float4*>(y + (size_t)row * ldy);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            float4 r;
+            r.x = (v[i].x - mean) * inv * ww.x; r.y = (v[i].y - mean) * inv * ww.y;
+            r.z = (v[i].z - mean) * inv * ww.z; r.w = (v[i].w - mean) * inv * ww.w;
+            if (b) {
+                const float4 bb = reinterpret_cast<const float4*>(b)[c];
+                r.x += bb.x; r.y += bb.y; r.z += bb.z; r.w += bb.w;
+            }
+            if (act != VH_ACT_NONE) {
+                r.x = apply_act(r.x, act); r.y = apply_act(r.y, act);
+                r.z = apply_act(r.z, act); r.w = apply_act(r.w, act);
+            }
+            r.x *= post_scale; r.y *= post_scale; r.z *= post_scale; r.w *= post_scale;
+            yp[c] = r;
+        }
+    }
+}
+
+__global__ void k_add(float* __restrict__ x, const float* __restrict__ y, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<float4*>(x)[i];
+        const float4 b = reinterpret_cast<const float4*>(y)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(x)[i] = a;
+    }
+}
+
+__global__ void k_cast_bf16_f32(const uint16_t* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = bf16_to_f32(in[i]);
+}
+
+// ---- InternViT front/back ends --------------------------------------------------------
+// patchify: conv 14x14 stride 14 as a GEMM row: out[(img,py,px), c*P*P + ky*P + kx]
+// (modeling_intern_vit.py:80-85,109-111); columns >= 3*P*P are zero padding (K % 64).
+__global__ void k_vit_patchify(const float* __restrict__ pix, float* __restrict__ out, int n, int img, int patch,
+                               int kpad) {
+    const int g = img / patch;
+    const long total = (long)n * g * g * kpad;
+    const int kk = 3 * patch * patch;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kpad);
+        const long row = i / kpad;
+        float v = 0.f;
+        if (k < kk) {
+            const int c = k / (patch * patch), rem = k % (patch * patch);
+            const int ky = rem / patch, kx = rem % patch;
+            const int px = (int)(row % g), py = (int)((row / g) % g), im = (int)(row / ((long)g * g));
+            v = pix[(((long)im * 3 + c) * img + (py * patch + ky)) * img + px * patch + kx];
+        }
+        out[i] = v;
+    }
+}
+
+// embeddings = cat([cls, patch_embeds]) + position_embedding (modeling_intern_vit.py:112-121;
+// the bicubic pos-embed resize is the identity at 448/14 = the trained 32x32 grid).
+__global__ void k_vit_assemble(const float* __restrict__ patches, const uint16_t* __restrict__ cls,
+                               const uint16_t* __restrict__ pos, float* __restrict__ x, int n, int ntok, int hid) {
+    const long total = (long)n * ntok * hid;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % hid);
+        const int t = (int)((i / hid) % ntok);
+        const long im = i / ((long)hid * ntok);
+        const float base = (t == 0) ? bf16_to_f32(cls[c]) : patches[((long)im * (ntok - 1) + (t - 1)) * hid + c];
+        x[i] = base + bf16_to_f32(pos[(long)t * hid + c]);
+    }
+}
+
+// drop CLS, x0.5, pixel_shuffle(0.5): out[n, a*g2+b, e] = mul * x[n, 1 + d1*g + d2, c] with
+// d1 = 2a + e/(2C), d2 = 2b + (e%(2C))/C, c = e%C   (internvit_encoder.py:35-53,71-77)
+__global__ void k_vit_pixel_shuffle(const float* __restrict__ x, float* __restrict__ out, int n, int g, int C,
+                                    float mul) {
+    const int g2 = g / 2;
+    const long total = (long)n * g2 * g2 * 4 * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % (4 * C));
+        const long t = i / (4 * C);
+        const int bb = (int)(t % g2), a = (int)((t / g2) % g2);
+        const long im = t / ((long)g2 * g2);
+        const int d1 = 2 * a + e / (2 * C), d2 = 2 * bb + (e % (2 * C)) / C, c = e % C;
+        out[i] = mul * x[((long)im * (g * g + 1) + 1 + d1 * g + d2) * C + c];
+    }
+}
+
+// ---- Whale front end: GlobalCMVN + Conv2d(1,C,3,2) + ReLU, channels-last output ---------
+// out[t1, f1, c] = relu(b[c] + sum_{kh,kw} w[c,kh,kw] * ((x[2t1+kh, 2f1+kw] - mean)*istd))
+// (cmvn.py:29-32, subsampling.py:28-31)
+__global__ void k_audio_conv1(const float* __restrict__ feats, const float* __restrict__ mean,
+                              const float* __restrict__ istd, const uint16_t* __restrict__ w,
+                              const float* __restrict__ b, float* __restrict__ out, int T, int F, int C) {
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const long total = (long)T1 * F1 * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int f1 = (int)((i / C) % F1);
+        const int t1 = (int)(i / ((long)C * F1));
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int f = 2 * f1 + kw;
+                const float xv = (feats[(long)(2 * t1 + kh) * F + f] - mean[f]) * istd[f];
+                acc = fmaf(bf16_to_f32(w[c * 9 + kh * 3 + kw]), xv, acc);
+            }
+        out[i] = fmaxf(acc + b[c], 0.f);
+    }
+}
+
+// ---- Mixtral prefill: rotate-half RoPE on q,k and KV-cache write ------------------------
+// qkv rows: [q (nq*128) | k (nkv*128) | v (nkv*128)]; token s sits at position pos0+s.
+__global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __restrict__ q_out,
+                          float* __restrict__ kcache, float* __restrict__ vcache,
+                          const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int S, int pos0,
+                          int nq, int nkv, int max_ctx) {
+    const int nh = nq + 2 * nkv;
+    const long total = (long)S * nh * 64;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i & 63);
+        const int hh = (int)((i >> 6) % nh);
+        const int s = (int)(i / ((long)nh * 64));
+        const int pos = pos0 + s;
+        const float* src = qkv + (size_t)s * ldqkv + hh * 128;
+        const float a = src[d], bq = src[d + 64];
+        if (hh < nq + nkv) {
+            const float c = rope_cos[(size_t)pos * 64 + d], sn = rope_sin[(size_t)pos * 64 + d];
+            const float ra = a * c - bq * sn, rb = bq * c + a * sn;
+            float* dst = (hh < nq) ? (q_out + ((size_t)s * nq + hh) * 128)
+                                   : (kcache + ((size_t)(hh - nq) * max_ctx + pos) * 128);
+            dst[d] = ra; dst[d + 64] = rb;
+        } else {
+            float* dst = vcache + ((size_t)(hh - nq - nkv) * max_ctx + pos) * 128;
+            dst[d] = a; dst[d + 64] = bq;
+        }
+    }
+}
+
+// ---- embedding gather + multimodal splice (vita_arch.py:237-321) ------------------------
+// host builds, per destination row, kind (0 text / 1 image / 2 audio) and source index.
+__global__ __launch_bounds__(256) void k_embed_splice(const int* __restrict__ kind, const int* __restrict__ idx,
+                                                      const uint16_t* __restrict__ embed,
+                                                      const float* __restrict__ img, const float* __restrict__ aud,
+                                                      float* __restrict__ out, int S, int H) {
+    const int r = blockIdx.x;
+    if (r >= S) return;
+    const int k = kind[r];
+    const long src = idx[r];
+    float* dst = out + (size_t)r * H;
+    if (k == 0) {
+        for (int c = threadIdx.x; c < H; c += 256) dst[c] = bf16_to_f32(embed[src * H + c]);
+    } else {
+        const float* sp = (k == 1 ? img : aud) + src * H;
+        for (int c = threadIdx.x; c < H; c += 256) dst[c] = sp[c];
+    }
+}
+
+// ---- MoE routing for S tokens (modeling_mixtral.py:96-111): one wave per token ----------
+__global__ __launch_bounds__(256) void k_moe_route(const float* __restrict__ xn, const uint16_t* __restrict__ Wg,
+                                                   int S, int H, int E, int* __restrict__ ids,
+                                                   float* __restrict__ wts) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wid;
+    if (s >= S) return;
+    float lg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lg[e] = 0.f;
+    const float* xr = xn + (size_t)s * H;
+    for (int c = lane; c * 8 < H; c += 64) {
+        float xv[8];
+        const float4 a = reinterpret_cast<const float4*>(xr)[c * 2], bq = reinterpret_cast<const float4*>(xr)[c * 2 + 1];
+        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = bq.x; xv[5] = bq.y; xv[6] = bq.z; xv[7] = bq.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < E) lg[e] += dot8_bf16_f32(reinterpret_cast<const uint4*>(Wg + (size_t)e * H)[c], xv);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lg[e] = wave_sum(lg[e]);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
+    float pr[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
+    int e0 = 0, e1 = 0;
+    float b0 = -1.f, b1 = -1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] /= sum; if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; } }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
+    if (lane == 0) {
+        const float t = b0 + b1;
+        ids[s * 2] = e0; ids[s * 2 + 1] = e1;
+        wts[s * 2] = b0 / t; wts[s * 2 + 1] = b1 / t;
+    }
+}
+
+// counting sort of the 2S (token, slot) entries by expert: wave e owns expert e.
+// sorted order inside an expert is ascending entry index -> deterministic.
+__global__ void k_moe_sort(const int* __restrict__ ids, int S, int E, int* __restrict__ group_off,
+                           int* __restrict__ sorted_tok, int* __restrict__ sorted_slot) {
+    __shared__ int cnt[8];
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int n = 2 * S;
+    int c = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool f = (i < n) && (ids[i] == e);
+        c += __popcll(__ballot(f));
+    }
+    if (lane == 0) cnt[e] = c;
+    __syncthreads();
+    int base = 0;
+    for (int j = 0; j < e; ++j) base += cnt[j];
+    if (lane == 0) {
+        group_off[e] = base;
+        if (e == E - 1) group_off[E] = base + c;
+    }
+    int run = base;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool f = (i < n) && (ids[i] == e);
+        const unsigned long long bal = __ballot(f);
+        if (f) {
+            const int p = run + __popcll(bal & ((1ull << lane) - 1ull));
+            sorted_tok[p] = i >> 1;
+            sorted_slot[p] = i;
+        }
+        run += __popcll(bal);
+    }
+}
+
+// x[s,:] += w0*y[2s,:] + w1*y[2s+1,:]   (MixtralExperts index_add_, modeling_mixtral.py:85-93)
+__global__ void k_moe_combine(float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ wts,
+                              int S, int H) {
+    const long total = (long)S * (H / 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / (H / 4);
+        const int c = (int)(i % (H / 4));
+        const float w0 = wts[s * 2], w1 = wts[s * 2 + 1];
+        float4 a = reinterpret_cast<float4*>(x + s * H)[c];
+        const float4 y0 = reinterpret_cast<const float4*>(y + (2 * s) * H)[c];
+        const float4 y1 = reinterpret_cast<const float4*>(y + (2 * s + 1) * H)[c];
+        a.x += w0 * y0.x + w1 * y1.x; a.y += w0 * y0.y + w1 * y1.y;
+        a.z += w0 * y0.z + w1 * y1.z; a.w += w0 * y0.w + w1 * y1.w;
+        reinterpret_cast<float4*>(x + s * H)[c] = a;
+    }
+}
+
+inline int grid_for(long total, int block) {
+    long g = (total + block - 1) / block;
+    if (g > 4096) g = 4096;  // grid-stride beyond ~16 blocks/CU (guide G11)
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+int vhk_layernorm(hipStream_t st, const float* x, long ldx, float* y, long ldy, const float* w, const float* b,
+                  int rows, int cols, float eps, int act, float post_scale) {
+    if (cols % 4 != 0 || cols > LN_MAXV * 256) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_norm_rows<false>, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, y, ldy, w, b, rows, cols,
+                       eps, act, post_scale);
+    return 0;
+}
+int vhk_rmsnorm(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps) {
+    if (cols % 4 != 0 || cols > LN_MAXV * 256) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_norm_rows<true>, dim3((rows + 3) / 4), dim3(256), 0, st, x, (long)cols, y, (long)cols, w,
+                       (const float*)nullptr, rows, cols, eps, VH_ACT_NONE, 1.0f);
+    return 0;
+}
+int vhk_add(hipStream_t st, float* x, const float* y, long n) {
+    if (n % 4 != 0) return -1;
+    hipLaunchKernelGGL(k_add, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, x, y, n / 4);
+    return 0;
+}
+int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n) {
+    hipLaunchKernelGGL(k_cast_bf16_f32, dim3(grid_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return 0;
+}
+int vhk_vit_patchify(hipStream_t st, const float* pix, float* out, int n, int img, int patch, int kpad) {
+    if (img % patch != 0 || kpad < 3 * patch * patch) return -1;
+    const int g = img / patch;
+    hipLaunchKernelGGL(k_vit_patchify, dim3(grid_for((long)n * g * g * kpad, 256)), dim3(256), 0, st, pix, out, n, img,
+                       patch, kpad);
+    return 0;
+}
+int vhk_vit_assemble(hipStream_t st, const float* patches, const uint16_t* cls, const uint16_t* pos, float* x, int n,
+                     int ntok, int hid) {
+    hipLaunchKernelGGL(k_vit_assemble, dim3(grid_for((long)n * ntok * hid, 256)), dim3(256), 0, st, patches, cls, pos,
+                       x, n, ntok, hid);
+    return 0;
+}
+int vhk_vit_pixel_shuffle(hipStream_t st, const float* x, float* out, int n, int grid, int hid, float mul) {
+    if (grid % 2 != 0) return -1;
+    hipLaunchKernelGGL(k_vit_pixel_shuffle, dim3(grid_for((long)n * (grid / 2) * (grid / 2) * 4 * hid, 256)),
+                       dim3(256), 0, st, x, out, n, grid, hid, mul);
+    return 0;
+}
+int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const float* istd, const uint16_t* w,
+                    const float* b, float* out, int T, int F, int C) {
+    if (T < 3 || F < 3) return -1;
+    const long total = (long)((T - 3) / 2 + 1) * ((F - 3) / 2 + 1) * C;
+    hipLaunchKernelGGL(k_audio_conv1, dim3(grid_for(total, 256)), dim3(256), 0, st, feats, mean, istd, w, b, out, T, F,
+                       C);
+    return 0;
+}
+int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
+                const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx) {
+    if (S == 0) return 0;
+    hipLaunchKernelGGL(k_rope_kv, dim3(grid_for((long)S * (nq + 2 * nkv) * 64, 256)), dim3(256), 0, st, qkv, ldqkv,
+                       q_out, kcache, vcache, rope_cos, rope_sin, S, pos0, nq, nkv, max_ctx);
+    return 0;
+}
+int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
+                     const float* img_feats, const float* aud_feats, float* out, int S, int H) {
+    if (S == 0) return 0;
+    hipLaunchKernelGGL(k_embed_splice, dim3(S), dim3(256), 0, st, src_kind, src_idx, embed, img_feats, aud_feats, out,
+                       S, H);
+    return 0;
+}
+int vhk_moe_route(hipStream_t st, const float* xn, const uint16_t* Wg, int S, int H, int E, int* ids, float* wts) {
+    if (E > 8 || E < 2 || H % 8 != 0) return -1;
+    if (S == 0) return 0;
+    hipLaunchKernelGGL(k_moe_route, dim3((S + 3) / 4), dim3(256), 0, st, xn, Wg, S, H, E, ids, wts);
+    return 0;
+}
+int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot) {
+    if (E > 8) return -1;
+    hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(64 * E), 0, st, ids, S, E, group_off, sorted_tok, sorted_slot);
+    return 0;
+}
+int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H) {
+    if (H % 4 != 0) return -1;
+    if (S == 0) return 0;
+    hipLaunchKernelGGL(k_moe_combine, dim3(grid_for((long)S * (H / 4), 256)), dim3(256), 0, st, x, y, wts, S, H);
+    return 0;
+}

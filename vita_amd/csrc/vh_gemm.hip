@@ -1,0 +1,216 @@
+// vh_gemm.hip — the multi-row GEMM workhorse (SURVEY §2.4 K1,K4,K6,K7,K9,K12,K13,K16,K17,
+// K21,K24,K26-prefill): C = epilogue(A · W^T) with fp32 activations A, bf16 weights W.
+//
+// MFMA: v_mfma_f32_16x16x32_bf16.  The fp32 activation tile is split once, while it is
+// staged into LDS, into hi = bf16(a) and lo = bf16(a - hi); each weight fragment is then
+// used by two MFMAs (hi and lo) accumulating into the same fp32 tile, i.e. the GEMM sees
+// 16 mantissa bits of A at the cost of 2x matrix-core work and no extra weight traffic.
+// (Prefill at S<~1000 and the encoders are weight-read/latency bound before they are
+// MFMA bound, so this buys fp32-oracle parity for little wall time.)
+//
+// Tile: 256 threads = 4 waves (2 along M x 2 along N); block tile 64(M) x 128(N) x 64(K);
+// wave tile 32 x 64 = 2x4 MFMA tiles (8 accumulators).  LDS rows are 128 B (64 bf16) with
+// the 16-byte chunk index XOR-swizzled by (row>>1)&7 so that every ds_read_b128 lane group
+// (rows {0-3,12-15} at chunk c and rows {4-11} at chunk c^1) hits 16 distinct 16-B slots.
+// Global->LDS is register staged and issued one K-tile ahead of the MFMAs.
+//
+// A addressing is generalised so convolutions and the MoE gather need no im2col copy:
+//   source row(m, k) = a_rowidx[m] (or m) + segrow[k / seglen],  column = k % seglen.
+// Grouped mode (top-2 MoE): rows are pre-sorted by expert, group_off[e..e+1] bounds expert
+// e's rows and W advances by w_group_stride per expert; blockIdx.y enumerates (expert,
+// m-tile) pairs on device so no host sync is needed to size the launch.
+#include "vh_common.h"
+#include "vh_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+#define GM_BM 64
+#define GM_BN 128
+#define GM_BK 64
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset in a [rows][128 B] tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <bool GLU>
+__global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_ahi[GM_BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_alo[GM_BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_w[GM_BN * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 1, wn = wid >> 1;
+    constexpr int NT = GLU ? 64 : 128;  // output columns per block
+
+    // ---- which (group, m-tile) is this block? -------------------------------------
+    int m_begin, m_end;
+    const uint16_t* Wb = p.W;
+    const uint16_t* Wu = p.W_up;
+    if (p.group_off) {
+        int tile = blockIdx.y, e = 0;
+        for (; e < p.ngroups; ++e) {
+            const int cnt = p.group_off[e + 1] - p.group_off[e];
+            const int nt = (cnt + GM_BM - 1) / GM_BM;
+            if (tile < nt) break;
+            tile -= nt;
+        }
+        if (e == p.ngroups) return;
+        m_begin = p.group_off[e] + tile * GM_BM;
+        m_end = p.group_off[e + 1];
+        Wb += (size_t)e * p.w_group_stride;
+        if (GLU) Wu += (size_t)e * p.w_group_stride;
+    } else {
+        m_begin = blockIdx.y * GM_BM;
+        m_end = p.M;
+        if (m_begin >= m_end) return;
+    }
+    const int n_begin = blockIdx.x * NT;
+
+    // ---- staging assignments -------------------------------------------------------
+    const int arow = tid >> 2, achunk0 = (tid & 3) * 2;  // 16 floats = 2 chunks
+    const int am = m_begin + arow;
+    const bool a_valid_m = am < m_end;
+    const int a_src = a_valid_m ? (p.a_rowidx ? p.a_rowidx[am] : am) : 0;
+
+    const int wrow = tid >> 1, wchunk0 = (tid & 1) * 4;  // 32 bf16 = 4 chunks
+    const uint16_t* wptr;
+    bool w_valid;
+    if (GLU) {
+        const int n = n_begin + (wrow & 63);
+        w_valid = n < p.N;
+        wptr = ((wrow < 64) ? Wb : Wu) + (size_t)(w_valid ? n : 0) * p.ldw + wchunk0 * 8;
+    } else {
+        const int n = n_begin + wrow;
+        w_valid = n < p.N;
+        wptr = Wb + (size_t)(w_valid ? n : 0) * p.ldw + wchunk0 * 8;
+    }
+
+    float4 ra[4];
+    uint4 rw[4];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * GM_BK;
+        const int seg = k0 / p.seglen;
+        const int koff = k0 - seg * p.seglen;
+        const int srow = a_src + p.segrow[seg];
+        if (a_valid_m && srow >= 0 && srow < p.a_rows) {
+            const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)srow * p.lda + koff + achunk0 * 8);
+            ra[0] = ap[0]; ra[1] = ap[1]; ra[2] = ap[2]; ra[3] = ap[3];
+        } else {
+            ra[0] = ra[1] = ra[2] = ra[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (w_valid) {
+            const uint4* wp = reinterpret_cast<const uint4*>(wptr + k0);
+            rw[0] = wp[0]; rw[1] = wp[1]; rw[2] = wp[2]; rw[3] = wp[3];
+        } else {
+            rw[0] = rw[1] = rw[2] = rw[3] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
+            const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_bf16(v[i], hi[i], lo[i]);
+            const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
+                                        hi[6] | (hi[7] << 16));
+            const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
+                                        lo[6] | (lo[7] << 16));
+            const int off = lds_off(arow, achunk0 + c);
+            *reinterpret_cast<uint4*>(lds_ahi + off) = ph;
+            *reinterpret_cast<uint4*>(lds_alo + off) = pl;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / GM_BK;
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();  // previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + (lane >> 4);
+            bf16x8_t ah[2], al[2], bw[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = lds_off(wm * 32 + i * 16 + (lane & 15), chunk);
+                ah[i] = *reinterpret_cast<const bf16x8_t*>(lds_ahi + off);
+                al[i] = *reinterpret_cast<const bf16x8_t*>(lds_alo + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int r;
+                if (GLU) r = (j < 2) ? (wn * 32 + j * 16) : (64 + wn * 32 + (j - 2) * 16);
+                else r = wn * 64 + j * 16;
+                bw[j] = *reinterpret_cast<const bf16x8_t*>(lds_w + lds_off(r + (lane & 15), chunk));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bw[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bw[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: D layout col = lane&15, row = (lane>>4)*4 + r ---------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_begin + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+            if (m >= m_end) continue;
+            const long orow = p.c_rowidx ? p.c_rowidx[m] : m;
+            if (GLU) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n_begin + wn * 32 + j * 16 + (lane & 15);
+                    if (n < p.N) p.C[orow * p.ldc + n] = silu_f(acc[i][j][r]) * acc[i][j + 2][r];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_begin + wn * 64 + j * 16 + (lane & 15);
+                    if (n < p.N) {
+                        float v = acc[i][j][r];
+                        if (p.bias) v += p.bias[n];
+                        v = apply_act(v, p.act);
+                        if (p.scale) v *= p.scale[n];
+                        if (p.resid) v += p.resid[orow * p.ldr + n];
+                        p.C[orow * p.ldc + n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
+    if (a.K <= 0 || a.K % GM_BK != 0 || a.nseg < 1 || a.nseg > 16 || a.seglen % GM_BK != 0 ||
+        a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0)
+        return -1;
+    if (a.M == 0) return 0;
+    const int mt = (a.M + GM_BM - 1) / GM_BM + (a.group_off ? a.ngroups : 0);
+    if (a.W_up) {
+        hipLaunchKernelGGL(k_gemm<true>, dim3((a.N + 63) / 64, mt), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_gemm<false>, dim3((a.N + GM_BN - 1) / GM_BN, mt), dim3(256), 0, st, a);
+    }
+    return 0;
+}

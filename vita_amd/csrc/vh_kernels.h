@@ -1,0 +1,76 @@
+// vh_kernels.h — internal launcher declarations (one per kernel family).  The public
+// C ABI in include/vita_hip.h is a thin, argument-checking layer over these.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+// ---- decode (vh_decode.hip) ---------------------------------------------------------
+int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
+                const uint16_t* W, int N, int K, float* out);
+int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
+                 const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int nq, int nkv,
+                 int max_ctx, int nsplit, float scale);
+int vhk_dec_oproj(hipStream_t st, const float* part_o, const float* part_ml, int nsplit, const uint16_t* W, int N,
+                  int K, float* out);
+int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
+                   const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
+                   float* hbuf, int grid);
+int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out);
+int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
+                   const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid);
+int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
+                   float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
+
+// ---- GEMM (vh_gemm.hip) -------------------------------------------------------------
+// C[orow(m), n] = epilogue( sum_k A[arow(m,k), k] * W[n, k] )
+//   A fp32, W bf16 [N][K] (torch Linear layout), C fp32.  K % 64 == 0.
+struct VhGemmArgs {
+    const float* A; long lda; int a_rows;     // a_rows: source rows outside [0,a_rows) read as zero
+    const int* a_rowidx;                      // nullable: source row of logical row m (else m)
+    int nseg, seglen; int segrow[16];         // K = nseg*seglen; segment s reads source row + segrow[s]
+    const uint16_t* W; const uint16_t* W_up;  // W_up != null => GLU: out = silu(A W^T) * (A W_up^T)
+    long ldw; long w_group_stride;
+    const int* group_off; int ngroups;        // nullable; device int[ngroups+1] row offsets (grouped GEMM)
+    float* C; long ldc; const int* c_rowidx;  // nullable output row map
+    const float* bias; const float* scale; const float* resid; long ldr;
+    int M, N, K, act;
+};
+int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
+
+// ---- attention (vh_attn.hip) --------------------------------------------------------
+struct VhAttnArgs {
+    const float* Q; long ldq; long hsq;   // Q[(b*Sq + q)*ldq + h*hsq + d]   (b strides below)
+    const float* K; long ldk; long hsk;
+    const float* V; long ldv; long hsv;
+    const float* P; long ldp; long hsp;   // rel-pos keys (audio), nullable
+    const float* bias_u; const float* bias_v;  // [H][d], nullable (rel-pos)
+    float* O; long ldo;                   // O[(b*Sq + q)*ldo + h*d + dd]
+    long bsq, bsk, bso;                   // batch strides in elements for Q / K,V / O
+    int B, Hq, Hkv, Sq, Sk, d;
+    int causal; int q_off;                // causal: key <= q + q_off visible
+    int klen;                             // keys >= klen are masked (pad mask); use Sk for none
+    int chunk, left;                      // chunk>0: whale chunk mask (utils.py:88-103); left<0 = all left chunks
+    float scale;
+};
+int vhk_attn(hipStream_t st, const VhAttnArgs& a);
+
+// ---- element-wise / index kernels (vh_elem.hip) -------------------------------------
+int vhk_layernorm(hipStream_t st, const float* x, long ldx, float* y, long ldy, const float* w, const float* b,
+                  int rows, int cols, float eps, int act, float post_scale);
+int vhk_rmsnorm(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps);
+int vhk_add(hipStream_t st, float* x, const float* y, long n);
+int vhk_vit_patchify(hipStream_t st, const float* pix, float* out, int n, int img, int patch, int kpad);
+int vhk_vit_assemble(hipStream_t st, const float* patches, const uint16_t* cls, const uint16_t* pos, float* x, int n,
+                     int ntok, int hid);
+int vhk_vit_pixel_shuffle(hipStream_t st, const float* x, float* out, int n, int grid, int hid, float mul);
+int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const float* istd, const uint16_t* w,
+                    const float* b, float* out, int T, int F, int C);
+int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
+                const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx);
+int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
+                     const float* img_feats, const float* aud_feats, float* out, int S, int H);
+int vhk_moe_route(hipStream_t st, const float* xn, const uint16_t* Wg, int S, int H, int E, int* ids, float* wts);
+int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot);
+int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H);
+int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n);

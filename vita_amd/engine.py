@@ -1,0 +1,129 @@
+"""MixtralEngine — host handle of the C-side Mixtral engine (vh_mixtral_* in include/vita_hip.h).
+
+Owns the packed weights, the caller-provided workspace (KV cache + scratch) and the RoPE
+tables; `prefill()` and `decode()` each enqueue a whole forward with one C call."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MixtralCfg, MixtralLayer, check
+from .config import VitaConfig
+
+
+def rope_tables(max_pos, head_dim, theta):
+    """cos/sin of pos * inv_freq in fp32, inv_freq = theta^(-2i/d) — HF MixtralRotaryEmbedding
+    (modeling_mixtral.py:154-201), computed once on the host."""
+    inv_freq = (1.0 / (np.float32(theta) ** (np.arange(0, head_dim, 2, dtype=np.float32) / np.float32(head_dim))))
+    inv_freq = inv_freq.astype(np.float32)
+    freqs = np.arange(max_pos, dtype=np.float32)[:, None] * inv_freq[None, :]
+    return np.cos(freqs).astype(np.float32), np.sin(freqs).astype(np.float32)
+
+
+class MixtralEngine:
+    def __init__(self, cfg: VitaConfig, packed, device, max_ctx=None, max_prefill=None, max_new=1024, rank=0,
+                 world=1, nsplit=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.VitaHipError("MixtralEngine needs a GPU (no CPU fallback)")
+        t = cfg.text
+        self.cfg, self.device, self.packed = cfg, device, packed
+        max_prefill = max_prefill or cfg.tokenizer_model_max_length
+        max_ctx = max_ctx or (max_prefill + max_new + 1)
+        self.max_ctx, self.max_prefill, self.max_new = max_ctx, max_prefill, max_new
+        lay0 = packed["layers"][0]
+        nq = (lay0["wqkv"].shape[0] // t.head_dim) * t.num_attention_heads // (
+            t.num_attention_heads + 2 * t.num_key_value_heads)
+        nkv = nq * t.num_key_value_heads // t.num_attention_heads
+        c = MixtralCfg()
+        c.hidden, c.n_layers, c.n_q_heads, c.n_kv_heads = t.hidden_size, t.num_hidden_layers, nq, nkv
+        c.head_dim, c.inter, c.n_experts, c.top_k = t.head_dim, lay0["w1"].shape[1], t.num_local_experts, t.num_experts_per_tok
+        c.vocab, c.rms_eps = t.vocab_size, t.rms_norm_eps
+        c.max_ctx, c.max_prefill, c.max_new = max_ctx, max_prefill, max_new
+        c.tp_rank, c.tp_world, c.nsplit = rank, world, nsplit
+        self.c = c
+        nbytes = self.lib.vh_mixtral_workspace_bytes(C.byref(c))
+        if nbytes == 0:
+            check(-1, "vh_mixtral_workspace_bytes")
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        cos, sin = rope_tables(max_ctx, t.head_dim, t.rope_theta)
+        self.rope_cos = torch.from_numpy(cos).to(device)
+        self.rope_sin = torch.from_numpy(sin).to(device)
+        layers = (MixtralLayer * t.num_hidden_layers)()
+        for i, L in enumerate(packed["layers"]):
+            for f, _ in MixtralLayer._fields_:
+                setattr(layers[i], f, L[f].data_ptr())
+        self._layers = layers
+        self.h = self.lib.vh_mixtral_create(C.byref(c), layers, packed["embed"].data_ptr(),
+                                            packed["final_norm"].data_ptr(), packed["lm_head"].data_ptr(),
+                                            self.rope_cos.data_ptr(), self.rope_sin.data_ptr(),
+                                            self.workspace.data_ptr(), nbytes)
+        if not self.h:
+            check(-1, "vh_mixtral_create")
+        self._ar_cb = None
+        self._tok_ptr = self.lib.vh_mixtral_tokens(self.h)
+        self._cnt_ptr = self.lib.vh_mixtral_counters(self.h)
+        self._logit_ptr = self.lib.vh_mixtral_logits(self.h)
+        # zero-copy views of the engine state living inside the workspace
+        base = self.workspace.data_ptr()
+        self.tokens = self.workspace[self._tok_ptr - base: self._tok_ptr - base + 4 * max(max_new, 1)].view(torch.int32)
+        self.counters = self.workspace[self._cnt_ptr - base: self._cnt_ptr - base + 8].view(torch.int32)
+        self.logits = self.workspace[self._logit_ptr - base: self._logit_ptr - base + 4 * t.vocab_size].view(
+            torch.float32)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vh_mixtral_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tensor parallel ---------------------------------------------------------------------
+    def use_rccl(self, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        check(self.lib.vh_mixtral_init_rccl(self.h, buf), "vh_mixtral_init_rccl")
+
+    def use_torch_allreduce(self, group=None):
+        """Fallback collective: torch.distributed.all_reduce (RCCL under backend 'nccl', gloo on CPU
+        tests) called back from the C layer loop."""
+        import torch.distributed as dist
+        base, ws = self.workspace.data_ptr(), self.workspace
+
+        def cb(_user, ptr, count, _stream):
+            t = ws[ptr - base: ptr - base + 4 * count].view(torch.float32)
+            dist.all_reduce(t, group=group)
+            return 0
+
+        self._ar_cb = _lib.ALLREDUCE_FN(cb)
+        check(self.lib.vh_mixtral_set_allreduce(self.h, self._ar_cb, None), "vh_mixtral_set_allreduce")
+
+    # ---- forward -----------------------------------------------------------------------------
+    def prefill(self, embeds, pos0=0, want_hidden=False):
+        """embeds fp32 [S, hidden] on device.  Returns (logits_of_last_pos view, hidden_dbg or None)."""
+        if embeds.dtype != torch.float32 or not embeds.is_cuda:
+            raise TypeError("embeds must be a float32 GPU tensor")
+        embeds = embeds.contiguous()
+        S = embeds.shape[0]
+        hid = None
+        if want_hidden:
+            hid = torch.empty((self.c.n_layers, S, self.c.hidden), dtype=torch.float32, device=self.device)
+        check(self.lib.vh_mixtral_prefill(self.h, embeds.data_ptr(), S, pos0, None,
+                                          hid.data_ptr() if hid is not None else None, self._stream()),
+              "vh_mixtral_prefill")
+        return self.logits, hid
+
+    def decode(self, n_steps):
+        check(self.lib.vh_mixtral_decode(self.h, int(n_steps), self._stream()), "vh_mixtral_decode")
+
+    def generated(self):
+        """(synchronising) list of token ids generated so far."""
+        n = int(self.counters[1].item())
+        return self.tokens[:min(n, self.max_new)].tolist()

@@ -1,0 +1,156 @@
+"""Thin torch-tensor front end over the C ABI.  torch is plumbing here (device memory, current
+stream); every computation is a HIP kernel in libvita_hip.so.  All operators require CUDA
+(ROCm) tensors and raise otherwise — there is deliberately no CPU path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, GemmArgs, check
+
+ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "silu": 3}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VitaHipError("vita_amd operators need GPU tensors (no CPU fallback)")
+
+
+def _f32(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t
+
+
+def _bf16(t, name="weight"):
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name} must be bfloat16, got {t.dtype}")
+    return t
+
+
+def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=None, a_rowidx=None, a_rows=None,
+         segrow=None, seglen=None, m=None, c_rowidx=None, group_off=None, ngroups=0, w_group_stride=0, lda=None,
+         ldc=None):
+    """out[orow(m), :] = epilogue(A[arow(m, k)] @ w.T).  a: fp32 [rows, lda]; w: bf16 [N, K] (or [E, N, K] grouped)."""
+    _dev(a, w, out)
+    _f32(a, "a"); _bf16(w, "w")
+    lib = _lib.load()
+    g = GemmArgs()
+    N, K = int(w.shape[-2]), int(w.shape[-1])
+    g.A = a.data_ptr(); g.lda = int(lda if lda is not None else a.stride(0))
+    g.a_rows = int(a_rows if a_rows is not None else a.shape[0])
+    g.a_rowidx = a_rowidx.data_ptr() if a_rowidx is not None else None
+    if segrow is None:
+        g.nseg, g.seglen = 1, K
+        g.segrow[0] = 0
+    else:
+        g.nseg, g.seglen = len(segrow), int(seglen)
+        for i, v in enumerate(segrow):
+            g.segrow[i] = int(v)
+    g.W = w.data_ptr(); g.W_up = w_up.data_ptr() if w_up is not None else None
+    g.ldw = K; g.w_group_stride = int(w_group_stride)
+    g.group_off = group_off.data_ptr() if group_off is not None else None
+    g.ngroups = int(ngroups)
+    M = int(m if m is not None else (a_rowidx.shape[0] if a_rowidx is not None else a.shape[0]))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    g.C = out.data_ptr(); g.ldc = int(ldc if ldc is not None else out.stride(0))
+    g.c_rowidx = c_rowidx.data_ptr() if c_rowidx is not None else None
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.scale = scale.data_ptr() if scale is not None else None
+    if resid is not None:
+        g.resid = resid.data_ptr(); g.ldr = int(resid.stride(0))
+    g.M, g.N, g.K, g.act = M, N, K, ACT[act]
+    check(lib.vh_gemm(C.byref(g), _stream()), "vh_gemm")
+    return out
+
+
+def attention(q, k, v, out, *, B, Hq, Hkv, Sq, Sk, d, ldq, hsq, ldk, hsk, ldv, hsv, ldo, bsq=0, bsk=0, bso=0, scale,
+              causal=False, q_off=0, klen=None, chunk=0, left=-1, p=None, ldp=0, hsp=0, bias_u=None, bias_v=None):
+    _dev(q, k, v, out)
+    lib = _lib.load()
+    a = AttnArgs()
+    a.Q, a.ldq, a.hsq = q.data_ptr(), ldq, hsq
+    a.K, a.ldk, a.hsk = k.data_ptr(), ldk, hsk
+    a.V, a.ldv, a.hsv = v.data_ptr(), ldv, hsv
+    if p is not None:
+        a.P, a.ldp, a.hsp = p.data_ptr(), ldp, hsp
+        a.bias_u, a.bias_v = bias_u.data_ptr(), bias_v.data_ptr()
+    a.O, a.ldo = out.data_ptr(), ldo
+    a.bsq, a.bsk, a.bso = bsq, bsk, bso
+    a.B, a.Hq, a.Hkv, a.Sq, a.Sk, a.d = B, Hq, Hkv, Sq, Sk, d
+    a.causal, a.q_off = int(causal), q_off
+    a.klen = Sk if klen is None else int(klen)
+    a.chunk, a.left = int(chunk), int(left)
+    a.scale = float(scale)
+    check(lib.vh_attention(C.byref(a), _stream()), "vh_attention")
+    return out
+
+
+def layernorm(x, w, b, eps, *, act=None, post_scale=1.0, out=None):
+    _dev(x, w)
+    rows, cols = x.shape[0], x.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().vh_layernorm(_p(x), x.stride(0), _p(out), out.stride(0), _p(w), _p(b), rows, cols, eps,
+                                   ACT[act], post_scale, _stream()), "vh_layernorm")
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    _dev(x, w)
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().vh_rmsnorm(_p(x), _p(out), _p(w), x.shape[0], x.shape[1], eps, _stream()), "vh_rmsnorm")
+    return out
+
+
+def vit_patchify(pix, patch, kpad):
+    _dev(pix)
+    n, _, img, _ = pix.shape
+    g = img // patch
+    out = torch.empty((n * g * g, kpad), dtype=torch.float32, device=pix.device)
+    check(_lib.load().vh_vit_patchify(_p(pix), _p(out), n, img, patch, kpad, _stream()), "vh_vit_patchify")
+    return out
+
+
+def vit_assemble(patches, cls, pos, n, ntok, hid):
+    x = torch.empty((n * ntok, hid), dtype=torch.float32, device=patches.device)
+    check(_lib.load().vh_vit_assemble(_p(patches), _p(cls), _p(pos), _p(x), n, ntok, hid, _stream()),
+          "vh_vit_assemble")
+    return x
+
+
+def vit_pixel_shuffle(x, n, grid, hid, mul):
+    g2 = grid // 2
+    out = torch.empty((n, g2 * g2, 4 * hid), dtype=torch.float32, device=x.device)
+    check(_lib.load().vh_vit_pixel_shuffle(_p(x), _p(out), n, grid, hid, mul, _stream()), "vh_vit_pixel_shuffle")
+    return out
+
+
+def audio_conv1(feats, mean, istd, w, b):
+    _dev(feats, w)
+    T, F = feats.shape
+    Cc = w.shape[0]
+    T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    out = torch.empty((T1 * F1, Cc), dtype=torch.float32, device=feats.device)
+    check(_lib.load().vh_audio_conv1(_p(feats), _p(mean), _p(istd), _p(w), _p(b), _p(out), T, F, Cc, _stream()),
+          "vh_audio_conv1")
+    return out, T1, F1
+
+
+def embed_splice(kind, idx, embed, img, aud, H):
+    S = kind.shape[0]
+    out = torch.empty((S, H), dtype=torch.float32, device=embed.device)
+    check(_lib.load().vh_embed_splice(_p(kind), _p(idx), _p(embed), _p(img), _p(aud), _p(out), S, H, _stream()),
+          "vh_embed_splice")
+    return out
