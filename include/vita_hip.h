@@ -111,6 +111,7 @@ typedef struct {
     int max_new;          /* capacity of the generated-token buffer */
     int tp_rank, tp_world;/* n_q_heads / n_kv_heads / inter above are THIS RANK's slices */
     int nsplit;           /* decode split-KV factor, 0 = auto */
+    int logit_rows;       /* >1: keep the fp32 logits of the first logit_rows generated tokens */
 } vh_mixtral_cfg;
 
 typedef struct {
@@ -151,7 +152,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
 /* Device pointers into the engine state (for the host loop and the tests). */
 const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */
 const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[2]: {pos, n_generated}    */
-const float* vh_mixtral_logits(const vh_mixtral_t* m);   /* fp32[vocab] of the last step  */
+const float* vh_mixtral_logits(const vh_mixtral_t* m);   /* fp32[max(1,logit_rows)][vocab]; row i = scores that produced token i */
 int vh_mixtral_reset(vh_mixtral_t* m, void* stream);     /* n_generated = 0, pos = 0      */
 
 #ifdef __cplusplus

@@ -58,11 +58,12 @@ def install():
         _stub("torchvision.ops.misc", SqueezeExcitation=_Any)
     if "timm" not in sys.modules:
         _stub("timm")
-        _stub("timm.layers")
+        _stub("timm.layers", drop_path=lambda x, *a, **k: x, to_2tuple=lambda x: (x, x),
+              trunc_normal_=torch.nn.init.trunc_normal_, DropPath=torch.nn.Identity)
         _stub("timm.layers.norm_act", LayerNormAct2d=_Any)
         _stub("timm.models")
-        _stub("timm.models.layers", DropPath=torch.nn.Identity, to_2tuple=lambda x: (x, x),
-              trunc_normal_=torch.nn.init.trunc_normal_)
+        _stub("timm.models.layers", DropPath=torch.nn.Identity, drop_path=lambda x, *a, **k: x,
+              to_2tuple=lambda x: (x, x), trunc_normal_=torch.nn.init.trunc_normal_)
         _stub("timm.models.registry", register_model=lambda f: f)
     if "xformers" not in sys.modules:
         _stub("xformers")
@@ -72,6 +73,8 @@ def install():
         _stub("torchaudio.compliance")
         _stub("torchaudio.compliance.kaldi")
         ta.transforms = _stub("torchaudio.transforms")
+    if "decord" not in sys.modules:
+        _stub("decord", VideoReader=_Any, cpu=_Any)
     if REF not in sys.path:
         sys.path.insert(0, REF)
     _done = True

@@ -1,0 +1,143 @@
+"""CPU: host-side logic against golden values taken from the reference's own functions
+(tests/golden/host_logic.npz, q1_audio.npz), the C-ABI surface, and config / checkpoint helpers."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class FakeTokenizer:  # same toy tokenizer oracle/make_golden.py used
+    bos_token_id = 1
+
+    def __call__(self, text):
+        from types import SimpleNamespace
+        return SimpleNamespace(input_ids=[1] + [3 + (ord(c) % 90) for c in text])
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return ["".join(chr(int(i)) for i in row if int(i) > 2) for row in ids]
+
+
+CASES = {"image": "<image><image>\ndescribe<audio>", "video": "<image>" * 4 + "\n<audio>", "lang": "hello there"}
+
+
+def test_prompt_and_placeholder_tokenisation_match_reference():
+    from vita_amd.host.prompt import conv_templates, tokenizer_image_audio_token, tokenizer_image_token
+    g = np.load(os.path.join(GOLD, "host_logic.npz"))
+    tok = FakeTokenizer()
+    for mod, q in CASES.items():
+        c = conv_templates["mixtral_two"].copy()
+        c.append_message(c.roles[0], q)
+        c.append_message(c.roles[1], None)
+        p = c.get_prompt(mod)
+        assert p == bytes(g[f"prompt_{mod}"]).decode("utf-8"), mod
+        assert tokenizer_image_audio_token(p, tok) == g[f"ids_ia_{mod}"].tolist()
+        assert tokenizer_image_token(p, tok) == g[f"ids_i_{mod}"].tolist()
+    # the template object must not be mutated by get_prompt on a copy
+    assert isinstance(conv_templates["mixtral_two"].system, list)
+    with pytest.raises(AssertionError):
+        c = conv_templates["mixtral_two"].copy()
+        c.append_message("user", "text only")
+        c.get_prompt("image")
+
+
+def test_dynamic_preprocess_matches_reference():
+    from PIL import Image
+    from vita_amd.host.image_processing import dynamic_preprocess
+    g = np.load(os.path.join(GOLD, "host_logic.npz"))
+    for (w, h), n in zip(g["tile_sizes"].tolist(), g["tile_counts"].tolist()):
+        tiles, cnt = dynamic_preprocess(Image.new("RGB", (w, h)), min_num=1, max_num=12, image_size=448,
+                                        use_thumbnail=True)
+        assert cnt == [n] and len(tiles) == n, (w, h)
+        assert all(t.size == (448, 448) for t in tiles)
+
+
+def test_stopping_criteria_and_names():
+    import torch
+    from vita_amd.host.prompt import KeywordsStoppingCriteria, get_model_name_from_path
+    tok = FakeTokenizer()
+    prompt = torch.tensor([[1, 50, 51]])
+    crit = KeywordsStoppingCriteria(["</s>"], tok, prompt)
+    kw = tok("</s>").input_ids[1:]
+    assert not crit(torch.tensor([[1, 50, 51, 60]]), None)
+    assert crit(torch.tensor([[1, 50, 51, 60] + kw]), None)
+    assert get_model_name_from_path("/a/b/VITA_ckpt/") == "VITA_ckpt"
+    assert get_model_name_from_path("/a/run/checkpoint-100") == "run_checkpoint-100"
+
+
+def test_fbank_matches_golden_and_token_count():
+    from vita_amd.audio_frontend import kaldi_fbank
+    from vita_amd.config import audio_token_count
+    g = np.load(os.path.join(GOLD, "q1_audio.npz"))
+    fb = kaldi_fbank(g["pcm16"].astype(np.float64), int(g["sr"]))
+    assert fb.shape == (352, 80)                       # q1.wav = 3.54 s -> 352 frames
+    assert np.abs(fb - g["fbank"]).max() < 1e-4
+    assert audio_token_count(352) == 44 and audio_token_count(998) == 124 and audio_token_count(400) == 50
+
+
+def test_image_processor_normalisation():
+    from PIL import Image
+    from vita_amd.host.image_processing import IMAGENET_MEAN, IMAGENET_STD, make_image_processor, process_images
+    ip = make_image_processor(448)
+    img = Image.new("RGB", (448, 448), (255, 0, 128))
+    px = ip.preprocess(img, return_tensors="pt")["pixel_values"]
+    assert tuple(px.shape) == (1, 3, 448, 448)
+    exp = [(v / 255.0 - m) / s for v, m, s in zip((255, 0, 128), IMAGENET_MEAN, IMAGENET_STD)]
+    assert np.allclose(px[0, :, 10, 10].numpy(), exp, atol=1e-6)
+    out = process_images([Image.new("RGB", (600, 300))], ip, "pad")
+    assert tuple(out.shape) == (1, 3, 448, 448)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """the library loads without a GPU and exports exactly what include/vita_hip.h declares."""
+    from vita_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vita_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vh_[a-z0-9_]+)\s*\(", hdr)) - {"vh_allreduce_fn"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    assert lib.vh_version() >= 100
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (vh_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert lib.vh_gemm(None, None) != 0 and b"null" in lib.vh_last_error()
+    cfg = _lib.MixtralCfg()
+    cfg.head_dim = 64
+    assert lib.vh_mixtral_workspace_bytes(ctypes.byref(cfg)) == 0 and b"head_dim" in lib.vh_last_error()
+
+
+def test_workspace_size_real_geometry():
+    from vita_amd import _lib
+    lib = _lib.load()
+    c = _lib.MixtralCfg(hidden=4096, n_layers=32, n_q_heads=32, n_kv_heads=8, head_dim=128, inter=14336, n_experts=8,
+                        top_k=2, vocab=51760, rms_eps=1e-5, max_ctx=2048, max_prefill=1024, max_new=1024, tp_rank=0,
+                        tp_world=1, nsplit=0, logit_rows=0)
+    n = lib.vh_mixtral_workspace_bytes(ctypes.byref(c))
+    kv = 2 * 32 * 8 * 2048 * 128 * 4
+    assert kv < n < kv + (1 << 30)
+
+
+def test_tp_slices_partition():
+    from vita_amd.checkpoint import tp_slices
+    from vita_amd.config import TextConfig
+    t = TextConfig()
+    for world in (1, 2, 4, 8):
+        qs, kvs, ffs = zip(*[tp_slices(t, r, world) for r in range(world)])
+        for parts, total in ((qs, 4096), (kvs, 1024), (ffs, 14336)):
+            assert parts[0].start == 0 and parts[-1].stop == total
+            assert all(a.stop == b.start for a, b in zip(parts, parts[1:]))
+    with pytest.raises(ValueError):
+        tp_slices(t, 0, 3)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from vita_amd import _lib, ops
+    with pytest.raises(_lib.VitaHipError):
+        ops.gemm(torch.zeros(4, 64), torch.zeros(8, 64, dtype=torch.bfloat16))

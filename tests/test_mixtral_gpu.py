@@ -27,14 +27,16 @@ def _run(dev, cfg, S, n_new, seed=0, nsplit=0, max_ctx=None, chunked=False):
     _, ref_hid = orc.forward(emb, want_hidden=True)
 
     eng = MixtralEngine(cfg, pack_mixtral(sd, cfg, dev), dev, max_ctx=max_ctx or (S + n_new + 8), max_prefill=S,
-                        max_new=n_new + 4, nsplit=nsplit)
+                        max_new=n_new + 4, nsplit=nsplit, logit_rows=(n_new + 4) if chunked else 0)
     logits, hid = eng.prefill(torch.from_numpy(emb).to(dev), want_hidden=True)
     torch.cuda.synchronize()
     for l in range(cfg.text.num_hidden_layers):
         assert_close(f"prefill hidden after layer {l}", to_np(hid[l]), ref_hid[l], atol=2e-4, rtol=1e-4)
     got_lg = [to_np(logits).copy()]
     if chunked:
-        eng.decode(n_new - 1)  # one C call, no host interaction
+        eng.decode(n_new - 1)  # one C call, no host interaction; scores come from the logits history
+        torch.cuda.synchronize()
+        got_lg = [to_np(eng.logits_all[i]).copy() for i in range(n_new)]
     else:
         for _ in range(n_new - 1):
             eng.decode(1)

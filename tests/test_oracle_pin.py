@@ -1,0 +1,90 @@
+"""CPU: pins the numpy oracle (oracle/) — (1) against the golden vectors produced by the
+REFERENCE'S OWN modules in the build container (tests/golden/tiny_e2e.npz, oracle/make_golden.py),
+(2) live against the installed HF Mixtral (the third-party code carrying the backbone arithmetic),
+(3) live against the reference modules when /root/reference is present."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import encoders as oe
+from oracle import mixtral as om
+from tests.util import assert_close
+from vita_amd.checkpoint import synth_state_dict
+from vita_amd.config import VitaConfig
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = VitaConfig.tiny()
+    g = np.load(os.path.join(GOLD, "tiny_e2e.npz"))
+    return cfg, synth_state_dict(cfg, seed=int(g["seed"])), g
+
+
+def test_vit_and_projector_vs_reference_golden(tiny):
+    cfg, sd, g = tiny
+    vit = oe.internvit_tower(sd, cfg.vision, g["pix"])
+    assert_close("oracle vit vs reference", vit, g["vit_out"], atol=5e-6)
+    assert_close("oracle projector vs reference", oe.projector(sd, g["vit_out"]), g["proj_out"], atol=2e-6)
+
+
+def test_whale_vs_reference_golden(tiny):
+    cfg, sd, g = tiny
+    out, mask = oe.whale_encoder(sd, cfg.audio, g["feats"])
+    assert_close("oracle whale vs reference", out, g["audio_out"], atol=5e-6)
+    assert mask.tolist() == g["audio_mask"].tolist()
+    feats_pad = np.concatenate([g["feats"], np.zeros((37, 80), np.float32)])
+    outp, maskp = oe.whale_encoder(sd, cfg.audio, feats_pad, length=123)
+    assert maskp.tolist() == g["audio_pad_mask"].tolist()
+    v = maskp
+    assert_close("oracle whale (padded) vs reference, valid rows", outp[v], g["audio_pad_out"][v], atol=5e-6)
+
+
+def test_splice_vs_reference_golden(tiny):
+    cfg, sd, g = tiny
+    emb = oe.splice(g["input_ids"], sd["model.embed_tokens.weight"], g["proj_out"], g["audio_out"][None],
+                    cfg.tokenizer_model_max_length)
+    assert_close("oracle splice vs reference", emb, g["inputs_embeds"], atol=2e-6)
+
+
+def test_mixtral_vs_hf_golden(tiny):
+    cfg, sd, g = tiny
+    orc = om.MixtralOracle(sd, cfg.text)
+    ids, lg = orc.greedy(g["inputs_embeds"], len(g["gen_ids"]))
+    assert ids == g["gen_ids"].tolist()
+    assert_close("oracle logits vs HF", lg, g["gen_logits"], atol=5e-6)
+    orc.reset()
+    _, hid = orc.forward(g["inputs_embeds"], want_hidden=True)
+    assert_close("oracle hidden vs HF", hid[:-1], g["hidden_layers"], atol=5e-6)
+
+
+def test_mixtral_live_vs_installed_hf():
+    """different seed / shapes than the golden; transformers is part of the image on both boxes."""
+    from oracle import hf_mixtral
+    cfg = VitaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=7, parts=("text",))
+    rng = np.random.default_rng(8)
+    emb = sd["model.embed_tokens.weight"][rng.integers(3, cfg.text.vocab_size, size=19)]
+    m = hf_mixtral.build(cfg.text, sd)
+    ids_hf, lg_hf, _ = hf_mixtral.greedy(m, emb, 6)
+    ids, lg = om.MixtralOracle(sd, cfg.text).greedy(emb, 6)
+    assert ids == ids_hf
+    assert_close("oracle vs installed HF", lg, lg_hf, atol=5e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vita"), reason="reference tree only exists in the build container")
+def test_live_vs_reference_modules():
+    import torch
+    from oracle import ref_harness as rh
+    cfg = VitaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=11)
+    rng = np.random.default_rng(12)
+    pix = rng.standard_normal((1, 3, 56, 56)).astype(np.float32)
+    feats = (rng.standard_normal((77, 80)) * 2 + 10).astype(np.float32)
+    with torch.no_grad():
+        ref_v = rh.build_internvit(cfg, sd)(torch.from_numpy(pix)).numpy()
+        ref_a = rh.build_whale(cfg, sd)(torch.from_numpy(feats)[None], torch.tensor([77]))["inputs_embeds"][0].numpy()
+    assert_close("live vit", oe.internvit_tower(sd, cfg.vision, pix), ref_v, atol=5e-6)
+    assert_close("live whale", oe.whale_encoder(sd, cfg.audio, feats)[0], ref_a, atol=5e-6)

@@ -46,7 +46,7 @@ class MixtralCfg(C.Structure):
         ("hidden", c_int), ("n_layers", c_int), ("n_q_heads", c_int), ("n_kv_heads", c_int),
         ("head_dim", c_int), ("inter", c_int), ("n_experts", c_int), ("top_k", c_int), ("vocab", c_int),
         ("rms_eps", c_float), ("max_ctx", c_int), ("max_prefill", c_int), ("max_new", c_int),
-        ("tp_rank", c_int), ("tp_world", c_int), ("nsplit", c_int),
+        ("tp_rank", c_int), ("tp_world", c_int), ("nsplit", c_int), ("logit_rows", c_int),
     ]
 
 

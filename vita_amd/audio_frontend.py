@@ -1,0 +1,105 @@
+"""Host-side speech front end: wav -> Kaldi-compatible log-mel filterbank features.
+
+Mirrors the reference's audioEncoderProcessor.process (vita/model/multimodal_encoder/whale/
+init_model.py:35-60), which calls torchaudio.compliance.kaldi.fbank on the CPU with
+num_mel_bins=80, frame_length=25 ms, frame_shift=10 ms, energy_floor=0 and the yaml's dither.
+torchaudio is not in this image, so the Kaldi recipe is written out in numpy: snip-edges framing,
+DC removal, 0.97 pre-emphasis, Povey window, 512-point power spectrum, 80 triangular filters on
+the Kaldi mel scale (20 Hz .. Nyquist), log with the fp32-epsilon floor.  It stays on the CPU like
+the reference's (it is ~1 ms of work and not on the GPU hot path).
+"""
+import math
+import wave
+
+import numpy as np
+
+from .config import audio_token_count
+
+EPS = 1.1920928955078125e-07  # torch.finfo(float32).eps, Kaldi's log floor
+
+
+def _mel(f):
+    return 1127.0 * np.log(1.0 + f / 700.0)
+
+
+def kaldi_mel_banks(num_bins=80, n_fft=512, sample_rate=16000, low=20.0, high=0.0):
+    nyq = 0.5 * sample_rate
+    if high <= 0.0:
+        high += nyq
+    fft_bin_width = sample_rate / n_fft
+    mel_lo, mel_hi = _mel(low), _mel(high)
+    delta = (mel_hi - mel_lo) / (num_bins + 1)
+    b = np.arange(num_bins, dtype=np.float64)[:, None]
+    left, center, right = mel_lo + b * delta, mel_lo + (b + 1) * delta, mel_lo + (b + 2) * delta
+    mel = _mel(fft_bin_width * np.arange(n_fft // 2, dtype=np.float64))[None, :]
+    up, down = (mel - left) / (center - left), (right - mel) / (right - center)
+    return np.maximum(0.0, np.minimum(up, down))  # [num_bins, n_fft/2]; the Nyquist bin gets weight 0
+
+
+def povey_window(n):
+    return (0.5 - 0.5 * np.cos(2.0 * math.pi * np.arange(n, dtype=np.float64) / (n - 1))) ** 0.85
+
+
+def kaldi_fbank(waveform, sample_rate=16000, num_mel_bins=80, frame_length_ms=25.0, frame_shift_ms=10.0,
+                dither=0.0, preemphasis=0.97, rng=None):
+    """waveform: 1-D float array already scaled to the int16 range (the reference multiplies by
+    1<<15, init_model.py:46).  Returns float32 [num_frames, num_mel_bins]."""
+    x = np.asarray(waveform, dtype=np.float64).reshape(-1)
+    win = int(sample_rate * frame_length_ms * 0.001)
+    hop = int(sample_rate * frame_shift_ms * 0.001)
+    n_fft = 1 << (win - 1).bit_length()
+    if x.shape[0] < win:
+        return np.zeros((0, num_mel_bins), np.float32)
+    n_frames = 1 + (x.shape[0] - win) // hop
+    idx = np.arange(win)[None, :] + hop * np.arange(n_frames)[:, None]
+    fr = x[idx]
+    if dither != 0.0:
+        rng = rng or np.random.default_rng()
+        fr = fr + dither * rng.standard_normal(fr.shape)
+    fr = fr - fr.mean(axis=1, keepdims=True)
+    prev = np.concatenate([fr[:, :1], fr[:, :-1]], axis=1)  # replicate-pad the first sample
+    fr = fr - preemphasis * prev
+    fr = fr * povey_window(win)[None, :]
+    spec = np.fft.rfft(fr, n=n_fft, axis=1)
+    power = (spec.real ** 2 + spec.imag ** 2)[:, : n_fft // 2]
+    mel = power @ kaldi_mel_banks(num_mel_bins, n_fft, sample_rate).T
+    return np.log(np.maximum(mel, EPS)).astype(np.float32)
+
+
+def load_wav(path):
+    """PCM wav -> (float waveform in [-1,1), sample_rate), first channel."""
+    with wave.open(path, "rb") as w:
+        sr, nch, sw, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if sw == 2:
+        d = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+    elif sw == 4:
+        d = np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0
+    elif sw == 1:
+        d = (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported sample width {sw}")
+    return d.reshape(-1, nch)[:, 0], sr
+
+
+class AudioEncoderProcessor:
+    """Same surface as the reference's audioEncoderProcessor: process(wav_path) -> (Tensor[T,80], n_tokens)."""
+
+    def __init__(self, dataset_conf=None):
+        self.dataset_conf = dataset_conf or {
+            "resample_conf": {"resample_rate": 16000},
+            "fbank_conf": {"num_mel_bins": 80, "frame_length": 25, "frame_shift": 10, "dither": 0.0}}
+
+    def process(self, wav_path):
+        import torch
+        wavef, sr = load_wav(wav_path)
+        target = self.dataset_conf["resample_conf"]["resample_rate"]
+        if sr != target:
+            from scipy.signal import resample_poly
+            g = math.gcd(int(sr), int(target))
+            wavef = resample_poly(wavef, target // g, sr // g)
+        fb = self.dataset_conf["fbank_conf"]
+        # NB the reference passes the ORIGINAL file rate as sample_frequency (init_model.py:55)
+        mat = kaldi_fbank(wavef * (1 << 15), sample_rate=sr, num_mel_bins=fb["num_mel_bins"],
+                          frame_length_ms=fb["frame_length"], frame_shift_ms=fb["frame_shift"], dither=fb["dither"])
+        return torch.from_numpy(mat), audio_token_count(mat.shape[0])

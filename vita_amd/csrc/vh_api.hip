@@ -174,7 +174,7 @@ struct vh_mixtral {
         part_o = cv.take<float>((size_t)nq * nsplit * hd);
         part_ml = cv.take<float>((size_t)nq * nsplit * 2);
         hbuf = cv.take<float>((size_t)2 * I);
-        logits = cv.take<float>(V);
+        logits = cv.take<float>((size_t)hist_rows() * V);
         blk_val = cv.take<float>(lm_grid);
         blk_idx = cv.take<int>(lm_grid);
         route = cv.take<int>(4);
@@ -190,6 +190,7 @@ struct vh_mixtral {
         pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
         return cv.off;
     }
+    int hist_rows() const { return c.logit_rows > 1 ? c.logit_rows : 1; }
     void derive() {
         nq = c.n_q_heads; nkv = c.n_kv_heads; hd = c.head_dim; H = c.hidden; I = c.inter; E = c.n_experts;
         V = c.vocab; nqkv = (nq + 2 * nkv) * hd;
@@ -318,6 +319,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     const float scale = 1.0f / sqrtf((float)hd);
     if (hipMemcpyAsync(m->px, embeds, (size_t)Sn * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(VH_E_HIP, "prefill: embed copy failed");
+    if (hipMemsetAsync(m->counters + 1, 0, sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
 
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
@@ -389,7 +391,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     // logits of the last position only (the reference computes all S rows and uses the last:
     // vita_mixtral.py:171-172 + HF greedy argmax(logits[:, -1]))
     VH_TRY(vhk_dec_lmhead(st, m->px + (size_t)(Sn - 1) * H, nullptr, m->final_norm, m->c.rms_eps, m->lm_head, m->V, H,
-                          m->logits, m->blk_val, m->blk_idx, m->lm_grid), "lm_head");
+                          m->logits, m->blk_val, m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "lm_head");
     VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters, m->counters + 1,
                           m->out_tokens, m->c.max_new, /*mode=*/0, /*set_pos=*/pos0 + Sn), "select");
     if (logits_out)
@@ -422,7 +424,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
             if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         }
         VH_TRY(vhk_dec_lmhead(st, m->xa, m->delta_moe, m->final_norm, eps, m->lm_head, m->V, H, m->logits, m->blk_val,
-                              m->blk_idx, m->lm_grid), "dec lm_head");
+                              m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "dec lm_head");
         VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters,
                               m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
     }

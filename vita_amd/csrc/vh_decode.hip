@@ -450,8 +450,12 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
                                                     const float* __restrict__ norm_w, float eps,
                                                     const uint16_t* __restrict__ W, int V, int K,
                                                     float* __restrict__ logits, float* __restrict__ blk_val,
-                                                    int* __restrict__ blk_idx) {
+                                                    int* __restrict__ blk_idx, const int* __restrict__ ngen_ptr,
+                                                    int hist_rows) {
     __shared__ float red[4 * LM_R];
+    // logits history: row = index of the token this step produces (clamped), so the host can
+    // read every step's scores after a multi-step launch (HF generate(output_scores=True)).
+    if (hist_rows > 1) logits += (size_t)min(*ngen_ptr, hist_rows - 1) * V;
     __shared__ float bv_s[LM_R];
     __shared__ int bi_s[LM_R];
     float xr[NJ][8];
@@ -594,10 +598,11 @@ int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint
 }
 
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
-                   const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid) {
+                   const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
+                   const int* ngen_ptr, int hist_rows) {
     return pick_nj(K, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_lmhead<decltype(nj)::value>), dim3(grid), dim3(256), 0, st, x_in, delta, norm_w, eps,
-                           W, V, K, logits, blk_val, blk_idx);
+                           W, V, K, logits, blk_val, blk_idx, ngen_ptr, hist_rows);
         return 0;
     });
 }

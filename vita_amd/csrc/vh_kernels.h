@@ -18,7 +18,8 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
                    float* hbuf, int grid);
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out);
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
-                   const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid);
+                   const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
+                   const int* ngen_ptr, int hist_rows);
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
                    float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
 

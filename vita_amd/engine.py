@@ -23,7 +23,7 @@ def rope_tables(max_pos, head_dim, theta):
 
 class MixtralEngine:
     def __init__(self, cfg: VitaConfig, packed, device, max_ctx=None, max_prefill=None, max_new=1024, rank=0,
-                 world=1, nsplit=0):
+                 world=1, nsplit=0, logit_rows=0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VitaHipError("MixtralEngine needs a GPU (no CPU fallback)")
@@ -41,7 +41,7 @@ class MixtralEngine:
         c.head_dim, c.inter, c.n_experts, c.top_k = t.head_dim, lay0["w1"].shape[1], t.num_local_experts, t.num_experts_per_tok
         c.vocab, c.rms_eps = t.vocab_size, t.rms_norm_eps
         c.max_ctx, c.max_prefill, c.max_new = max_ctx, max_prefill, max_new
-        c.tp_rank, c.tp_world, c.nsplit = rank, world, nsplit
+        c.tp_rank, c.tp_world, c.nsplit, c.logit_rows = rank, world, nsplit, logit_rows
         self.c = c
         nbytes = self.lib.vh_mixtral_workspace_bytes(C.byref(c))
         if nbytes == 0:
@@ -69,8 +69,11 @@ class MixtralEngine:
         base = self.workspace.data_ptr()
         self.tokens = self.workspace[self._tok_ptr - base: self._tok_ptr - base + 4 * max(max_new, 1)].view(torch.int32)
         self.counters = self.workspace[self._cnt_ptr - base: self._cnt_ptr - base + 8].view(torch.int32)
-        self.logits = self.workspace[self._logit_ptr - base: self._logit_ptr - base + 4 * t.vocab_size].view(
-            torch.float32)
+        self.logit_rows = max(1, logit_rows)
+        self.logits_all = self.workspace[self._logit_ptr - base: self._logit_ptr - base +
+                                         4 * t.vocab_size * self.logit_rows].view(torch.float32).view(
+            self.logit_rows, t.vocab_size)  # row i = the scores that produced generated token i
+        self.n_gen = 0
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -118,10 +121,17 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_prefill(self.h, embeds.data_ptr(), S, pos0, None,
                                           hid.data_ptr() if hid is not None else None, self._stream()),
               "vh_mixtral_prefill")
-        return self.logits, hid
+        self.n_gen = 1
+        return self.logits_all[0], hid
 
     def decode(self, n_steps):
         check(self.lib.vh_mixtral_decode(self.h, int(n_steps), self._stream()), "vh_mixtral_decode")
+        self.n_gen += int(n_steps)
+
+    @property
+    def logits(self):
+        """scores of the most recent step (row n_gen-1 of the history, or the single row)."""
+        return self.logits_all[min(self.n_gen - 1, self.logit_rows - 1) if self.logit_rows > 1 else 0]
 
     def generated(self):
         """(synchronising) list of token ids generated so far."""

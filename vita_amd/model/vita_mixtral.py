@@ -1,0 +1,227 @@
+"""VITAMixtralForCausalLM on HIP — the drop-in for the reference class of the same name
+(vita/model/language_model/vita_mixtral.py:225-415) plus the multimodal assembly of
+VITAMetaForCausalLM (vita/model/vita_arch.py:110-407) and the greedy loop of HF generate as
+video_audio_demo.py:257-270 drives it.
+
+What a caller of the reference finds unchanged: get_vision_tower(), get_audio_encoder(),
+process_images(), encode_images(), prepare_inputs_labels_for_multimodal() (inference subset),
+generate(input_ids, images=, audios=, ... ) -> object with .sequences / .scores, config, dtype,
+eval(), resize_token_embeddings().  Only greedy decoding is implemented (the reference demos
+use do_sample=False / temperature 0.01)."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..config import VitaConfig
+from ..engine import MixtralEngine
+from ..host.constants import AUDIO_TOKEN_INDEX, IMAGE_TOKEN_INDEX
+from ..host.image_processing import process_images as _process_images
+from .encoders import InternViTVisionTower, VisionProjector, WhaleAudioEncoder, _HipModule
+
+
+class GenerateOutput(SimpleNamespace):
+    """Minimal stand-in for HF GenerateDecoderOnlyOutput: .sequences, .scores."""
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class _Backbone(_HipModule):
+    """`model.model` of the reference: holds the towers, projector, audio encoder, embed_tokens."""
+
+    def __init__(self, vision_tower, mm_projector, audio_encoder, embed):
+        super().__init__()
+        self.vision_tower, self.mm_projector, self.audio_encoder = vision_tower, mm_projector, audio_encoder
+        self._embed = embed
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    def get_audio_encoder(self):
+        return self.audio_encoder
+
+    def embed_tokens(self, ids):
+        kind = torch.zeros_like(ids, dtype=torch.int32)
+        H = self._embed.shape[1]
+        return ops.embed_splice(kind, ids.to(torch.int32), self._embed, None, None, H)
+
+
+class VITAMixtralForCausalLM(_HipModule):
+    def __init__(self, cfg: VitaConfig, state_dict, device="cuda:0", packed_llm=None, max_new_tokens=1024,
+                 max_prefill=None, rank=0, world=1, keep_scores=True):
+        super().__init__()
+        from ..checkpoint import pack_mixtral
+        self.vcfg_all = cfg
+        self._device = torch.device(device)
+        t = cfg.text
+        self.config = SimpleNamespace(
+            model_type="vita-mixtral", hidden_size=t.hidden_size, vocab_size=t.vocab_size,
+            num_hidden_layers=t.num_hidden_layers, image_aspect_ratio=cfg.image_aspect_ratio,
+            tokenizer_model_max_length=cfg.tokenizer_model_max_length, tokenizer_padding_side="right",
+            mm_vision_tower="InternViT-300M-448px", mm_projector_type="mlp2x_gelu", mm_hidden_size=cfg.vision.out_dim,
+            mm_audio_encoder="audio-encoder", max_dynamic_patch=cfg.max_dynamic_patch,
+            bos_token_id=t.bos_token_id, eos_token_id=t.eos_token_id)
+        self.generation_config = SimpleNamespace(pad_token_id=None, eos_token_id=t.eos_token_id, max_new_tokens=None)
+        tower = InternViTVisionTower("InternViT-300M-448px", vcfg=cfg.vision)
+        audio = WhaleAudioEncoder(acfg=cfg.audio, llm_dim=t.hidden_size)
+        proj = VisionProjector()
+        if state_dict is not None:
+            tower.set_state_dict(state_dict, device)
+            if any(k.startswith("model.mm_projector.") for k in state_dict):
+                proj.load(state_dict, device)
+            if any(k.startswith("model.audio_encoder.") for k in state_dict):
+                audio.load(state_dict, device)
+        self.packed = packed_llm if packed_llm is not None else pack_mixtral(state_dict, cfg, device, rank, world)
+        self.model = _Backbone(tower, proj, audio, self.packed["embed"])
+        self.max_new_tokens = max_new_tokens
+        self.max_prefill = max_prefill or cfg.tokenizer_model_max_length
+        self.engine = MixtralEngine(cfg, self.packed, self._device, max_prefill=self.max_prefill,
+                                    max_new=max_new_tokens, rank=rank, world=world,
+                                    logit_rows=max_new_tokens if keep_scores else 0)
+        self.lookahead = 8          # decode steps enqueued per host synchronisation in generate()
+        self.last_timing = {}
+
+    # ---- reference surface -------------------------------------------------------------------
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.model.get_vision_tower()
+
+    def get_audio_encoder(self):
+        return self.model.get_audio_encoder()
+
+    def eval(self):
+        return self
+
+    def resize_token_embeddings(self, n):
+        if n is not None and n > self.config.vocab_size:
+            raise NotImplementedError(
+                f"growing the embedding table ({self.config.vocab_size} -> {n}) is not supported by the HIP engine")
+        return None
+
+    def process_images(self, images, model_cfg=None):
+        tower = self.get_vision_tower()
+        if not tower.is_loaded:
+            tower.load_model()
+        return _process_images(images, tower.image_processor, getattr(model_cfg or self.config, "image_aspect_ratio", None))
+
+    def encode_images(self, images):
+        """tower -> projector (vita_arch.py:131-134)."""
+        return self.model.mm_projector(self.get_vision_tower()(images))
+
+    # ---- multimodal assembly -----------------------------------------------------------------
+    @torch.no_grad()
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             images, audios):
+        """Inference subset of vita_arch.py:151-407 for batch size 1: encode, check the placeholder
+        counts, splice image / audio embeddings at the -200 / -500 sentinels, truncate to
+        tokenizer_model_max_length.  Returns the reference's 6-tuple with inputs_embeds [1,S,H]."""
+        if input_ids.shape[0] != 1:
+            raise NotImplementedError("the HIP path serves one request per call (batch 1), like the demo")
+        dev = self._device
+        ids = input_ids[0]
+        if attention_mask is not None:
+            ids = ids[attention_mask[0].bool().to(ids.device)]
+        if type(images) is list or images.ndim == 5:
+            images = torch.cat([im for im in images], dim=0)
+        image_features = self.encode_images(images)                       # [n_tiles, 256, H]
+        if audios is not None:
+            audio_features = self.get_audio_encoder()(audios["audios"], audios["lengths"])
+        else:
+            raise ValueError("audios must be provided (the reference passes a dummy clip for text/image prompts)")
+        ids_np = ids.detach().cpu().numpy()
+        n_img, n_aud = int((ids_np == IMAGE_TOKEN_INDEX).sum()), int((ids_np == AUDIO_TOKEN_INDEX).sum())
+        aud_emb = audio_features["inputs_embeds"]
+        assert n_img + (0 if n_img else 1) == image_features.shape[0]       # vita_arch.py:227-231
+        assert n_aud + (0 if n_aud else 1) == aud_emb.shape[0]             # vita_arch.py:232-236
+        tiles_tok, aud_tok = image_features.shape[1], aud_emb.shape[1]
+        kind, idx, ii, ai = [], [], 0, 0
+        for t in ids_np.tolist():
+            if t == IMAGE_TOKEN_INDEX:
+                kind += [1] * tiles_tok
+                idx += list(range(ii * tiles_tok, (ii + 1) * tiles_tok)); ii += 1
+            elif t == AUDIO_TOKEN_INDEX:
+                kind += [2] * aud_tok
+                idx += list(range(ai * aud_tok, (ai + 1) * aud_tok)); ai += 1
+            else:
+                if t < 0 or t >= self.config.vocab_size:
+                    raise ValueError(f"token id {t} outside the vocabulary")
+                kind.append(0); idx.append(t)
+        max_len = getattr(self.config, "tokenizer_model_max_length", None)
+        if max_len is not None:
+            kind, idx = kind[:max_len], idx[:max_len]
+        H = self.config.hidden_size
+        emb = ops.embed_splice(torch.tensor(kind, dtype=torch.int32, device=dev),
+                               torch.tensor(idx, dtype=torch.int32, device=dev), self.packed["embed"],
+                               image_features.reshape(-1, H).contiguous(), aud_emb.reshape(-1, H).contiguous(), H)
+        S = emb.shape[0]
+        pos = torch.arange(S, device=dev)[None] if position_ids is not None else None
+        mask = torch.ones((1, S), dtype=attention_mask.dtype, device=dev) if attention_mask is not None else None
+        return None, pos, mask, past_key_values, emb[None], labels
+
+    # ---- forward / generate --------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, labels=None, use_cache=None, images=None, audios=None, **_):
+        """Prefill forward.  Returns .logits [1,1,V] of the LAST position only (the reference computes
+        all S rows, vita_mixtral.py:171-172, and greedy decoding reads the last)."""
+        if inputs_embeds is None:
+            _, _, _, _, inputs_embeds, _ = self.prepare_inputs_labels_for_multimodal(
+                input_ids, position_ids, attention_mask, past_key_values, labels, images, audios)
+        logits, _ = self.engine.prefill(inputs_embeds[0].to(torch.float32))
+        return SimpleNamespace(logits=logits[None, None, :], past_key_values=self.engine)
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, images=None, audios=None, do_sample=False, temperature=None, top_p=None,
+                 num_beams=1, output_scores=False, return_dict_in_generate=False, max_new_tokens=None,
+                 use_cache=True, stopping_criteria=None, inputs_embeds=None, attention_mask=None,
+                 eos_token_id=None, **kwargs):
+        if do_sample or num_beams != 1:
+            raise NotImplementedError("vita_amd implements greedy decoding (do_sample=False, num_beams=1)")
+        max_new = int(max_new_tokens or self.generation_config.max_new_tokens or 20)
+        if max_new > self.max_new_tokens:
+            raise ValueError(f"max_new_tokens={max_new} exceeds the engine capacity {self.max_new_tokens}")
+        eos = self.generation_config.eos_token_id if eos_token_id is None else eos_token_id
+        eos_set = set(eos if isinstance(eos, (list, tuple)) else [eos]) - {None}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        if inputs_embeds is None:
+            _, _, _, _, inputs_embeds, _ = self.prepare_inputs_labels_for_multimodal(
+                input_ids, None, attention_mask, None, None, images, audios)
+        emb = inputs_embeds[0].to(torch.float32)
+        if emb.shape[0] + max_new + 1 > self.engine.max_ctx:
+            raise ValueError("prompt + max_new_tokens exceeds the KV-cache capacity")
+        ev[1].record()
+        eng = self.engine
+        eng.prefill(emb)
+        prompt = input_ids if input_ids is not None else torch.zeros((1, 0), dtype=torch.long, device=self._device)
+        prompt = prompt.to(self._device)
+        crit = list(stopping_criteria or [])
+        keep_scores = output_scores and eng.logit_rows > 1
+        generated, done, n_checked = [], False, 0
+        while not done:
+            # tokens [n_checked, eng.n_gen) are on the device; look at them one at a time, in order,
+            # so stopping is decided exactly as a token-by-token loop would
+            torch.cuda.current_stream().synchronize()
+            new = eng.tokens[n_checked:eng.n_gen].tolist()
+            for tok in new:
+                generated.append(tok)
+                n_checked += 1
+                seq = torch.cat([prompt, torch.tensor([generated], dtype=prompt.dtype, device=self._device)], dim=1)
+                if tok in eos_set or len(generated) >= max_new or any(c(seq, None) for c in crit):
+                    done = True
+                    break
+            if not done:
+                eng.decode(min(self.lookahead, max_new - eng.n_gen))
+        ev[2].record()
+        torch.cuda.synchronize()
+        self.last_timing = {"encode_ms": ev[0].elapsed_time(ev[1]), "llm_ms": ev[1].elapsed_time(ev[2]),
+                            "prompt_tokens": int(emb.shape[0]), "new_tokens": len(generated)}
+        sequences = torch.cat([prompt, torch.tensor([generated], dtype=prompt.dtype, device=self._device)], dim=1)
+        if not return_dict_in_generate:
+            return sequences
+        scores = tuple(eng.logits_all[i][None].clone() for i in range(len(generated))) if keep_scores else None
+        return GenerateOutput(sequences=sequences, scores=scores, past_key_values=None)
