@@ -132,7 +132,7 @@ def conv2d_valid_s2(x, w, b):
     return out.reshape(To, Fo, -1).transpose(2, 0, 1)
 
 
-def whale_encoder(sd, a, feats, length=None, chunk=0, left=-1, want_layers=False):
+def whale_encoder(sd, a, feats, length=None, chunk=0, left=-1, want_layers=False, dbg=None):
     """audioEncoder.forward for ONE utterance — whale/init_model.py:114-139.
     feats [T, 80] fp32.  Full attention unless chunk > 0 (hazard H1: the reference's random
     dynamic-chunk mask is pinned off; an explicit (chunk, left) mask is supported)."""
@@ -146,9 +146,15 @@ def whale_encoder(sd, a, feats, length=None, chunk=0, left=-1, want_layers=False
     # Conv2dSubsampling4.forward — module/component/subsampling.py:38-43
     c = "encoder.enc.0.core."
     y = np.maximum(conv2d_valid_s2(x[None], g(c + "conv.0.weight"), g(c + "conv.0.bias")), 0)
+    if dbg is not None:
+        dbg["conv1"] = y.transpose(1, 2, 0).copy()          # [T1, F1, C]
     y = np.maximum(conv2d_valid_s2(y, g(c + "conv.2.weight"), g(c + "conv.2.bias")), 0)
     C, T2, F2 = y.shape
+    if dbg is not None:
+        dbg["conv2"] = y.transpose(1, 2, 0).copy()          # [T2, F2, C]
     y = y.transpose(1, 0, 2).reshape(T2, C * F2) @ g(c + "out.0.weight").T + g(c + "out.0.bias")
+    if dbg is not None:
+        dbg["sub_out"] = y.copy()
     mask = mask[2::2][2::2]
     # Transformer.forward — module/component/transformer.py:374-394
     e = "encoder.enc.1."
@@ -158,6 +164,8 @@ def whale_encoder(sd, a, feats, length=None, chunk=0, left=-1, want_layers=False
     y = np.maximum(layernorm(y @ g(e + "embed.0.weight").T + g(e + "embed.0.bias"), g(e + "embed.1.weight"),
                              g(e + "embed.1.bias"), 1e-5), 0)
     y = y * math.sqrt(C)                                    # RelPositionalEncoding.forward — attention.py:100-111
+    if dbg is not None:
+        dbg["embed"] = y.copy()
     pos = sinusoid_pe(T2, C).astype(F)
     nh = a.num_attention_heads
     dk = C // nh

@@ -114,7 +114,7 @@ def main():
                      frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False, preemphasis=0.97,
                      mel_filters=mf, log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
     np.savez_compressed(os.path.join(GOLD, "q1_audio.npz"), pcm16=np.round(w * 32768).astype(np.int16), sr=sr,
-                        fbank=fb.astype(np.float32))
+                        fbank=np.ascontiguousarray(fb, dtype=np.float32))
     print("golden written:", sorted(os.listdir(GOLD)))
     print("gen ids:", gen_ids)
 

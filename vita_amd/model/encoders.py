@@ -288,20 +288,25 @@ class WhaleAudioEncoder(_HipModule):
         return self._idx_cache[key]
 
     @torch.no_grad()
-    def encode_one(self, feats, length=None, want_layers=False):
+    def encode_one(self, feats, length=None, want_layers=False, dbg=None):
         """feats fp32 [T, 80] on device, `length` valid frames.  Returns (embeds [T'', H], mask [T''] bool)."""
         a, w = self.acfg, self.w
         C, nh = a.hidden_size, a.num_attention_heads
         dk = C // nh
+        feats = feats.to(device=self._device, dtype=torch.float32).contiguous()
         T = feats.shape[0]
         length = T if length is None else int(length)
         y1, T1, F1 = ops.audio_conv1(feats, w["mean"], w["istd"], w["c1_w"], w["c1_b"])        # [T1*F1, C]
         rows, T2, F2, segrow = self._conv2_rows(T1, F1)
         y2 = ops.gemm(y1, w["c2_w"], bias=w["c2_b"], act="relu", a_rowidx=rows, segrow=segrow, seglen=C)
         y = ops.gemm(y2.view(T2, F2 * C), w["out_w"], bias=w["out_b"])                          # [T2, C]
+        if dbg is not None:
+            dbg.update(conv1=y1.view(T1, F1, C).clone(), conv2=y2.view(T2, F2, C).clone(), sub_out=y.clone())
         klen = len(range(T)[:length][2::2][2::2])                                               # x_mask[:, :, 2::2][:, :, 2::2]
         y = ops.gemm(y, w["emb_w"], bias=w["emb_b"])
         y = ops.layernorm(y, w["emb_nw"], w["emb_nb"], 1e-5, act="relu", post_scale=math.sqrt(C))
+        if dbg is not None:
+            dbg["embed"] = y.clone()
         pos = self.pe[:T2]
         o = torch.empty((T2, C), dtype=torch.float32, device=self._device)
         layers = []

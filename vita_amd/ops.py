@@ -25,6 +25,17 @@ def _dev(*ts):
             raise _lib.VitaHipError("vita_amd operators need GPU tensors (no CPU fallback)")
 
 
+def _c(t, name="tensor"):
+    """kernels index raw pointers: require a dense row-major tensor (rows may be strided views)."""
+    if t is not None and t.ndim >= 1 and t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise ValueError(f"{name} must be contiguous along its last dimension (got strides {t.stride()})")
+    return t
+
+
+def _dense(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _f32(t, name="tensor"):
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
@@ -42,7 +53,9 @@ def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=No
          ldc=None):
     """out[orow(m), :] = epilogue(A[arow(m, k)] @ w.T).  a: fp32 [rows, lda]; w: bf16 [N, K] (or [E, N, K] grouped)."""
     _dev(a, w, out)
-    _f32(a, "a"); _bf16(w, "w")
+    _f32(_c(a, "a"), "a"); _bf16(w, "w")
+    if not w.is_contiguous():
+        raise ValueError("w must be contiguous")
     lib = _lib.load()
     g = GemmArgs()
     N, K = int(w.shape[-2]), int(w.shape[-1])
@@ -77,6 +90,8 @@ def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=No
 def attention(q, k, v, out, *, B, Hq, Hkv, Sq, Sk, d, ldq, hsq, ldk, hsk, ldv, hsv, ldo, bsq=0, bsk=0, bso=0, scale,
               causal=False, q_off=0, klen=None, chunk=0, left=-1, p=None, ldp=0, hsp=0, bias_u=None, bias_v=None):
     _dev(q, k, v, out)
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (p, "p")):
+        _c(t, nm)
     lib = _lib.load()
     a = AttnArgs()
     a.Q, a.ldq, a.hsq = q.data_ptr(), ldq, hsq
@@ -98,9 +113,10 @@ def attention(q, k, v, out, *, B, Hq, Hkv, Sq, Sk, d, ldq, hsq, ldk, hsk, ldv, h
 
 def layernorm(x, w, b, eps, *, act=None, post_scale=1.0, out=None):
     _dev(x, w)
+    _c(x, "x")
     rows, cols = x.shape[0], x.shape[1]
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
     check(_lib.load().vh_layernorm(_p(x), x.stride(0), _p(out), out.stride(0), _p(w), _p(b), rows, cols, eps,
                                    ACT[act], post_scale, _stream()), "vh_layernorm")
     return out
@@ -108,6 +124,7 @@ def layernorm(x, w, b, eps, *, act=None, post_scale=1.0, out=None):
 
 def rmsnorm(x, w, eps, out=None):
     _dev(x, w)
+    x = _dense(x)
     if out is None:
         out = torch.empty_like(x)
     check(_lib.load().vh_rmsnorm(_p(x), _p(out), _p(w), x.shape[0], x.shape[1], eps, _stream()), "vh_rmsnorm")
@@ -116,6 +133,7 @@ def rmsnorm(x, w, eps, out=None):
 
 def vit_patchify(pix, patch, kpad):
     _dev(pix)
+    pix = _dense(pix)
     n, _, img, _ = pix.shape
     g = img // patch
     out = torch.empty((n * g * g, kpad), dtype=torch.float32, device=pix.device)
@@ -139,6 +157,7 @@ def vit_pixel_shuffle(x, n, grid, hid, mul):
 
 def audio_conv1(feats, mean, istd, w, b):
     _dev(feats, w)
+    feats = _dense(feats)
     T, F = feats.shape
     Cc = w.shape[0]
     T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
