@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: greedy-decode tokens/s (+ prefill / encoder ms) of the
+VITA-Mixtral-8x7B geometry on a 1 image + 10 s audio + text prompt, tensor-parallel over N GPUs.
+
+  python bench.py --gpus 1 --steps 64 --warmup 8
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one greedy decode step (one pass of the decode hot path over the whole model for one
+token).  Warm-up steps are untimed; exactly K steps are timed between barrier + synchronize pairs,
+inputs (weights, KV cache, prompt) resident in HBM; value = K / max-over-ranks time.  Rank 0 prints
+ONE JSON line.  Data and weights are synthetic (no checkpoint offline): seeded N(0, 0.02) weights of
+the released geometry, a random 448x448 image, a seeded 10 s waveform, random prompt ids."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(cfg, n_layers=2, ctx=64, n_tok=6):
+    """The oracle (numpy port of the HF Mixtral arithmetic the reference calls) timed on this box's
+    host cores: `n_layers` real-geometry decoder layers + LM head, decode steps at a short context,
+    extrapolated to 32 layers.  Bounded to a few seconds of weight generation + ~10-20 s of compute."""
+    import copy
+    from oracle import mixtral as om
+    t = copy.deepcopy(cfg.text)
+    t.num_hidden_layers = n_layers
+    rng = np.random.default_rng(0)
+    H, I, E, hd = t.hidden_size, t.intermediate_size, t.num_local_experts, t.head_dim
+
+    def W(*shape):  # cheap uniform init (values do not matter for timing), distinct memory per tensor
+        return (rng.random(shape, dtype=np.float32) - 0.5) * np.float32(0.07)
+
+    sd = {"model.embed_tokens.weight": W(1024, H), "model.norm.weight": np.ones(H, np.float32),
+          "lm_head.weight": W(t.vocab_size, H)}
+    for l in range(n_layers):
+        p = f"model.layers.{l}."
+        sd[p + "input_layernorm.weight"] = np.ones(H, np.float32)
+        sd[p + "post_attention_layernorm.weight"] = np.ones(H, np.float32)
+        sd[p + "self_attn.q_proj.weight"] = W(t.num_attention_heads * hd, H)
+        sd[p + "self_attn.k_proj.weight"] = W(t.num_key_value_heads * hd, H)
+        sd[p + "self_attn.v_proj.weight"] = W(t.num_key_value_heads * hd, H)
+        sd[p + "self_attn.o_proj.weight"] = W(H, t.num_attention_heads * hd)
+        sd[p + "block_sparse_moe.gate.weight"] = W(E, H)
+        for e in range(E):
+            q = p + f"block_sparse_moe.experts.{e}."
+            sd[q + "w1.weight"], sd[q + "w2.weight"], sd[q + "w3.weight"] = W(I, H), W(H, I), W(I, H)
+    orc = om.MixtralOracle(sd, t)
+    del sd
+    x = W(ctx, H)
+    orc.forward(x)                                   # prefill the oracle's KV cache (untimed)
+    tok = W(1, H)
+    t_full, t_head = [], []
+    for _ in range(n_tok):
+        t0 = time.perf_counter()
+        orc.forward(tok)
+        t_full.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        _ = (om.rmsnorm(tok, orc.norm, t.rms_norm_eps) @ orc.lm_head.T)
+        t_head.append(time.perf_counter() - t0)
+    full, head = float(np.median(t_full[1:])), float(np.median(t_head[1:]))
+    per_layer = max(full - head, 1e-9) / n_layers
+    tok_s = 1.0 / (per_layer * cfg.text.num_hidden_layers + head)
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": round(tok_s, 4), "unit": "tokens/s", "cores": int(threads), "kind": "port",
+            "sample": f"numpy fp32 oracle: {n_layers} of {cfg.text.num_hidden_layers} real-geometry decoder layers + "
+                      f"LM head, {n_tok - 1} timed decode steps at ctx {ctx}, median, extrapolated x"
+                      f"{cfg.text.num_hidden_layers}/{n_layers} (the full fp32 model is 187 GB)",
+            "ms_per_layer_token": round(per_layer * 1e3, 3), "ms_lm_head": round(head * 1e3, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from vita_amd.checkpoint import synth_mixtral_device, synth_state_dict
+    from vita_amd.config import VitaConfig, audio_token_count
+    from vita_amd.audio_frontend import kaldi_fbank
+    from vita_amd.host.constants import AUDIO_TOKEN_INDEX, IMAGE_TOKEN_INDEX
+    from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
+
+    cfg = VitaConfig()
+    if args.layers:
+        cfg.text.num_hidden_layers = args.layers
+    t = cfg.text
+    K, Wm = args.steps, args.warmup
+
+    # ---- model: random-init weights of the released geometry --------------------------------------
+    t0 = time.time()
+    packed = synth_mixtral_device(cfg, dev, seed=0, rank=rank, world=world)
+    sd_enc = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
+    model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=K + Wm + 8,
+                                   max_prefill=1024, rank=rank, world=world, keep_scores=False)
+    model.get_vision_tower().load_model()
+    eng = model.engine
+    collective = "none"
+    if world > 1:
+        collective = args.collective
+        if collective == "rccl":
+            try:
+                import ctypes
+                from vita_amd import _lib
+                uid = ctypes.create_string_buffer(128)
+                if rank == 0:
+                    _lib.check(_lib.load().vh_rccl_unique_id(uid), "vh_rccl_unique_id")
+                obj = [bytes(uid.raw)]
+                dist.broadcast_object_list(obj, src=0)
+                eng.use_rccl(obj[0])
+            except Exception as e:  # fall back to torch.distributed's RCCL communicator
+                if rank == 0:
+                    print(f"[bench] native RCCL path unavailable ({e}); using torch.distributed all_reduce", file=sys.stderr)
+                collective = "torch"
+        if collective == "torch":
+            eng.use_torch_allreduce()
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+
+    # ---- synthetic request: 1 image tile + 10 s audio + text (configs[2]) -----------------------------
+    g = torch.Generator(device="cpu").manual_seed(2)
+    image = ((torch.rand((1, 3, 448, 448), generator=g) - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+             / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)).to(dev)
+    wav = 0.1 * np.random.default_rng(3).standard_normal(160000)
+    feats = kaldi_fbank(wav * (1 << 15), 16000)                      # [998, 80]
+    n_aud_tok = audio_token_count(feats.shape[0])
+    rng = np.random.default_rng(1)
+    sys_ids = rng.integers(3, 51000, size=139).tolist()              # stand-in for the ~140-token system prompt
+    txt_ids = rng.integers(3, 51000, size=32).tolist()
+    ids = [t.bos_token_id] + sys_ids + [IMAGE_TOKEN_INDEX] + txt_ids + [AUDIO_TOKEN_INDEX]
+    input_ids = torch.tensor([ids], dtype=torch.long, device=dev)
+    audios = {"audios": torch.from_numpy(feats)[None].to(dev), "lengths": torch.tensor([feats.shape[0]], device=dev)}
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def encode_and_prefill():
+        e = [ev() for _ in range(5)]
+        e[0].record()
+        img_feats = model.encode_images(image)
+        e[1].record()
+        aud = model.get_audio_encoder()(audios["audios"], audios["lengths"])
+        e[2].record()
+        _, _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(input_ids, None, None, None, None, image, audios)
+        e[3].record()
+        eng.prefill(emb[0])
+        e[4].record()
+        torch.cuda.synchronize()
+        return emb.shape[1], {"vit_proj_ms": e[0].elapsed_time(e[1]), "audio_ms": e[1].elapsed_time(e[2]),
+                              "prefill_ms": e[3].elapsed_time(e[4]), "n_audio_tokens": int(aud["inputs_embeds"].shape[1])}
+
+    S, _ = encode_and_prefill()                                        # warm-up of the prefill path
+    S, phase = encode_and_prefill()
+    assert phase["n_audio_tokens"] == n_aud_tok
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- decode: W warm-up steps, then exactly K timed steps ---------------------------------------------
+    eng.decode(Wm)
+    eng.profile(stride=4, max_samples=K * 8 + 8)       # sample the gate|up GEMV of every 4th layer
+    barrier()
+    t1 = time.perf_counter()
+    eng.decode(K)
+    barrier()
+    dt = time.perf_counter() - t1
+    tot_ms, n_samp = eng.profile_read()
+    eng.profile(stride=0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    toks = eng.generated()
+    assert len(toks) == 1 + Wm + K
+
+    ms_step = dt * 1e3 / K
+    tok_s = K / dt
+    lay0 = packed["layers"][0]
+    I_r = lay0["w1"].shape[1]
+    gateup_bytes = 2 * 2 * I_r * t.hidden_size * 2 + t.num_local_experts * t.hidden_size * 2   # per launch, this rank
+    k_ms = tot_ms / max(n_samp, 1)
+    achieved = gateup_bytes / (k_ms * 1e-3) / 1e9 if n_samp else None
+    ctx_mid = S + Wm + K // 2
+    heads_r = lay0["wqkv"].shape[0] // t.head_dim                      # q + 2*kv heads on this rank
+    nkv_r = heads_r * t.num_key_value_heads // (t.num_attention_heads + 2 * t.num_key_value_heads)
+    per_layer_w = 2 * (lay0["wqkv"].numel() + lay0["wo"].numel() + 2 * 3 * I_r * t.hidden_size + lay0["wrouter"].numel())
+    step_bytes = t.num_hidden_layers * per_layer_w + 2 * packed["lm_head"].numel()   # algorithmic weight bytes / token
+    kv_bytes = t.num_hidden_layers * 2 * nkv_r * t.head_dim * 4 * ctx_mid            # fp32 KV cache read / token
+    eff = (step_bytes + kv_bytes) / (ms_step * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "decode_tokens_per_s", "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world,
+            "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16 weights, f32 activations/accumulate",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 1 image (448x448, 1 tile -> 256 tokens) + 10 s audio "
+                                   f"(998 fbank frames -> {n_aud_tok} tokens) + {len(ids) - 2} text ids, prefill S={S}, "
+                                   "greedy decode, batch 1; VITA-Mixtral-8x7B geometry (32 layers, 8 experts top-2)",
+                       "parallelism": f"tp{world}", "collective": collective, "prompt_tokens": int(S),
+                       "layers": t.num_hidden_layers},
+            "prefill_ms": round(phase["prefill_ms"], 3), "vit_projector_ms": round(phase["vit_proj_ms"], 3),
+            "audio_encoder_ms": round(phase["audio_ms"], 3),
+            "ttft_ms": round(phase["prefill_ms"] + phase["vit_proj_ms"] + phase["audio_ms"], 3),
+            "decode_effective_GBps_per_gpu": round(eff, 1),
+            "decode_effective_frac_of_8TBps": round(eff / HBM_PEAK_GBPS, 4),
+            "roofline": {"bound": "hbm", "kernel": "k_dec_gateup (router + gate|up GEMV of the 2 routed experts)",
+                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+                         "bytes_per_launch": gateup_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "samples": n_samp,
+                         "traffic": None},
+            "build_s": round(t_build, 1),
+        }
+        if args.layers:
+            out["INVALID_debug_layers"] = args.layers
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(VitaConfig())
+            except Exception as e:  # never lose the GPU line to a host-side problem
+                out["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

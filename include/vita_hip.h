@@ -154,6 +154,10 @@ const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: genera
 const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[2]: {pos, n_generated}    */
 const float* vh_mixtral_logits(const vh_mixtral_t* m);   /* fp32[max(1,logit_rows)][vocab]; row i = scores that produced token i */
 int vh_mixtral_reset(vh_mixtral_t* m, void* stream);     /* n_generated = 0, pos = 0      */
+/* Live HIP-event timing of the dominant decode kernel (gate|up expert GEMV): sample one launch
+ * every `stride` layers (0 = off), up to max_samples; read returns summed ms and sample count. */
+int vh_mixtral_profile(vh_mixtral_t* m, int stride, int max_samples);
+int vh_mixtral_profile_read(vh_mixtral_t* m, double* total_ms /* host */, int* count /* host */);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,8 @@ SIGNATURES = {
     "vh_mixtral_counters": (c_void_p, [c_void_p]),
     "vh_mixtral_logits": (c_void_p, [c_void_p]),
     "vh_mixtral_reset": (c_int, [c_void_p, c_void_p]),
+    "vh_mixtral_profile": (c_int, [c_void_p, c_int, c_int]),
+    "vh_mixtral_profile_read": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
 }
 
 _lib = None

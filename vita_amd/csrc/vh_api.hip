@@ -162,6 +162,10 @@ struct vh_mixtral {
     int *pids, *pgoff, *pstok, *psslot;
     // tensor parallel
     vh_allreduce_fn ar_fn; void* ar_user; void* rccl_comm;
+    // optional live timing of the dominant decode kernel (gate/up GEMV), sampled every prof_stride layers
+    int prof_stride = 0;
+    std::vector<hipEvent_t> prof_ev;  // start/stop pairs
+    size_t prof_used = 0;
 
     size_t carve(void* ws) {
         Carver cv{reinterpret_cast<char*>(ws), 0};
@@ -263,6 +267,7 @@ vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_laye
 
 void vh_mixtral_destroy(vh_mixtral_t* m) {
     if (!m) return;
+    for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
     if (m->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->rccl_comm);
     delete m;
 }
@@ -289,6 +294,34 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* uid) {
     if (rc != 0) return fail(VH_E_COMM, "ncclCommInitRank failed (%d)", rc);
     m->rccl_comm = comm;
     m->ar_fn = rccl_allreduce_cb; m->ar_user = m;
+    return VH_OK;
+}
+
+int vh_mixtral_profile(vh_mixtral_t* m, int stride, int max_samples) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    m->prof_stride = stride;
+    m->prof_used = 0;
+    while ((int)m->prof_ev.size() < 2 * max_samples) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return fail(VH_E_HIP, "hipEventCreate failed");
+        m->prof_ev.push_back(e);
+    }
+    return VH_OK;
+}
+
+int vh_mixtral_profile_read(vh_mixtral_t* m, double* total_ms, int* count) {
+    if (!m || !total_ms || !count) return fail(VH_E_ARG, "null argument");
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(m->prof_ev[i + 1]) != hipSuccess) return fail(VH_E_HIP, "event sync failed");
+        if (hipEventElapsedTime(&ms, m->prof_ev[i], m->prof_ev[i + 1]) != hipSuccess)
+            return fail(VH_E_HIP, "hipEventElapsedTime failed");
+        tot += ms; ++n;
+    }
+    *total_ms = tot; *count = n;
+    m->prof_used = 0;
     return VH_OK;
 }
 
@@ -418,8 +451,11 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
                                 nkv, m->c.max_ctx, m->nsplit, scale), "dec attn");
             VH_TRY(vhk_dec_oproj(st, m->part_o, m->part_ml, m->nsplit, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
             if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+            const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+            if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
             VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
                                   m->route, m->hbuf, 0), "dec gateup");
+            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe), "dec down");
             if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         }

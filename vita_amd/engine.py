@@ -133,6 +133,15 @@ class MixtralEngine:
         """scores of the most recent step (row n_gen-1 of the history, or the single row)."""
         return self.logits_all[min(self.n_gen - 1, self.logit_rows - 1) if self.logit_rows > 1 else 0]
 
+    def profile(self, stride, max_samples=2048):
+        check(self.lib.vh_mixtral_profile(self.h, int(stride), int(max_samples)), "vh_mixtral_profile")
+
+    def profile_read(self):
+        """(total_ms, n_samples) of the sampled gate|up GEMV launches since the last read."""
+        tot, n = C.c_double(0.0), C.c_int(0)
+        check(self.lib.vh_mixtral_profile_read(self.h, C.byref(tot), C.byref(n)), "vh_mixtral_profile_read")
+        return tot.value, n.value
+
     def generated(self):
         """(synchronising) list of token ids generated so far."""
         n = int(self.counters[1].item())
