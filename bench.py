@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--tune", default="", help="debug: kernel-variant knobs key=val[,key=val] (vh_tune)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +112,11 @@ def main():
     from vita_amd.host.constants import AUDIO_TOKEN_INDEX, IMAGE_TOKEN_INDEX
     from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
 
+    if args.tune:
+        from vita_amd import _lib as _l
+        for kv in args.tune.split(","):
+            k, v = kv.split("=")
+            _l.tune(k.strip(), int(v))
     cfg = VitaConfig()
     if args.layers:
         cfg.text.num_hidden_layers = args.layers
@@ -245,6 +251,8 @@ def main():
         }
         if args.layers:
             out["INVALID_debug_layers"] = args.layers
+        if args.tune:
+            out["tune"] = args.tune
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(VitaConfig())

@@ -36,6 +36,9 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
+/* Kernel-variant knobs for experiments (keys: "gateup_variant", "gateup_grid"); the defaults are
+ * the measured-best variants, results are identical across variants. */
+int vh_tune(const char* key, int value);
 
 /* ---- generic operators --------------------------------------------------------------
  * vh_gemm: C = epilogue(A W^T).  Replaces every nn.Linear / conv-as-GEMM on the path:

@@ -1,0 +1,14 @@
+"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite) kernel trace into the per-kernel stats table that
+`--stats` prints: python profiles/summarize.py <results.db> [> profiles/<name>.txt]"""
+import sqlite3
+import sys
+
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
+                 "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+print(f"# rocprofv3 --kernel-trace --stats summary of {sys.argv[1]}")
+print(f"# total kernel time {tot / 1e3:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+print(f"{'pct':>7} {'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>9} {'max_us':>9}  kernel")
+for r in rows:
+    print(f"{r[2] / tot * 100:7.2f} {r[1]:7d} {r[2]:12.1f} {r[3]:10.2f} {r[4]:9.2f} {r[5]:9.2f}  {r[0][:110]}")

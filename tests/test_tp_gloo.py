@@ -1,0 +1,117 @@
+"""World-size-2 check of the tensor-parallel partition on CPU (gloo).
+
+The device engine shards the backbone exactly as the reference's vLLM flavour does
+(web_demo/vllm_tools/vllm_file/mixtral.py:375-414,441-476): q/kv heads column-sharded, o_proj
+row-sharded, every expert on every rank with intermediate/world columns, one all-reduce(sum) of
+the [tokens, hidden] partial after o_proj and one after the MoE down projection.  The slices
+come from vita_amd.checkpoint.tp_slices — the same function pack_mixtral() uses for the HIP
+engine — so this test proves the partition + collective placement reproduces the unsharded
+oracle; the per-rank arithmetic here is the oracle's (no GPU in this container)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import mixtral as om
+from vita_amd.checkpoint import synth_state_dict, tp_slices
+from vita_amd.config import VitaConfig
+
+F32 = np.float32
+
+
+def _allreduce(x):
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=F32))
+    dist.all_reduce(t)
+    return t.numpy()
+
+
+def _tp_forward(sd, t, x, rank, world, n_allreduce):
+    """One prefill forward of the sharded backbone on this rank; returns last-row logits."""
+    qs, kvs, ff = tp_slices(t, rank, world)
+    d = t.head_dim
+    nq_r, nkv_r = (qs.stop - qs.start) // d, (kvs.stop - kvs.start) // d
+    S = x.shape[0]
+    cos, sin = om.rope_cos_sin(np.arange(S), d, t.rope_theta)
+    g = lambda k: np.asarray(sd[k], F32)
+    x = x.astype(F32)
+    for l in range(t.num_hidden_layers):
+        p = f"model.layers.{l}."
+        xn = om.rmsnorm(x, g(p + "input_layernorm.weight"), t.rms_norm_eps)
+        q = (xn @ g(p + "self_attn.q_proj.weight")[qs].T).astype(F32).reshape(S, nq_r, d).transpose(1, 0, 2)
+        k = (xn @ g(p + "self_attn.k_proj.weight")[kvs].T).astype(F32).reshape(S, nkv_r, d).transpose(1, 0, 2)
+        v = (xn @ g(p + "self_attn.v_proj.weight")[kvs].T).astype(F32).reshape(S, nkv_r, d).transpose(1, 0, 2)
+        a = om.attention(om.apply_rope(q, cos, sin), om.apply_rope(k, cos, sin), v, 0)
+        part = (a @ g(p + "self_attn.o_proj.weight")[:, qs].T).astype(F32)
+        x = (x + _allreduce(part)).astype(F32); n_allreduce[0] += 1
+        xn = om.rmsnorm(x, g(p + "post_attention_layernorm.weight"), t.rms_norm_eps)
+        E = t.num_local_experts
+        ex = lambda nm, sl: np.stack([g(p + f"block_sparse_moe.experts.{e}.{nm}.weight")[sl] for e in range(E)])
+        lw = {"gate": g(p + "block_sparse_moe.gate.weight"), "w1": ex("w1", ff), "w3": ex("w3", ff),
+              "w2": ex("w2", (slice(None), ff))}
+        y, _, _ = om.moe(xn, lw, t.num_experts_per_tok)          # router replicated, experts I-sliced
+        x = (x + _allreduce(y)).astype(F32); n_allreduce[0] += 1
+    return (om.rmsnorm(x[-1:], g("model.norm.weight"), t.rms_norm_eps) @ g("lm_head.weight").T).astype(F32)[0]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = VitaConfig.tiny()
+        sd = synth_state_dict(cfg, seed=0, rich=True, parts=("text",))
+        rng = np.random.default_rng(7)
+        ids = rng.integers(3, cfg.text.vocab_size, size=19)
+        x = np.asarray(sd["model.embed_tokens.weight"], F32)[ids]
+        n_ar = [0]
+        logits = _tp_forward(sd, cfg.text, x, rank, world, n_ar)
+        gathered = [torch.zeros(logits.shape[0]) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(logits))
+        if rank == 0:
+            full, _ = om.MixtralOracle(sd, cfg.text).forward(x)
+            ret["err"] = float(np.max(np.abs(full[-1] - logits)))
+            ret["argmax_same"] = bool(int(np.argmax(full[-1])) == int(np.argmax(logits)))
+            ret["ranks_agree"] = bool(all(torch.equal(gathered[0], gi) for gi in gathered))
+            ret["n_allreduce"] = n_ar[0]
+            ret["layers"] = cfg.text.num_hidden_layers
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_tp2_partition_matches_unsharded_oracle():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert ret["ranks_agree"]                        # every rank ends with identical logits
+        assert ret["n_allreduce"] == 2 * ret["layers"]   # the reference's 2 collectives per layer
+        assert ret["err"] < 1e-4, ret["err"]             # fp32 summation-order noise only
+        assert ret["argmax_same"]
+
+
+def test_tp_slices_cover_real_geometry():
+    t = VitaConfig().text
+    for world in (1, 2, 4, 8):
+        qcov, kvcov, ffcov = [], [], []
+        for r in range(world):
+            q, kv, ff = tp_slices(t, r, world)
+            qcov += list(range(q.start, q.stop, t.head_dim)); kvcov += list(range(kv.start, kv.stop, t.head_dim))
+            ffcov.append((ff.start, ff.stop))
+            # each rank's q heads map onto exactly its own kv heads (GQA group stays local)
+            g = t.num_attention_heads // t.num_key_value_heads
+            assert q.start // t.head_dim // g == kv.start // t.head_dim
+        assert qcov == list(range(0, t.num_attention_heads * t.head_dim, t.head_dim))
+        assert kvcov == list(range(0, t.num_key_value_heads * t.head_dim, t.head_dim))
+        assert ffcov[0][0] == 0 and ffcov[-1][1] == t.intermediate_size
+        assert all(ffcov[i][1] == ffcov[i + 1][0] for i in range(world - 1))

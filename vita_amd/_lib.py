@@ -63,6 +63,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
 SIGNATURES = {
     "vh_version": (c_int, []),
     "vh_last_error": (C.c_char_p, []),
+    "vh_tune": (c_int, [C.c_char_p, c_int]),
     "vh_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "vh_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "vh_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
@@ -118,6 +119,10 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def tune(key, value):
+    check(load().vh_tune(key.encode(), int(value)), f"vh_tune({key})")
 
 
 def check(rc, what=""):

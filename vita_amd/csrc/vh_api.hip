@@ -29,12 +29,23 @@ int check_launch(const char* what, int rc) {
     return VH_OK;
 }
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+VhTuning g_tuning;
 }  // namespace
+
+VhTuning* vh_tuning() { return &g_tuning; }
 
 extern "C" {
 
 int vh_version(void) { return 100; }
 const char* vh_last_error(void) { return g_err; }
+
+int vh_tune(const char* key, int value) {
+    if (!key) return fail(VH_E_ARG, "vh_tune: null key");
+    if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
+    if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
+    return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
+}
 
 int vh_gemm(const vh_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->C) return fail(VH_E_ARG, "vh_gemm: null pointer");
@@ -152,11 +163,12 @@ struct vh_mixtral {
     std::vector<vh_mixtral_layer> L;
     const uint16_t* embed; const float* final_norm; const uint16_t* lm_head;
     const float* rope_cos; const float* rope_sin;
-    int nq, nkv, hd, H, I, E, V, nqkv, nsplit, lm_grid;
+    int nq, nkv, hd, H, I, E, V, nqkv, max_splits, lm_grid;
+    int host_pos = 0;  // host mirror of counters[0] (sizes the split-KV grid without a device read)
     // state
     float *kcache, *vcache;  // [layer][nkv][max_ctx][hd]
-    float *xa, *xb, *delta_attn, *delta_moe, *qkv, *part_o, *part_ml, *hbuf, *logits, *blk_val;
-    int *blk_idx, *route, *counters, *out_tokens;
+    float *xa, *xb, *delta_attn, *delta_moe, *qkv, *part_o, *part_ml, *attn_out, *hbuf, *logits, *blk_val;
+    int *blk_idx, *route, *counters, *out_tokens, *attn_cnt;
     // prefill scratch
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
     int *pids, *pgoff, *pstok, *psslot;
@@ -175,8 +187,10 @@ struct vh_mixtral {
         xa = cv.take<float>(H); xb = cv.take<float>(H);
         delta_attn = cv.take<float>(H); delta_moe = cv.take<float>(H);
         qkv = cv.take<float>(nqkv);
-        part_o = cv.take<float>((size_t)nq * nsplit * hd);
-        part_ml = cv.take<float>((size_t)nq * nsplit * 2);
+        part_o = cv.take<float>((size_t)nq * max_splits * hd);
+        part_ml = cv.take<float>((size_t)nq * max_splits * 2);
+        attn_out = cv.take<float>((size_t)nq * hd);
+        attn_cnt = cv.take<int>(nkv);  // arrival tickets; zero at creation, reset by each last arriver
         hbuf = cv.take<float>((size_t)2 * I);
         logits = cv.take<float>((size_t)hist_rows() * V);
         blk_val = cv.take<float>(lm_grid);
@@ -198,12 +212,12 @@ struct vh_mixtral {
     void derive() {
         nq = c.n_q_heads; nkv = c.n_kv_heads; hd = c.head_dim; H = c.hidden; I = c.inter; E = c.n_experts;
         V = c.vocab; nqkv = (nq + 2 * nkv) * hd;
-        nsplit = c.nsplit > 0 ? c.nsplit : (c.max_ctx >= 1024 ? 8 : (c.max_ctx >= 256 ? 4 : 2));
+        max_splits = (c.max_ctx + 63) / 64;
         lm_grid = (V + 7) / 8;
         if (lm_grid > 1024) lm_grid = 1024;
     }
     int allreduce(float* buf, long count, hipStream_t st) {
-        if (c.tp_world <= 1) return 0;
+        if (c.tp_world <= 1 && !vh_tuning()->force_allreduce) return 0;
         if (!ar_fn) return -1;
         return ar_fn(ar_user, buf, count, st);
     }
@@ -348,7 +362,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     if (pos0 < 0 || pos0 + Sn >= m->c.max_ctx) return fail(VH_E_SHAPE, "prefill exceeds KV capacity %d", m->c.max_ctx);
     hipStream_t st = S(stream);
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
-    const bool tp = m->c.tp_world > 1;
+    const bool tp = m->c.tp_world > 1 || vh_tuning()->force_allreduce;
     const float scale = 1.0f / sqrtf((float)hd);
     if (hipMemcpyAsync(m->px, embeds, (size_t)Sn * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(VH_E_HIP, "prefill: embed copy failed");
@@ -427,6 +441,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
                           m->logits, m->blk_val, m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "lm_head");
     VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters, m->counters + 1,
                           m->out_tokens, m->c.max_new, /*mode=*/0, /*set_pos=*/pos0 + Sn), "select");
+    m->host_pos = pos0 + Sn;
     if (logits_out)
         hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipError_t e = hipGetLastError();
@@ -441,15 +456,17 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
     for (int step = 0; step < n_steps; ++step) {
+        if (m->host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx);
         for (int l = 0; l < m->c.n_layers; ++l) {
             const vh_mixtral_layer& w = m->L[l];
             float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
             float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
             VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                                m->qkv), "dec qkv");
-            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml, nq,
-                                nkv, m->c.max_ctx, m->nsplit, scale), "dec attn");
-            VH_TRY(vhk_dec_oproj(st, m->part_o, m->part_ml, m->nsplit, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
+            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                                m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale),
+                   "dec attn");
+            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
             if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
             const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
             if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
@@ -463,6 +480,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
                               m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "dec lm_head");
         VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters,
                               m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
+        m->host_pos += 1;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VH_E_HIP, "decode: %s", hipGetErrorString(e));

@@ -5,23 +5,25 @@
 // GEMV whose prologue recomputes the (tiny, L2-resident) activation-side work instead
 // of paying a kernel boundary for it:
 //
-//   k_dec_qkv     x = x_in + delta ; RMSNorm ; fused Q|K|V GEMV           (K20,K21)
-//   k_dec_attn    RoPE(q,k_new) ; KV-cache append ; split-KV GQA attention (K22,K23)
-//   k_dec_oproj   split-KV combine ; O-projection GEMV -> delta_attn       (K24)
-//   k_dec_gateup  x = x_in + delta ; RMSNorm ; router softmax/top-2 (on device, no
-//                 host sync) ; gate|up GEMV of the two chosen experts ; SiLU*up  (K25,K26)
-//   k_dec_down    down GEMV of the two experts, routing-weighted sum -> delta_moe (K26)
-//   k_dec_lmhead  final RMSNorm ; LM-head GEMV ; per-block argmax          (K27)
-//   k_dec_select  global argmax ; append token ; pos++ ; next embedding    (K28,K18)
+//   k_dec_gemv<NORM>   x = x_in + delta ; RMSNorm ; fused Q|K|V GEMV           (K20,K21)
+//   k_dec_attn         RoPE(q,k_new) ; KV-cache append ; split-KV GQA attention ;
+//                      last-arriver merge of the split partials                 (K22,K23)
+//   k_dec_gemv<!NORM>  O-projection GEMV -> delta_attn                          (K24)
+//   k_dec_gateup       x = x_in + delta ; RMSNorm ; router softmax/top-2 (on device, no
+//                      host sync) ; gate|up GEMV of the two chosen experts ; SiLU*up (K25,K26)
+//   k_dec_down         down GEMV of the two experts, routing-weighted sum -> delta_moe (K26)
+//   k_dec_lmhead       final RMSNorm ; LM-head GEMV ; per-block argmax          (K27)
+//   k_dec_select       global argmax ; append token ; pos++ ; next embedding    (K28,K18)
 //
 // GEMV shape: a 256-thread block owns R output rows; thread t owns 16-byte chunks
 // c = t + 256*j of every row (a wave reads 1 KiB contiguous per load instruction),
-// keeps its slice of the fp32 activation vector in registers and issues all R*NJ
-// weight loads before the first FMA (deep vmcnt, no LDS round trip — guide §5 "GEMV /
-// M<=16 decode weights").  Output rows are reduced wave->LDS->thread, no atomics, so
-// results are deterministic.  Residual adds are deferred into the consumer's prologue
-// ("delta" buffers) so that under tensor parallelism the same kernels run unchanged
-// with an all-reduce on the delta buffer between them.
+// keeps its slice of the fp32 activation vector in registers and puts all R*NJ weight
+// loads in flight before anything else (deep vmcnt, no LDS round trip — guide §5 "GEMV /
+// M<=16 decode weights"); persistent variants keep the NEXT row group's loads in flight
+// while the current group is reduced.  Output rows are reduced wave->LDS->thread, no
+// atomics, so results are deterministic.  Residual adds are deferred into the consumer's
+// prologue ("delta" buffers) so that under tensor parallelism the same kernels run
+// unchanged with an all-reduce on the delta buffer between them.
 //
 // Reference semantics restated: transformers/models/mixtral/modeling_mixtral.py
 // (MixtralRMSNorm, MixtralAttention + apply_rotary_pos_emb, MixtralTopKRouter,
@@ -75,37 +77,32 @@ __device__ __forceinline__ void store_x(float* __restrict__ x, int K, const floa
     }
 }
 
-// MixtralRMSNorm in fp32: (x * rsqrt(mean(x^2) + eps)) * w   (modeling_mixtral.py:143-148)
+// x <- x * w_norm (elementwise); returns this thread's share of sum(x^2).  The scalar
+// rsqrt(mean(x^2)+eps) of MixtralRMSNorm (modeling_mixtral.py:143-148) commutes with the GEMV,
+// so it is applied to the reduced dot products: one block reduction instead of two.
 template <int NJ>
-__device__ __forceinline__ void rmsnorm_x(const float* __restrict__ w, int K, float eps,
-                                          float (&xr)[NJ][8], float* red) {
-    float ss[1] = {0.f};
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ss[0] = fmaf(xr[j][i], xr[j][i], ss[0]);
-    block256_sum<1>(ss, red);
-    const float inv = rsqrtf(ss[0] / (float)K + eps);
+__device__ __forceinline__ float scale_by_norm_weight(const float* __restrict__ w, int K, float (&xr)[NJ][8]) {
+    float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c * 8 < K) {
             const float4 a = reinterpret_cast<const float4*>(w)[c * 2];
             const float4 b = reinterpret_cast<const float4*>(w)[c * 2 + 1];
-            xr[j][0] = xr[j][0] * inv * a.x; xr[j][1] = xr[j][1] * inv * a.y;
-            xr[j][2] = xr[j][2] * inv * a.z; xr[j][3] = xr[j][3] * inv * a.w;
-            xr[j][4] = xr[j][4] * inv * b.x; xr[j][5] = xr[j][5] * inv * b.y;
-            xr[j][6] = xr[j][6] * inv * b.z; xr[j][7] = xr[j][7] * inv * b.w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
+            xr[j][0] *= a.x; xr[j][1] *= a.y; xr[j][2] *= a.z; xr[j][3] *= a.w;
+            xr[j][4] *= b.x; xr[j][5] *= b.y; xr[j][6] *= b.z; xr[j][7] *= b.w;
         }
     }
+    return ss;
 }
 
-// R rows of W (bf16, row stride ldw elements) dotted with the register-resident x.
-// rows[r] must be valid pointers (callers clamp out-of-range rows and drop the result).
+// R rows of W (bf16) against the register-resident x, in two phases so the weight loads are in
+// flight BEFORE the (L2-resident) activation loads and prologue math.  rows[r] must be valid
+// pointers (callers clamp out-of-range rows and drop the result).
 template <int NJ, int R>
-__device__ __forceinline__ void gemv_rows(const uint16_t* const (&rows)[R], int K,
-                                          const float (&xr)[NJ][8], float (&acc)[R]) {
-    uint4 w[R][NJ];
+__device__ __forceinline__ void gemv_issue(const uint16_t* const (&rows)[R], int K, uint4 (&w)[R][NJ]) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -114,6 +111,9 @@ __device__ __forceinline__ void gemv_rows(const uint16_t* const (&rows)[R], int 
             if (c * 8 < K) w[r][j] = ld_weight16(rows[r] + (size_t)c * 8);
             else w[r][j] = make_uint4(0, 0, 0, 0);
         }
+}
+template <int NJ, int R>
+__device__ __forceinline__ void gemv_fma(const uint4 (&w)[R][NJ], const float (&xr)[NJ][8], float (&acc)[R]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float a = 0.f;
@@ -123,75 +123,91 @@ __device__ __forceinline__ void gemv_rows(const uint16_t* const (&rows)[R], int 
     }
 }
 
-// ---- K_A: residual add + RMSNorm + fused QKV GEMV -----------------------------------
-template <int NJ, int R>
-__global__ __launch_bounds__(256) void k_dec_qkv(const float* __restrict__ x_in, const float* __restrict__ delta,
-                                                 float* __restrict__ x_out, const float* __restrict__ norm_w,
-                                                 float eps, const uint16_t* __restrict__ W, int N, int K,
-                                                 float* __restrict__ out) {
-    __shared__ float red[4 * R];
-    float xr[NJ][8];
-    load_x<NJ>(x_in, K, xr);
-    if (delta) add_x<NJ>(delta, K, xr);
-    if (blockIdx.x == 0 && x_out) store_x<NJ>(x_out, K, xr);
-    rmsnorm_x<NJ>(norm_w, K, eps, xr, red);
-
+// ---- K_A / K_C: (residual add + RMSNorm +) row-parallel GEMV -------------------------------
+// NORM=true : out = rsqrt(mean(x^2)+eps) * W (x*w_norm), x = x_in + delta      (fused QKV)
+// NORM=false: out = W x_in                                                    (O projection)
+template <int NJ, int R, bool NORM>
+__global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
+                                                  float* __restrict__ x_out, const float* __restrict__ norm_w,
+                                                  float eps, const uint16_t* __restrict__ W, int N, int K,
+                                                  float* __restrict__ out) {
+    __shared__ float red[4 * (R + 1)];
     const int n0 = blockIdx.x * R;
     const uint16_t* rows[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, N - 1) * K;
+    uint4 w[R][NJ];
+    gemv_issue<NJ, R>(rows, K, w);
+
+    float xr[NJ][8];
+    load_x<NJ>(x_in, K, xr);
+    if (delta) add_x<NJ>(delta, K, xr);
+    if (blockIdx.x == 0 && x_out) store_x<NJ>(x_out, K, xr);
+    float vals[R + 1];
+    vals[R] = NORM ? scale_by_norm_weight<NJ>(norm_w, K, xr) : 0.f;
     float acc[R];
-    gemv_rows<NJ, R>(rows, K, xr, acc);
-    block256_sum<R>(acc, red);
+    gemv_fma<NJ, R>(w, xr, acc);
+#pragma unroll
+    for (int r = 0; r < R; ++r) vals[r] = acc[r];
+    block256_sum<R + 1>(vals, red);
+    const float inv = NORM ? rsqrtf(vals[R] / (float)K + eps) : 1.0f;
     if (threadIdx.x < R && n0 + threadIdx.x < N) {
         float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = acc[r];
-        out[n0 + threadIdx.x] = v;
+        for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = vals[r];
+        out[n0 + threadIdx.x] = v * inv;
     }
 }
 
-// ---- K_B: RoPE + KV append + split-KV GQA attention ---------------------------------
-// grid (nkv, nsplit); wave w < G serves query head h*G + w; lanes index keys for QK^T
-// and head dims (2 per lane) for PV.  K/V tiles (64 keys) are staged through LDS once
-// and shared by the G query heads of the KV head (K23: "4 q-heads share each LDS-staged
-// KV tile").  head_dim is 128 (config.json:16-44).
+// ---- K_B: RoPE + KV append + split-KV GQA attention + in-kernel merge -----------------------
+// grid (nkv, nsplit): block (h, sp) owns keys [64 sp, 64 sp + 64) of KV head h — exactly one LDS
+// tile, shared by the G = nq/nkv query heads of that KV head (wave w < G serves head h*G + w;
+// lanes index keys for QK^T and head dims, 2 per lane, for PV).  The host sizes nsplit from its
+// mirror of the position, so no block is empty.  Each block publishes (m, l, o) partials; the
+// LAST block to arrive for a KV head merges them (agent-scope release -> ticket -> acquire, guide
+// §6 G16 counter form) and writes the attention output, so the O-projection reads 16 KB instead of
+// re-merging the partials in each of its blocks.  head_dim is 128 (config.json:16-44).
 #define DA_KT 64
 #define DA_KSTR 132
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
                                                   float* __restrict__ vcache, const int* __restrict__ pos_ptr,
                                                   const float* __restrict__ rope_cos,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
-                                                  float* __restrict__ part_ml, int nq, int nkv, int max_ctx,
-                                                  int nsplit, float scale) {
+                                                  float* __restrict__ part_ml, int* __restrict__ cnt,
+                                                  float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
+                                                  int max_splits, float scale) {
     __shared__ __attribute__((aligned(16))) float q_s[4][128];
     __shared__ __attribute__((aligned(16))) float kn_s[128];
     __shared__ __attribute__((aligned(16))) float vn_s[128];
     __shared__ __attribute__((aligned(16))) float Kt[DA_KT * DA_KSTR];
     __shared__ __attribute__((aligned(16))) float Vt[DA_KT * 128];
+    __shared__ int last_s;
 
-    const int h = blockIdx.x, sp = blockIdx.y;
+    const int h = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = nq / nkv;
     const int pos = *pos_ptr;
-    const int ctx = pos + 1;
-    const int span = (((ctx + nsplit - 1) / nsplit) + DA_KT - 1) & ~(DA_KT - 1);
-    const int k0 = sp * span;
-    const int k1 = min(ctx, k0 + span);
+    const int k0 = sp * DA_KT;
+    const int k1 = min(pos + 1, k0 + DA_KT);
     const int head = h * G + wid;
 
-    if (k0 >= k1) {  // empty split (uniform per block)
-        if (wid < G) {
-            reinterpret_cast<float2*>(part_o + ((size_t)head * nsplit + sp) * 128)[lane] = make_float2(0.f, 0.f);
-            if (lane == 0) {
-                part_ml[((size_t)head * nsplit + sp) * 2] = -INFINITY;
-                part_ml[((size_t)head * nsplit + sp) * 2 + 1] = 0.f;
-            }
+    // 1. put the K/V tile loads in flight first (8 float4 each per thread)
+    float4 kreg[8], vreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 5, c4 = idx & 31;
+        const int key = k0 + row;
+        if (key < k1 && key != pos) {
+            kreg[i] = reinterpret_cast<const float4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
+            vreg[i] = reinterpret_cast<const float4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
+        } else {
+            kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[i] = kreg[i];
         }
-        return;
     }
 
-    // rotate-half RoPE (modeling_mixtral.py:203-241): out = x*cos + rotate_half(x)*sin
+    // 2. rotate-half RoPE (modeling_mixtral.py:203-241): out = x*cos + rotate_half(x)*sin
     const float c = rope_cos[(size_t)pos * 64 + lane], s = rope_sin[(size_t)pos * 64 + lane];
     if (wid < G) {
         const float a = qkv[head * 128 + lane], b = qkv[head * 128 + 64 + lane];
@@ -214,160 +230,132 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
     }
     __syncthreads();
 
-    float4 qreg[32];
-    if (wid < G) {
+    // 3. tiles -> LDS (the new token's row comes from LDS, not from the cache)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) qreg[i] = reinterpret_cast<const float4*>(q_s[wid])[i];
-    }
-
-    float m = -INFINITY, l = 0.f;
-    float2 o = make_float2(0.f, 0.f);
-
-    for (int t0 = k0; t0 < k1; t0 += DA_KT) {
-        // stage K and V tiles: 64 rows x 32 float4 each
-        for (int idx = tid; idx < DA_KT * 32; idx += 256) {
-            const int row = idx >> 5, c4 = idx & 31;
-            const int key = t0 + row;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (key < k1) {
-                if (key == pos) {
-                    kv = reinterpret_cast<const float4*>(kn_s)[c4];
-                    vv = reinterpret_cast<const float4*>(vn_s)[c4];
-                } else {
-                    kv = reinterpret_cast<const float4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
-                    vv = reinterpret_cast<const float4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
-                }
-            }
-            *reinterpret_cast<float4*>(&Kt[row * DA_KSTR + c4 * 4]) = kv;
-            *reinterpret_cast<float4*>(&Vt[row * 128 + c4 * 4]) = vv;
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 5, c4 = idx & 31;
+        float4 kv = kreg[i], vv = vreg[i];
+        if (k0 + row == pos) {
+            kv = reinterpret_cast<const float4*>(kn_s)[c4];
+            vv = reinterpret_cast<const float4*>(vn_s)[c4];
         }
-        __syncthreads();
-        if (wid < G) {
-            const bool valid = (t0 + lane) < k1;
-            float sc = 0.f;
-            const float4* kr = reinterpret_cast<const float4*>(&Kt[lane * DA_KSTR]);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float4 kk = kr[i];
-                sc = fmaf(qreg[i].x, kk.x, sc);
-                sc = fmaf(qreg[i].y, kk.y, sc);
-                sc = fmaf(qreg[i].z, kk.z, sc);
-                sc = fmaf(qreg[i].w, kk.w, sc);
-            }
-            sc = valid ? sc * scale : -INFINITY;
-            const float m_new = fmaxf(m, wave_max(sc));  // finite: the tile has >= 1 valid key
-            const float alpha = __expf(m - m_new);       // m = -inf -> 0
-            const float p = valid ? __expf(sc - m_new) : 0.f;
-            l = l * alpha + wave_sum(p);
-            o.x *= alpha; o.y *= alpha;
-#pragma unroll
-            for (int kk = 0; kk < DA_KT; ++kk) {
-                const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), kk));
-                const float2 vv = reinterpret_cast<const float2*>(&Vt[kk * 128])[lane];
-                o.x = fmaf(pk, vv.x, o.x);
-                o.y = fmaf(pk, vv.y, o.y);
-            }
-            m = m_new;
-        }
-        __syncthreads();
+        *reinterpret_cast<float4*>(&Kt[row * DA_KSTR + c4 * 4]) = kv;
+        *reinterpret_cast<float4*>(&Vt[row * 128 + c4 * 4]) = vv;
     }
+    __syncthreads();
+
+    // 4. scores, softmax statistics and PV for this tile
     if (wid < G) {
-        reinterpret_cast<float2*>(part_o + ((size_t)head * nsplit + sp) * 128)[lane] = o;
+        const bool valid = (k0 + lane) < k1;
+        float sc = 0.f;
+        const float4* qr = reinterpret_cast<const float4*>(q_s[wid]);
+        const float4* kr = reinterpret_cast<const float4*>(&Kt[lane * DA_KSTR]);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float4 qq = qr[i], kk = kr[i];
+            sc = fmaf(qq.x, kk.x, sc);
+            sc = fmaf(qq.y, kk.y, sc);
+            sc = fmaf(qq.z, kk.z, sc);
+            sc = fmaf(qq.w, kk.w, sc);
+        }
+        sc = valid ? sc * scale : -INFINITY;
+        const float m = wave_max(sc);                    // finite: the host never launches an empty tile
+        const float p = valid ? __expf(sc - m) : 0.f;
+        const float l = wave_sum(p);
+        float2 o = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int kk = 0; kk < DA_KT; ++kk) {
+            const float pk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), kk));
+            const float2 vv = reinterpret_cast<const float2*>(&Vt[kk * 128])[lane];
+            o.x = fmaf(pk, vv.x, o.x);
+            o.y = fmaf(pk, vv.y, o.y);
+        }
+        reinterpret_cast<float2*>(part_o + ((size_t)head * max_splits + sp) * 128)[lane] = o;
         if (lane == 0) {
-            part_ml[((size_t)head * nsplit + sp) * 2] = m;
-            part_ml[((size_t)head * nsplit + sp) * 2 + 1] = l;
+            part_ml[((size_t)head * max_splits + sp) * 2] = m;
+            part_ml[((size_t)head * max_splits + sp) * 2 + 1] = l;
         }
     }
-}
 
-// ---- K_C: split-KV combine + O-projection GEMV --------------------------------------
-// K = nq*128 (this rank's heads); chunk c covers dims [8c, 8c+8) of head c>>4.
-template <int NJ, int R>
-__global__ __launch_bounds__(256) void k_dec_oproj(const float* __restrict__ part_o,
-                                                   const float* __restrict__ part_ml, int nsplit,
-                                                   const uint16_t* __restrict__ W, int N, int K,
-                                                   float* __restrict__ out) {
-    __shared__ float red[4 * R];
-    float xr[NJ][8];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = threadIdx.x + j * 256;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xr[j][i] = 0.f;
-        if (c * 8 < K) {
-            const int head = c >> 4, d0 = (c & 15) * 8;
-            float M = -INFINITY;
-            for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[((size_t)head * nsplit + s) * 2]);
-            float den = 0.f;
-            for (int s = 0; s < nsplit; ++s) {
-                const float ms = part_ml[((size_t)head * nsplit + s) * 2];
-                const float ls = part_ml[((size_t)head * nsplit + s) * 2 + 1];
-                const float wgt = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-                den = fmaf(wgt, ls, den);
-                const float4 a = reinterpret_cast<const float4*>(part_o + ((size_t)head * nsplit + s) * 128 + d0)[0];
-                const float4 b = reinterpret_cast<const float4*>(part_o + ((size_t)head * nsplit + s) * 128 + d0)[1];
-                xr[j][0] = fmaf(wgt, a.x, xr[j][0]); xr[j][1] = fmaf(wgt, a.y, xr[j][1]);
-                xr[j][2] = fmaf(wgt, a.z, xr[j][2]); xr[j][3] = fmaf(wgt, a.w, xr[j][3]);
-                xr[j][4] = fmaf(wgt, b.x, xr[j][4]); xr[j][5] = fmaf(wgt, b.y, xr[j][5]);
-                xr[j][6] = fmaf(wgt, b.z, xr[j][6]); xr[j][7] = fmaf(wgt, b.w, xr[j][7]);
-            }
-            const float inv = 1.0f / den;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xr[j][i] *= inv;
-        }
+    // 5. publish; the last arriver of this KV head merges (placement-independent hand-off)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(&cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (ticket == nsplit - 1) ? 1 : 0;
     }
-    const int n0 = blockIdx.x * R;
-    const uint16_t* rows[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, N - 1) * K;
-    float acc[R];
-    gemv_rows<NJ, R>(rows, K, xr, acc);
-    block256_sum<R>(acc, red);
-    if (threadIdx.x < R && n0 + threadIdx.x < N) {
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = acc[r];
-        out[n0 + threadIdx.x] = v;
+    __syncthreads();
+    if (!last_s) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    if (wid < G) {
+        const float* ml = part_ml + (size_t)head * max_splits * 2;
+        const float* po = part_o + (size_t)head * max_splits * 128;
+        float M = -INFINITY;
+        for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, ml[sidx * 2]);
+        float den = 0.f;
+        float2 num = make_float2(0.f, 0.f);
+#pragma unroll 4
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const float wgt = __expf(ml[sidx * 2] - M);
+            den = fmaf(wgt, ml[sidx * 2 + 1], den);
+            const float2 ov = reinterpret_cast<const float2*>(po + (size_t)sidx * 128)[lane];
+            num.x = fmaf(wgt, ov.x, num.x);
+            num.y = fmaf(wgt, ov.y, num.y);
+        }
+        const float inv = 1.0f / den;
+        reinterpret_cast<float2*>(attn_out + (size_t)head * 128)[lane] = make_float2(num.x * inv, num.y * inv);
     }
 }
 
 // ---- K_D: residual add + RMSNorm + router + gate|up GEMV + SiLU*up ------------------
 // Router (modeling_mixtral.py:96-111): logits = x_n @ Wg^T ; softmax fp32 ; top-2 ;
 // renormalise.  Every block recomputes it (8 rows, L2-resident) so the expert ids never
-// leave the device.  route_out = {e0, e1, bits(w0), bits(w1)}.
-#define GU_RP 4  // (gate,up) row pairs per block iteration
-template <int NJ>
+// leave the device.  route_out = {e0, e1, bits(w0), bits(w1)}.  Blocks are persistent: each
+// loops over 2*RP-row groups (RP gate + RP up rows of one expert).  DB=true keeps the NEXT
+// group's weight loads in flight in a second register buffer while the current one is reduced
+// (fewer, fatter waves); DB=false relies on co-resident blocks for the overlap (measured faster
+// at K=4096: 84 vs 91 us — the second buffer costs two waves/SIMD of occupancy).
+template <int NJ, int RP, bool DB>
 __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                     float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                     float eps, const uint16_t* __restrict__ Wg, int E,
                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
                                                     int I, int K, int* __restrict__ route_out,
                                                     float* __restrict__ hbuf) {
-    __shared__ float red[4 * 8];
+    __shared__ float red[4 * 9];
     float xr[NJ][8];
-    load_x<NJ>(x_in, K, xr);
-    if (delta) add_x<NJ>(delta, K, xr);
-    if (blockIdx.x == 0 && x_out) store_x<NJ>(x_out, K, xr);
-    rmsnorm_x<NJ>(norm_w, K, eps, xr, red);
-
-    // router
-    float lg[8];
-    {
-        const uint16_t* rows[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rows[e] = Wg + (size_t)min(e, E - 1) * K;
-        gemv_rows<NJ, 8>(rows, K, xr, lg);
-        block256_sum<8>(lg, red);
-    }
+    float inv;
     int e0 = 0, e1 = 0;
-    float w0, w1;
     {
+        const uint16_t* rrows[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rrows[e] = Wg + (size_t)min(e, E - 1) * K;
+        uint4 wr[8][NJ];
+        gemv_issue<NJ, 8>(rrows, K, wr);
+        load_x<NJ>(x_in, K, xr);
+        if (delta) add_x<NJ>(delta, K, xr);
+        if (blockIdx.x == 0 && x_out) store_x<NJ>(x_out, K, xr);
+        float vals[9];
+        vals[8] = scale_by_norm_weight<NJ>(norm_w, K, xr);
+        float lg[8];
+        gemv_fma<NJ, 8>(wr, xr, lg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vals[e] = lg[e];
+        block256_sum<9>(vals, red);
+        inv = rsqrtf(vals[8] / (float)K + eps);
         float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
+        for (int e = 0; e < 8; ++e) { vals[e] *= inv; if (e < E) mx = fmaxf(mx, vals[e]); }
         float pr[8], sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
+        for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(vals[e] - mx) : 0.f; sum += pr[e]; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) pr[e] = pr[e] / sum;
         float b0 = -1.f, b1 = -1.f;
@@ -375,34 +363,63 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
         for (int e = 0; e < 8; ++e) if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
-        const float t = b0 + b1;
-        w0 = b0 / t; w1 = b1 / t;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        route_out[0] = e0; route_out[1] = e1;
-        route_out[2] = __float_as_int(w0); route_out[3] = __float_as_int(w1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const float t = b0 + b1;
+            route_out[0] = e0; route_out[1] = e1;
+            route_out[2] = __float_as_int(b0 / t); route_out[3] = __float_as_int(b1 / t);
+        }
     }
 
-    const int per_slot = I / GU_RP;
+    const int per_slot = I / RP;
     const int n_iter = 2 * per_slot;
-    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    auto rows_of = [&](int it, const uint16_t* (&rows)[2 * RP]) {
         const int slot = it / per_slot;
-        const int i0 = (it - slot * per_slot) * GU_RP;
+        const int i0 = (it - slot * per_slot) * RP;
         const int e = slot ? e1 : e0;
-        const uint16_t* rows[2 * GU_RP];
 #pragma unroll
-        for (int r = 0; r < GU_RP; ++r) {
+        for (int r = 0; r < RP; ++r) {
             rows[r] = W1 + ((size_t)e * I + i0 + r) * K;
-            rows[GU_RP + r] = W3 + ((size_t)e * I + i0 + r) * K;
+            rows[RP + r] = W3 + ((size_t)e * I + i0 + r) * K;
         }
-        float acc[2 * GU_RP];
-        gemv_rows<NJ, 2 * GU_RP>(rows, K, xr, acc);
-        block256_sum<2 * GU_RP>(acc, red);
-        if (threadIdx.x < GU_RP) {
+    };
+    auto finish = [&](int it, const uint4 (&w)[2 * RP][NJ]) {
+        float acc[2 * RP];
+        gemv_fma<NJ, 2 * RP>(w, xr, acc);
+        block256_sum<2 * RP>(acc, red);
+        if (threadIdx.x < RP) {
             float g = 0.f, u = 0.f;
 #pragma unroll
-            for (int r = 0; r < GU_RP; ++r) if (threadIdx.x == r) { g = acc[r]; u = acc[GU_RP + r]; }
-            hbuf[(size_t)slot * I + i0 + threadIdx.x] = silu_f(g) * u;
+            for (int r = 0; r < RP; ++r) if (threadIdx.x == r) { g = acc[r]; u = acc[RP + r]; }
+            const int slot = it / per_slot;
+            const int i0 = (it - slot * per_slot) * RP;
+            hbuf[(size_t)slot * I + i0 + threadIdx.x] = silu_f(g * inv) * (u * inv);
+        }
+    };
+    int it = blockIdx.x;
+    if (it >= n_iter) return;
+    const uint16_t* rows[2 * RP];
+    if (DB) {
+        uint4 wa[2 * RP][NJ], wb[2 * RP][NJ];
+        rows_of(it, rows);
+        gemv_issue<NJ, 2 * RP>(rows, K, wa);
+        while (true) {
+            int nxt = it + gridDim.x;
+            if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, wb); }
+            finish(it, wa);
+            it = nxt;
+            if (it >= n_iter) break;
+            nxt = it + gridDim.x;
+            if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, wa); }
+            finish(it, wb);
+            it = nxt;
+            if (it >= n_iter) break;
+        }
+    } else {
+        for (; it < n_iter; it += gridDim.x) {
+            uint4 w[2 * RP][NJ];
+            rows_of(it, rows);
+            gemv_issue<NJ, 2 * RP>(rows, K, w);
+            finish(it, w);
         }
     }
 }
@@ -416,24 +433,34 @@ __global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf
     const int e0 = route[0], e1 = route[1];
     const float w0 = __int_as_float(route[2]), w1 = __int_as_float(route[3]);
     const int n0 = blockIdx.x * R;
-    float tot[R];
+    const uint16_t* rows0[R];
+    const uint16_t* rows1[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) tot[r] = 0.f;
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-        const int e = slot ? e1 : e0;
-        const float wt = slot ? w1 : w0;
-        float xr[NJ][8];
-        load_x<NJ>(hbuf + (size_t)slot * I, I, xr);
-        const uint16_t* rows[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) rows[r] = W2 + ((size_t)e * N + min(n0 + r, N - 1)) * I;
-        float acc[R];
-        gemv_rows<NJ, R>(rows, I, xr, acc);
-#pragma unroll
-        for (int r = 0; r < R; ++r) tot[r] = fmaf(wt, acc[r], tot[r]);
+    for (int r = 0; r < R; ++r) {
+        rows0[r] = W2 + ((size_t)e0 * N + min(n0 + r, N - 1)) * I;
+        rows1[r] = W2 + ((size_t)e1 * N + min(n0 + r, N - 1)) * I;
     }
-    // sum over threads is linear, so the routing weights were applied per thread above
+    uint4 wa[R][NJ], wb[R][NJ];
+    gemv_issue<NJ, R>(rows0, I, wa);
+    gemv_issue<NJ, R>(rows1, I, wb);
+    float tot[R];
+    {
+        float xr[NJ][8];
+        load_x<NJ>(hbuf, I, xr);
+        float acc[R];
+        gemv_fma<NJ, R>(wa, xr, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) tot[r] = w0 * acc[r];
+    }
+    {
+        float xr[NJ][8];
+        load_x<NJ>(hbuf + (size_t)I, I, xr);
+        float acc[R];
+        gemv_fma<NJ, R>(wb, xr, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) tot[r] = fmaf(w1, acc[r], tot[r]);
+    }
+    // the thread sum is linear, so the routing weights were applied per thread above
     block256_sum<R>(tot, red);
     if (threadIdx.x < R && n0 + threadIdx.x < N) {
         float v = 0.f;
@@ -452,34 +479,50 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
                                                     float* __restrict__ logits, float* __restrict__ blk_val,
                                                     int* __restrict__ blk_idx, const int* __restrict__ ngen_ptr,
                                                     int hist_rows) {
-    __shared__ float red[4 * LM_R];
+    __shared__ float red[4 * (LM_R + 1)];
+    __shared__ float bv_s[LM_R];
+    __shared__ int bi_s[LM_R];
     // logits history: row = index of the token this step produces (clamped), so the host can
     // read every step's scores after a multi-step launch (HF generate(output_scores=True)).
     if (hist_rows > 1) logits += (size_t)min(*ngen_ptr, hist_rows - 1) * V;
-    __shared__ float bv_s[LM_R];
-    __shared__ int bi_s[LM_R];
+    const int n_iter = (V + LM_R - 1) / LM_R;
+    auto rows_of = [&](int it, const uint16_t* (&rows)[LM_R]) {
+#pragma unroll
+        for (int r = 0; r < LM_R; ++r) rows[r] = W + (size_t)min(it * LM_R + r, V - 1) * K;
+    };
+    int it = blockIdx.x;
+    uint4 wa[LM_R][NJ];
+    const uint16_t* rows[LM_R];
+    if (it < n_iter) { rows_of(it, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
     float xr[NJ][8];
     load_x<NJ>(x_in, K, xr);
     if (delta) add_x<NJ>(delta, K, xr);
-    rmsnorm_x<NJ>(norm_w, K, eps, xr, red);
+    const float ss = scale_by_norm_weight<NJ>(norm_w, K, xr);
+    float inv = 0.f;
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    const int n_iter = (V + LM_R - 1) / LM_R;
-    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const int n0 = it * LM_R;
-        const uint16_t* rows[LM_R];
-#pragma unroll
-        for (int r = 0; r < LM_R; ++r) rows[r] = W + (size_t)min(n0 + r, V - 1) * K;
+    bool first = true;
+    while (it < n_iter) {
         float acc[LM_R];
-        gemv_rows<NJ, LM_R>(rows, K, xr, acc);
-        block256_sum<LM_R>(acc, red);
+        gemv_fma<NJ, LM_R>(wa, xr, acc);
+        const int nxt = it + gridDim.x;
+        if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
+        float vals[LM_R + 1];
+#pragma unroll
+        for (int r = 0; r < LM_R; ++r) vals[r] = acc[r];
+        vals[LM_R] = first ? ss : 0.f;
+        block256_sum<LM_R + 1>(vals, red);
+        if (first) { inv = rsqrtf(vals[LM_R] / (float)K + eps); first = false; }
+        const int n0 = it * LM_R;
         if (threadIdx.x < LM_R && n0 + threadIdx.x < V) {
             float v = 0.f;
 #pragma unroll
-            for (int r = 0; r < LM_R; ++r) if (threadIdx.x == r) v = acc[r];
+            for (int r = 0; r < LM_R; ++r) if (threadIdx.x == r) v = vals[r];
+            v *= inv;
             logits[n0 + threadIdx.x] = v;
             if (v > best) { best = v; besti = n0 + threadIdx.x; }  // ascending n: first max wins
         }
+        it = nxt;
     }
     if (threadIdx.x < LM_R) { bv_s[threadIdx.x] = best; bi_s[threadIdx.x] = besti; }
     __syncthreads();
@@ -533,6 +576,19 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ bl
     }
 }
 
+inline int vh_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 template <typename F>
 inline int pick_nj(int K, F&& f) {
     // chunk slots per thread: K <= NJ * 2048
@@ -548,29 +604,30 @@ inline int pick_nj(int K, F&& f) {
 // ---- launchers (declared in vh_kernels.h) -------------------------------------------
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                 const uint16_t* W, int N, int K, float* out) {
-    constexpr int R = 4;
+    constexpr int R = 8;
     return pick_nj(K, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_qkv<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in, delta,
-                           x_out, norm_w, eps, W, N, K, out);
+        hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, true>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
+                           delta, x_out, norm_w, eps, W, N, K, out);
         return 0;
     });
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
-                 const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int nq, int nkv,
-                 int max_ctx, int nsplit, float scale) {
+                 const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
+                 float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale) {
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
+    const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
+    if (nsplit < 1 || nsplit > max_splits) return -1;
     hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, pos_ptr, rope_cos,
-                       rope_sin, part_o, part_ml, nq, nkv, max_ctx, nsplit, scale);
+                       rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
     return 0;
 }
 
-int vhk_dec_oproj(hipStream_t st, const float* part_o, const float* part_ml, int nsplit, const uint16_t* W, int N,
-                  int K, float* out) {
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out) {
     constexpr int R = 8;
     return pick_nj(K, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_oproj<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, part_o,
-                           part_ml, nsplit, W, N, K, out);
+        hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, false>), dim3((N + R - 1) / R), dim3(256), 0, st,
+                           attn_out, (const float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f, W, N, K, out);
         return 0;
     });
 }
@@ -578,12 +635,26 @@ int vhk_dec_oproj(hipStream_t st, const float* part_o, const float* part_ml, int
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid) {
-    if (E > 8 || E < 2 || I % GU_RP != 0) return -1;
-    const int n_iter = 2 * (I / GU_RP);
-    if (grid <= 0 || grid > n_iter) grid = n_iter < 1024 ? n_iter : 1024;
+    const int variant = vh_tuning()->gateup_variant;   // 0: RP=4 single buffer, 1: RP=4 double buffer, 2: RP=2 single
+    const int rp = variant == 2 ? 2 : 4;
+    if (E > 8 || E < 2 || I % rp != 0) return -1;
+    const int n_iter = 2 * (I / rp);
+    if (grid <= 0) grid = vh_tuning()->gateup_grid;
+    // two persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so
+    // fewer, longer-lived blocks win — measured 79 us at 512 blocks vs 83 at 1024 and 82 at 1280
+    if (grid <= 0) grid = 2 * vh_num_cus();
+    if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_gateup<decltype(nj)::value>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out,
-                           norm_w, eps, Wg, E, W1, W3, I, K, route_out, hbuf);
+        constexpr int NJ = decltype(nj)::value;
+        if (variant == 1)
+            hipLaunchKernelGGL((k_dec_gateup<NJ, 4, true>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
+                               eps, Wg, E, W1, W3, I, K, route_out, hbuf);
+        else if (variant == 2)
+            hipLaunchKernelGGL((k_dec_gateup<NJ, 2, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
+                               eps, Wg, E, W1, W3, I, K, route_out, hbuf);
+        else
+            hipLaunchKernelGGL((k_dec_gateup<NJ, 4, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
+                               eps, Wg, E, W1, W3, I, K, route_out, hbuf);
         return 0;
     });
 }

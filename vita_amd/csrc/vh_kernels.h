@@ -5,14 +5,21 @@
 #include <stdint.h>
 #include <type_traits>
 
+// ---- run-time tuning knobs (set through vh_tune(); defaults are the measured-best variants) ---
+struct VhTuning {
+    int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
+    int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
+    int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
+};
+VhTuning* vh_tuning();
+
 // ---- decode (vh_decode.hip) ---------------------------------------------------------
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                 const uint16_t* W, int N, int K, float* out);
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
-                 const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int nq, int nkv,
-                 int max_ctx, int nsplit, float scale);
-int vhk_dec_oproj(hipStream_t st, const float* part_o, const float* part_ml, int nsplit, const uint16_t* W, int N,
-                  int K, float* out);
+                 const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
+                 float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale);
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid);
