@@ -26,6 +26,17 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass (FETCH_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes; collected by profiles/pmc_pass.sh in its own run — counters cannot be
+    read from inside this process).  TP=1 only: the launch moves 1/N of the bytes at TP=N."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            return int(json.load(f)[kernel]["hbm_read_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, n_layers=2, ctx=64, n_tok=6):
     """The oracle (numpy port of the HF Mixtral arithmetic the reference calls) timed on this box's
     host cores: `n_layers` real-geometry decoder layers + LM head, decode steps at a short context,
@@ -246,7 +257,7 @@ def main():
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                          "bytes_per_launch": gateup_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "samples": n_samp,
-                         "traffic": None},
+                         "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None},
             "build_s": round(t_build, 1),
         }
         if args.layers:

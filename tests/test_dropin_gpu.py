@@ -1,0 +1,137 @@
+"""Drop-in check of the `vita.model` boundary (SURVEY §8(b) flavour 1): the call sequence of the
+reference's video_audio_demo.py:155-283, written against the reference's OWN import names
+(`from vita.model.builder import load_pretrained_model`, ... resolved by compat/), on a tiny
+checkpoint directory in the reference's format (config.json + tokenizer + safetensors shards with
+HF-4.41 names).  Token ids must equal those of the same weights loaded through the synthetic path
+(whose parity with the reference's modules is pinned by test_model_gpu.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from tests import tiny_ckpt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("vita_tiny_ckpt"))
+    sd = tiny_ckpt.write(d, seed=21)
+    wav = os.path.join(d, "q.wav")
+    tiny_ckpt.write_wav(wav)
+    img = os.path.join(d, "img.png")
+    rng = np.random.default_rng(9)
+    Image.fromarray(rng.integers(0, 255, size=(90, 150, 3), dtype=np.uint8)).save(img)
+    return d, sd, wav, img
+
+
+def _demo(model_path, image_path, audio_path, question, max_new_tokens=12):
+    """video_audio_demo.py:155-283 with its own names; only argparse / printing removed."""
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    try:
+        from vita.constants import DEFAULT_AUDIO_TOKEN, DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX
+        from vita.conversation import SeparatorStyle, conv_templates
+        from vita.model.builder import load_pretrained_model
+        from vita.util.data_utils_video_audio_neg_patch import dynamic_preprocess
+        from vita.util.mm_utils import (KeywordsStoppingCriteria, get_model_name_from_path,
+                                        tokenizer_image_audio_token, tokenizer_image_token)
+        from vita.util.utils import disable_torch_init
+    finally:
+        sys.path.pop(0)
+    disable_torch_init()
+    model_name = get_model_name_from_path(model_path)
+    tokenizer, model, image_processor, context_len = load_pretrained_model(model_path, None, model_name, "mixtral-8x7b")
+    model.resize_token_embeddings(len(tokenizer))
+    vision_tower = model.get_vision_tower()
+    if not vision_tower.is_loaded:
+        vision_tower.load_model()
+    image_processor = vision_tower.image_processor
+    audio_encoder = model.get_audio_encoder()
+    audio_encoder.to(dtype=torch.float16)
+    audio_processor = audio_encoder.audio_processor
+    model.eval()
+    qs = question
+    if audio_path is not None:
+        audio, audio_for_llm_lens = audio_processor.process(os.path.join(audio_path))
+        audio_length = audio.shape[0]
+    else:
+        audio = torch.zeros(400, 80)
+        audio_length = audio.shape[0]
+    audio = torch.unsqueeze(audio, dim=0)
+    audio_length = torch.unsqueeze(torch.tensor(audio_length), dim=0)
+    audios = {"audios": audio.half().cuda(), "lengths": audio_length.half().cuda()}
+    if image_path is not None:
+        image = Image.open(image_path).convert("RGB")
+        image, p_num = dynamic_preprocess(image, min_num=1, max_num=12, image_size=image_processor.crop_size["height"],
+                                          use_thumbnail=True)
+        assert len(p_num) == 1
+        image_tensor = model.process_images(image, model.config).to(dtype=model.dtype, device="cuda")
+        qs = DEFAULT_IMAGE_TOKEN * p_num[0] + "\n" + qs + (DEFAULT_AUDIO_TOKEN if audio_path else "")
+        modality = "image"
+    else:
+        size = image_processor.crop_size["height"]
+        image_tensor = torch.zeros((1, 3, size, size)).to(dtype=model.dtype, device="cuda")
+        if audio_path:
+            qs = qs + DEFAULT_AUDIO_TOKEN
+        modality = "lang"
+    conv = conv_templates["mixtral_two"].copy()
+    conv.append_message(conv.roles[0], qs)
+    conv.append_message(conv.roles[1], None)
+    prompt = conv.get_prompt(modality)
+    if audio_path:
+        input_ids = tokenizer_image_audio_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()
+    else:
+        input_ids = tokenizer_image_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()
+    stop_str = conv.sep if conv.sep_style != SeparatorStyle.TWO else conv.sep2
+    stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
+    with torch.inference_mode():
+        output_ids = model.generate(input_ids, images=image_tensor, audios=audios, do_sample=False, temperature=0.01,
+                                    top_p=None, num_beams=1, output_scores=True, return_dict_in_generate=True,
+                                    max_new_tokens=max_new_tokens, use_cache=True,
+                                    stopping_criteria=[stopping_criteria])
+    seqs = output_ids.sequences
+    n_in = input_ids.shape[1]
+    assert (input_ids != seqs[:, :n_in]).sum().item() == 0            # the demo's own self-check (:272-276)
+    text = tokenizer.batch_decode(seqs[:, n_in:], skip_special_tokens=False)[0].strip()
+    return model, input_ids, image_tensor, audios, seqs[0, n_in:].tolist(), output_ids.scores, text
+
+
+def _expected(sd, cfg, input_ids, image_tensor, audios, n):
+    from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
+    m = VITAMixtralForCausalLM(cfg, sd, device="cuda:0", max_new_tokens=32, max_prefill=1024)
+    m.get_vision_tower().load_model()
+    out = m.generate(input_ids, images=image_tensor, audios=audios, do_sample=False, num_beams=1,
+                     return_dict_in_generate=True, output_scores=True, max_new_tokens=n, eos_token_id=-1)
+    return out.sequences[0, input_ids.shape[1]:].tolist(), out.scores
+
+
+def test_demo_sequence_image_audio(ckpt, dev):
+    d, sd, wav, img = ckpt
+    from vita_amd.config import VitaConfig
+    model, ids, pix, audios, got, scores, text = _demo(d, img, wav, "describe this picture")
+    assert (ids == -200).sum().item() == pix.shape[0] >= 1 and (ids == -500).sum().item() == 1
+    exp, exp_scores = _expected(sd, VitaConfig.tiny(), ids, pix, audios, 12)
+    n = len(got)
+    assert n >= 1 and got == exp[:n], (got, exp)
+    assert n == 12 or got[-1] == 2                                      # stopped on </s> or ran to the cap
+    err = max(float((scores[i] - exp_scores[i]).abs().max()) for i in range(n))
+    assert err < 1e-5, err                                             # same kernels, same weights
+    assert isinstance(text, str)
+
+
+def test_demo_sequence_text_only(ckpt, dev):
+    """text-only prompt: the demo still feeds a zero image and a 400-frame zero clip (video_audio_demo.py:188-195,227-231)."""
+    d, sd, _, _ = ckpt
+    model, ids, pix, audios, got, _, _ = _demo(d, None, None, "hello what is your name", max_new_tokens=6)
+    assert (ids < 0).sum().item() == 0 and 1 <= len(got) <= 6
+
+
+def test_load_pretrained_rejects_unknown_type(ckpt):
+    from vita_amd.model import load_pretrained_model
+    with pytest.raises(ValueError):
+        load_pretrained_model(ckpt[0], None, "x", "qwen2")             # builder.py:25-26

@@ -44,12 +44,24 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
     const int wm = wid & 1, wn = wid >> 1;
     constexpr int NT = GLU ? 64 : 128;  // output columns per block
 
-    // ---- which (group, m-tile) is this block? -------------------------------------
+    // ---- which (n-tile, group, m-tile) is this block? -------------------------------
+    // 1-D grid.  Hardware block b runs on XCD b % 8 (own L2): remap b -> logical l so that each XCD
+    // owns a CONTIGUOUS range of l (bijective for any grid size), and let the m-tiles of one weight
+    // tile be adjacent in l.  All m-tiles that stream the same W[n-tile] rows then run back to back
+    // on one XCD: W leaves HBM once and is re-read from that XCD's L2.
+    const int mt = p.mt_slots;
+    int l;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, idx = b >> 3, q = nwg >> 3, r = nwg & 7;
+        l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n_tile = l / mt, slot = l - n_tile * mt;
     int m_begin, m_end;
     const uint16_t* Wb = p.W;
     const uint16_t* Wu = p.W_up;
     if (p.group_off) {
-        int tile = blockIdx.y, e = 0;
+        int tile = slot, e = 0;
         for (; e < p.ngroups; ++e) {
             const int cnt = p.group_off[e + 1] - p.group_off[e];
             const int nt = (cnt + GM_BM - 1) / GM_BM;
@@ -62,11 +74,11 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
         Wb += (size_t)e * p.w_group_stride;
         if (GLU) Wu += (size_t)e * p.w_group_stride;
     } else {
-        m_begin = blockIdx.y * GM_BM;
+        m_begin = slot * GM_BM;
         m_end = p.M;
         if (m_begin >= m_end) return;
     }
-    const int n_begin = blockIdx.x * NT;
+    const int n_begin = n_tile * NT;
 
     // ---- staging assignments -------------------------------------------------------
     const int arow = tid >> 2, achunk0 = (tid & 3) * 2;  // 16 floats = 2 chunks
@@ -206,11 +218,12 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
         a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0)
         return -1;
     if (a.M == 0) return 0;
-    const int mt = (a.M + GM_BM - 1) / GM_BM + (a.group_off ? a.ngroups : 0);
+    VhGemmArgs g = a;
+    g.mt_slots = (a.M + GM_BM - 1) / GM_BM + (a.group_off ? a.ngroups : 0);  // grouped: upper bound on m-tiles
     if (a.W_up) {
-        hipLaunchKernelGGL(k_gemm<true>, dim3((a.N + 63) / 64, mt), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_gemm<true>, dim3(((a.N + 63) / 64) * g.mt_slots), dim3(256), 0, st, g);
     } else {
-        hipLaunchKernelGGL(k_gemm<false>, dim3((a.N + GM_BN - 1) / GM_BN, mt), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_gemm<false>, dim3(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots), dim3(256), 0, st, g);
     }
     return 0;
 }

@@ -43,6 +43,7 @@ struct VhGemmArgs {
     float* C; long ldc; const int* c_rowidx;  // nullable output row map
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
+    int mt_slots;                             // set by the launcher: m-tile slots per n-tile
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
 
