@@ -36,7 +36,7 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
-/* Kernel-variant knobs for experiments (keys: "gateup_variant", "gateup_grid"); the defaults are
+/* Kernel-variant knobs for experiments (keys: "gateup_variant", "gateup_grid", "fuse_attn_oproj", "prefill_moe_gemm", "gemm_order", ...); the defaults are
  * the measured-best variants, results are identical across variants. */
 int vh_tune(const char* key, int value);
 
@@ -63,6 +63,21 @@ typedef struct {
     int M, N, K, act;
 } vh_gemm_args;
 int vh_gemm(const vh_gemm_args* args, void* stream);
+
+/* vh_gemm_ps: the same contraction for SKINNY M (Mixtral prefill, MoE grouped GEMMs: HF MixtralExperts,
+ * modeling_mixtral.py:57-93) on activations already split into bf16 hi/lo planes (x = hi + lo to 2^-17;
+ * vh_split_planes makes them, vh_gemm_ps can also emit them).  One m-tile covers up to 192 rows of a group
+ * so each weight byte is read once; K % 64 == 0, lda % 8 == 0.  `wide` != 0 selects 256-column tiles. */
+typedef struct {
+    const uint16_t* A_hi; const uint16_t* A_lo; long lda; const int* a_rowidx;
+    const uint16_t* W; const uint16_t* W_up; long ldw; long w_group_stride;
+    const int* group_off; int ngroups;
+    float* C; long ldc; uint16_t* C_hi; uint16_t* C_lo; long ldc_split; const int* c_rowidx;
+    const float* bias; const float* scale; const float* resid; long ldr;
+    int M, N, K, act, wide;
+} vh_gemm_ps_args;
+int vh_gemm_ps(const vh_gemm_ps_args* args, void* stream);
+int vh_split_planes(const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows, int cols, void* stream);
 
 /* vh_attention: softmax(scale * Q K^T [+ (Q+v) P^T]) V with causal / pad / chunk masks.
  * Replaces InternAttention._naive_attn (modeling_intern_vit.py:158-177), Whale
@@ -154,7 +169,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, fl
 int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
 /* Device pointers into the engine state (for the host loop and the tests). */
 const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */
-const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[2]: {pos, n_generated}    */
+const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[4]: {pos, n_generated, attn hand-off counter, device error flag (0 = ok)} */
 const float* vh_mixtral_logits(const vh_mixtral_t* m);   /* fp32[max(1,logit_rows)][vocab]; row i = scores that produced token i */
 int vh_mixtral_reset(vh_mixtral_t* m, void* stream);     /* n_generated = 0, pos = 0      */
 /* Live HIP-event timing of the dominant decode kernel (gate|up expert GEMV): sample one launch

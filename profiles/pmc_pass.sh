@@ -4,9 +4,9 @@
 # Output: gpurun_out/pmc_<counter>.txt = per-kernel mean counter value per launch.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for ctr in FETCH_SIZE WRITE_SIZE; do
+for ctr in ${PMC_CTRS:-FETCH_SIZE WRITE_SIZE}; do
   rm -rf /tmp/pmc_$ctr
-  timeout 400 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$ctr -o r -- python $R/bench.py --layers 4 --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_$ctr.log 2>&1
+  timeout ${PP_TIMEOUT:-120} rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$ctr -o r -- python $R/bench.py --layers ${PP_LAYERS:-4} --steps 8 --warmup 2 --no-cpu-baseline $PMC_EXTRA > $R/gpurun_out/pmc_$ctr.log 2>&1
   db=$(find /tmp/pmc_$ctr -name '*.db' | head -1)
   cp $db $R/gpurun_out/pmc_$ctr.db
   python - "$db" $ctr > $R/gpurun_out/pmc_$ctr.txt <<'PY'

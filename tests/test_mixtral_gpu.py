@@ -192,3 +192,33 @@ def test_rccl_binding_single_rank(dev):
     finally:
         _lib.tune("force_allreduce", 0)
         eng.close()
+
+
+@pytest.mark.parametrize("knob,value", [("fuse_attn_oproj", 1), ("prefill_moe_gemm", 0), ("gemm_order", 1)])
+def test_alternative_paths(dev, knob, value):
+    """the non-default code paths stay correct: two-kernel attention / O-projection (also the fallback
+    for contexts too long to co-schedule), the pre-split skinny MoE GEMM, the XCD-contiguous GEMM order."""
+    from vita_amd import _lib
+    cfg = VitaConfig.tiny()
+    cfg.text = TextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
+                          intermediate_size=1024, num_local_experts=8, vocab_size=2000)
+    default = {"fuse_attn_oproj": 0, "prefill_moe_gemm": 1, "gemm_order": 0}[knob]
+    _lib.tune(knob, value)
+    try:
+        _run(dev, cfg, S=200, n_new=8, seed=9)
+    finally:
+        _lib.tune(knob, default)
+
+
+def test_fused_attention_falls_back_on_long_context(dev):
+    """ctx large enough that attention + O-proj blocks cannot all be resident: the engine must take the
+    two-kernel path on its own, and switch mid-generation without changing results."""
+    from vita_amd import _lib
+    cfg = VitaConfig.tiny()
+    _lib.tune("fuse_attn_oproj", 1)
+    _lib.tune("fuse_max_blocks", 20)       # pretend the device holds 20 blocks: ctx 128+ no longer fits
+    try:
+        _run(dev, cfg, S=120, n_new=14, seed=13)   # crosses ctx 128 (2 -> 3 KV splits) during decode
+    finally:
+        _lib.tune("fuse_max_blocks", 0)
+        _lib.tune("fuse_attn_oproj", 0)

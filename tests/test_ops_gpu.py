@@ -152,6 +152,72 @@ def test_gemm_grouped_glu_and_scatter(dev):
     assert_close("grouped down + scatter", to_np(y), yref, atol=2e-4)
 
 
+def _planes_to_f32(hi, lo):
+    return hi.float() + lo.float()
+
+
+def test_split_planes(dev):
+    from vita_amd import ops
+    rng = np.random.default_rng(17)
+    x = (rng.standard_normal((37, 256), dtype=np.float32) * np.exp(rng.standard_normal((37, 256)) * 3)).astype(np.float32)
+    hi, lo = ops.split_planes(_dev(x, dev))
+    rec = to_np(_planes_to_f32(hi, lo))
+    assert np.all(np.abs(rec - x) <= np.abs(x) * 2.0 ** -16)          # two bf16 terms carry >= 16 mantissa bits
+    assert np.array_equal(to_np(hi.float()), round_bf16(x))
+
+
+@pytest.mark.parametrize("M,N,K,wide", [(1, 64, 64, False), (16, 128, 64, False), (138, 300, 192, False),
+                                        (193, 257, 128, True), (400, 512, 4096, True), (552, 4096, 1024, False)])
+def test_gemm_ps_plain(dev, M, N, K, wide):
+    """pre-split skinny GEMM vs fp64 reference on the same bf16 weights: ragged M (row tiles + clamped
+    rows), N tails, several 192-row m-tiles, K long enough to wrap the LDS ring many times."""
+    from vita_amd import ops
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = _w(rng, N, K)
+    b = _w(rng, N)
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    hi, lo = ops.split_planes(_dev(x, dev))
+    y = ops.gemm_ps(hi, lo, _dev(w, dev, torch.bfloat16), bias=_dev(b, dev), act="gelu", resid=_dev(r, dev), wide=wide)
+    ref = gelu(x.astype(np.float64) @ w.T.astype(np.float64) + b) + r
+    assert_close(f"gemm_ps {M}x{N}x{K}", to_np(y), ref, atol=3e-4 if K > 1024 else 1e-4)
+
+
+def test_gemm_ps_grouped_glu_and_scatter(dev):
+    """the MoE pair on the pre-split kernel: gather by sorted token, grouped GLU emitting split planes,
+    grouped down GEMM scattered to (token, slot) rows; one expert empty, one above 192 rows."""
+    from vita_amd import ops
+    rng = np.random.default_rng(8)
+    S, H, I, E = 330, 128, 256, 5
+    x = rng.standard_normal((S, H), dtype=np.float32)
+    w1, w3, w2 = _w(rng, E, I, H), _w(rng, E, I, H), _w(rng, E, H, I)
+    ids = np.stack([rng.permutation(4)[:2] for _ in range(S)]).astype(np.int32)   # expert 4 never chosen
+    ids[:250] = [[1, 3]] * 250                                                      # expert 1 and 3 exceed one m-tile
+    flat = ids.reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    goff = np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=E))]).astype(np.int32)
+    stok, sslot = (order // 2).astype(np.int32), order.astype(np.int32)
+    xh, xl = ops.split_planes(_dev(x, dev))
+    hh, hl = ops.gemm_ps(xh, xl, _dev(w1, dev, torch.bfloat16), w_up=_dev(w3, dev, torch.bfloat16),
+                         a_rowidx=_dev(stok, dev, torch.int32), group_off=_dev(goff, dev, torch.int32), ngroups=E,
+                         w_group_stride=I * H, m=2 * S, out_split=True)
+    href = np.zeros((2 * S, I))
+    for p, slot in enumerate(order):
+        e, t = flat[slot], slot // 2
+        g, u = x[t].astype(np.float64) @ w1[e].T, x[t].astype(np.float64) @ w3[e].T
+        href[p] = g / (1 + np.exp(-g)) * u
+    h = _planes_to_f32(hh, hl)
+    assert_close("ps grouped GLU (planes)", to_np(h), href, atol=2e-4)
+    y = torch.zeros((2 * S, H), dtype=torch.float32, device=dev)
+    ops.gemm_ps(hh, hl, _dev(w2, dev, torch.bfloat16), group_off=_dev(goff, dev, torch.int32), ngroups=E,
+                w_group_stride=H * I, c_rowidx=_dev(sslot, dev, torch.int32), out=y)
+    yref = np.zeros((2 * S, H))
+    hn = to_np(h).astype(np.float64)
+    for p, slot in enumerate(order):
+        yref[slot] = hn[p] @ w2[flat[slot]].T
+    assert_close("ps grouped down + scatter", to_np(y), yref, atol=2e-4)
+
+
 # ---------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, scale, mask=None, p=None, bu=None, bv=None):
     """q [H,Sq,d], k/v [Hkv,Sk,d]; mask [Sq,Sk] True = visible."""

@@ -26,6 +26,17 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmPsArgs(C.Structure):
+    _fields_ = [
+        ("A_hi", c_void_p), ("A_lo", c_void_p), ("lda", c_long), ("a_rowidx", c_void_p),
+        ("W", c_void_p), ("W_up", c_void_p), ("ldw", c_long), ("w_group_stride", c_long),
+        ("group_off", c_void_p), ("ngroups", c_int),
+        ("C", c_void_p), ("ldc", c_long), ("C_hi", c_void_p), ("C_lo", c_void_p), ("ldc_split", c_long),
+        ("c_rowidx", c_void_p), ("bias", c_void_p), ("scale", c_void_p), ("resid", c_void_p), ("ldr", c_long),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("act", c_int), ("wide", c_int),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", c_void_p), ("ldq", c_long), ("hsq", c_long),
@@ -65,6 +76,8 @@ SIGNATURES = {
     "vh_last_error": (C.c_char_p, []),
     "vh_tune": (c_int, [C.c_char_p, c_int]),
     "vh_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "vh_gemm_ps": (c_int, [C.POINTER(GemmPsArgs), c_void_p]),
+    "vh_split_planes": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "vh_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "vh_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                              c_float, c_void_p]),

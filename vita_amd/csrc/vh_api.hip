@@ -43,6 +43,11 @@ int vh_tune(const char* key, int value) {
     if (!key) return fail(VH_E_ARG, "vh_tune: null key");
     if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
+    if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
+    if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
+    if (!strcmp(key, "gemm_order")) { g_tuning.gemm_order = value; return VH_OK; }
+    if (!strcmp(key, "ps_ablate")) { g_tuning.ps_ablate = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
@@ -60,6 +65,22 @@ int vh_gemm(const vh_gemm_args* a, void* stream) {
     g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act;
     if ((a->lda % 4) != 0 || (a->ldw % 8) != 0) return fail(VH_E_SHAPE, "vh_gemm: lda%%4 / ldw%%8 alignment");
     return check_launch("vh_gemm", vhk_gemm(S(stream), g));
+}
+
+int vh_gemm_ps(const vh_gemm_ps_args* a, void* stream) {
+    if (!a || !a->A_hi || !a->A_lo || !a->W) return fail(VH_E_ARG, "vh_gemm_ps: null pointer");
+    VhGemmPsArgs g;
+    g.A_hi = a->A_hi; g.A_lo = a->A_lo; g.lda = a->lda; g.a_rowidx = a->a_rowidx;
+    g.W = a->W; g.W_up = a->W_up; g.ldw = a->ldw; g.w_group_stride = a->w_group_stride;
+    g.group_off = a->group_off; g.ngroups = a->ngroups;
+    g.C = a->C; g.ldc = a->ldc; g.C_hi = a->C_hi; g.C_lo = a->C_lo; g.ldc_split = a->ldc_split;
+    g.c_rowidx = a->c_rowidx; g.bias = a->bias; g.scale = a->scale; g.resid = a->resid; g.ldr = a->ldr;
+    g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act; g.wide = a->wide; g.ablate = 0;
+    return check_launch("vh_gemm_ps", vhk_gemm_ps(S(stream), g));
+}
+int vh_split_planes(const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows, int cols, void* stream) {
+    if (!x || !hi || !lo) return fail(VH_E_ARG, "vh_split_planes: null pointer");
+    return check_launch("vh_split_planes", vhk_split_planes(S(stream), x, ldx, hi, lo, ldo, rows, cols));
 }
 
 int vh_attention(const vh_attn_args* a, void* stream) {
@@ -165,12 +186,14 @@ struct vh_mixtral {
     const float* rope_cos; const float* rope_sin;
     int nq, nkv, hd, H, I, E, V, nqkv, max_splits, lm_grid;
     int host_pos = 0;  // host mirror of counters[0] (sizes the split-KV grid without a device read)
+    int attn_epoch = 0;  // fused attention+O-proj launches since the last reset (counters[2] grows by nkv per launch)
     // state
     float *kcache, *vcache;  // [layer][nkv][max_ctx][hd]
     float *xa, *xb, *delta_attn, *delta_moe, *qkv, *part_o, *part_ml, *attn_out, *hbuf, *logits, *blk_val;
     int *blk_idx, *route, *counters, *out_tokens, *attn_cnt;
     // prefill scratch
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
+    uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
     int *pids, *pgoff, *pstok, *psslot;
     // tensor parallel
     vh_allreduce_fn ar_fn; void* ar_user; void* rccl_comm;
@@ -196,12 +219,14 @@ struct vh_mixtral {
         blk_val = cv.take<float>(lm_grid);
         blk_idx = cv.take<int>(lm_grid);
         route = cv.take<int>(4);
-        counters = cv.take<int>(2);
+        counters = cv.take<int>(4);  // {pos, n_generated, attn_done (monotonic), device error flag}
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
         px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
         pqkv = cv.take<float>(Sm * nqkv);
         pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
         ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(2 * Sm * H);
+        pxn_hi = cv.take<uint16_t>(Sm * H); pxn_lo = cv.take<uint16_t>(Sm * H);
+        ph_hi = cv.take<uint16_t>(2 * Sm * I); ph_lo = cv.take<uint16_t>(2 * Sm * I);
         ptmp = cv.take<float>(Sm * H);
         pwts = cv.take<float>(2 * Sm);
         pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
@@ -345,8 +370,9 @@ const float* vh_mixtral_logits(const vh_mixtral_t* m) { return m ? m->logits : n
 
 int vh_mixtral_reset(vh_mixtral_t* m, void* stream) {
     if (!m) return fail(VH_E_ARG, "null engine");
-    if (hipMemsetAsync(m->counters, 0, 2 * sizeof(int), S(stream)) != hipSuccess)
+    if (hipMemsetAsync(m->counters, 0, 4 * sizeof(int), S(stream)) != hipSuccess)
         return fail(VH_E_HIP, "reset memset failed");
+    m->host_pos = 0; m->attn_epoch = 0;
     return VH_OK;
 }
 
@@ -366,7 +392,8 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     const float scale = 1.0f / sqrtf((float)hd);
     if (hipMemcpyAsync(m->px, embeds, (size_t)Sn * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(VH_E_HIP, "prefill: embed copy failed");
-    if (hipMemsetAsync(m->counters + 1, 0, sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
+    if (hipMemsetAsync(m->counters + 1, 0, 3 * sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
+    m->attn_epoch = 0;
 
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
@@ -406,21 +433,38 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
         VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.ffn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
         VH_TRY(vhk_moe_route(st, m->pxn, w.wrouter, Sn, H, E, m->pids, m->pwts), "route");
         VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
-        {
-            VhGemmArgs g{};
-            g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.a_rowidx = m->pstok; g.nseg = 1; g.seglen = H;
+        if (vh_tuning()->prefill_moe_gemm == 0) {
+            // pre-split path: activations split once, one 192-row m-tile per expert, weights read once
+            VH_TRY(vhk_split_planes(st, m->pxn, H, m->pxn_hi, m->pxn_lo, H, Sn, H), "split planes");
+            VhGemmPsArgs g{};
+            g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; g.lda = H; g.a_rowidx = m->pstok;
             g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
             g.group_off = m->pgoff; g.ngroups = E;
-            g.C = m->ph; g.ldc = I; g.M = 2 * Sn; g.N = I; g.K = H;
-            VH_TRY(vhk_gemm(st, g), "gate/up gemm");
-        }
-        {
-            VhGemmArgs g{};
-            g.A = m->ph; g.lda = I; g.a_rows = 2 * Sn; g.nseg = 1; g.seglen = I;
-            g.W = w.w2; g.ldw = I; g.w_group_stride = (long)H * I;
-            g.group_off = m->pgoff; g.ngroups = E;
-            g.C = m->py; g.ldc = H; g.c_rowidx = m->psslot; g.M = 2 * Sn; g.N = H; g.K = I;
-            VH_TRY(vhk_gemm(st, g), "down gemm");
+            g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * Sn; g.N = I; g.K = H;
+            VH_TRY(vhk_gemm_ps(st, g), "gate/up gemm");
+            VhGemmPsArgs d{};
+            d.A_hi = m->ph_hi; d.A_lo = m->ph_lo; d.lda = I;
+            d.W = w.w2; d.ldw = I; d.w_group_stride = (long)H * I;
+            d.group_off = m->pgoff; d.ngroups = E;
+            d.C = m->py; d.ldc = H; d.c_rowidx = m->psslot; d.M = 2 * Sn; d.N = H; d.K = I;
+            VH_TRY(vhk_gemm_ps(st, d), "down gemm");
+        } else {
+            {
+                VhGemmArgs g{};
+                g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.a_rowidx = m->pstok; g.nseg = 1; g.seglen = H;
+                g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
+                g.group_off = m->pgoff; g.ngroups = E;
+                g.C = m->ph; g.ldc = I; g.M = 2 * Sn; g.N = I; g.K = H;
+                VH_TRY(vhk_gemm(st, g), "gate/up gemm");
+            }
+            {
+                VhGemmArgs g{};
+                g.A = m->ph; g.lda = I; g.a_rows = 2 * Sn; g.nseg = 1; g.seglen = I;
+                g.W = w.w2; g.ldw = I; g.w_group_stride = (long)H * I;
+                g.group_off = m->pgoff; g.ngroups = E;
+                g.C = m->py; g.ldc = H; g.c_rowidx = m->psslot; g.M = 2 * Sn; g.N = H; g.K = I;
+                VH_TRY(vhk_gemm(st, g), "down gemm");
+            }
         }
         if (tp) {
             if (hipMemsetAsync(m->ptmp, 0, (size_t)Sn * H * sizeof(float), st) != hipSuccess)
@@ -439,7 +483,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     // vita_mixtral.py:171-172 + HF greedy argmax(logits[:, -1]))
     VH_TRY(vhk_dec_lmhead(st, m->px + (size_t)(Sn - 1) * H, nullptr, m->final_norm, m->c.rms_eps, m->lm_head, m->V, H,
                           m->logits, m->blk_val, m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "lm_head");
-    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters, m->counters + 1,
+    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->V, m->xa, m->counters, m->counters + 1,
                           m->out_tokens, m->c.max_new, /*mode=*/0, /*set_pos=*/pos0 + Sn), "select");
     m->host_pos = pos0 + Sn;
     if (logits_out)
@@ -463,10 +507,21 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
             float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
             VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                                m->qkv), "dec qkv");
-            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
-                                m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale),
-                   "dec attn");
-            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
+            int fused = 1;
+            if (vh_tuning()->fuse_attn_oproj) {
+                fused = vhk_dec_attn_oproj(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o,
+                                           m->part_ml, m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits,
+                                           m->host_pos + 1, scale, m->counters + 2, (m->attn_epoch + 1) * nkv,
+                                           m->counters + 3, w.wo, H, nq * hd, m->delta_attn);
+                if (fused < 0) return fail(VH_E_SHAPE, "dec attn+oproj: launch rejected");
+                if (fused == 0) m->attn_epoch += 1;
+            }
+            if (fused != 0) {  // long contexts (grid not co-resident) or fusion disabled: two kernels
+                VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                                    m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
+                                    scale), "dec attn");
+                VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
+            }
             if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
             const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
             if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
@@ -478,7 +533,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
         }
         VH_TRY(vhk_dec_lmhead(st, m->xa, m->delta_moe, m->final_norm, eps, m->lm_head, m->V, H, m->logits, m->blk_val,
                               m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "dec lm_head");
-        VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->xa, m->counters,
+        VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->V, m->xa, m->counters,
                               m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
         m->host_pos += 1;
     }

@@ -169,13 +169,16 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
 // re-merging the partials in each of its blocks.  head_dim is 128 (config.json:16-44).
 #define DA_KT 64
 #define DA_KSTR 132
-__global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                                  float* __restrict__ vcache, const int* __restrict__ pos_ptr,
-                                                  const float* __restrict__ rope_cos,
-                                                  const float* __restrict__ rope_sin, float* __restrict__ part_o,
-                                                  float* __restrict__ part_ml, int* __restrict__ cnt,
-                                                  float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
-                                                  int max_splits, float scale) {
+// Body of one attention block (h, sp of nsplit).  Returns true in the block that merged the partials
+// of its KV head and wrote attn_out rows [h*G*128, (h+1)*G*128) (block-uniform).
+__device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const int nsplit,
+                                               const float* __restrict__ qkv, float* __restrict__ kcache,
+                                               float* __restrict__ vcache, const int* __restrict__ pos_ptr,
+                                               const float* __restrict__ rope_cos,
+                                               const float* __restrict__ rope_sin, float* __restrict__ part_o,
+                                               float* __restrict__ part_ml, int* __restrict__ cnt,
+                                               float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
+                                               int max_splits, float scale) {
     __shared__ __attribute__((aligned(16))) float q_s[4][128];
     __shared__ __attribute__((aligned(16))) float kn_s[128];
     __shared__ __attribute__((aligned(16))) float vn_s[128];
@@ -183,7 +186,6 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
     __shared__ __attribute__((aligned(16))) float Vt[DA_KT * 128];
     __shared__ int last_s;
 
-    const int h = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = nq / nkv;
     const int pos = *pos_ptr;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
         last_s = (ticket == nsplit - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (!last_s) return;
+    if (!last_s) return false;
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -311,6 +313,91 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
         }
         const float inv = 1.0f / den;
         reinterpret_cast<float2*>(attn_out + (size_t)head * 128)[lane] = make_float2(num.x * inv, num.y * inv);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
+                                                  float* __restrict__ vcache, const int* __restrict__ pos_ptr,
+                                                  const float* __restrict__ rope_cos,
+                                                  const float* __restrict__ rope_sin, float* __restrict__ part_o,
+                                                  float* __restrict__ part_ml, int* __restrict__ cnt,
+                                                  float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
+                                                  int max_splits, float scale) {
+    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos_ptr, rope_cos, rope_sin, part_o,
+                   part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
+}
+
+// ---- K_B + K_C in one launch: attention blocks and O-projection blocks run side by side ------
+// The O-projection is a pure weight stream that depends on the attention output only through its
+// 16 KB activation vector.  Its blocks therefore put their weight rows in flight FIRST (R rows x K
+// bf16 per block, the whole 33.5 MB matrix across the grid), then wait for the attention blocks of
+// the same launch to publish attn_out, then multiply: the HBM stream hides behind the latency-bound
+// attention instead of following it across a kernel boundary.
+// Hand-off (guide §6 G16, counter form): the merging block of each KV head stores its attn_out rows ->
+// vmcnt(0) -> barrier -> lane 0 agent-scope release -> monotonic done counter += 1.  O-proj blocks:
+// lane 0 polls the counter with relaxed agent-scope loads (s_sleep between polls, bounded) until it
+// reaches epoch*nkv, one agent-scope acquire, barrier, plain loads.  The counter only grows (the host
+// passes the launch's epoch), so nothing has to be reset between launches.
+// No-deadlock argument: only O-proj blocks wait, attention blocks never do; the launcher sizes the
+// grid so that ALL blocks of the launch are co-resident (<= 2 per CU by LDS), hence every attention
+// block is scheduled no matter in which order the dispatcher places blocks.
+template <int NJ, int R>
+__global__ __launch_bounds__(256) void k_dec_attn_oproj(const float* __restrict__ qkv, float* __restrict__ kcache,
+                                                        float* __restrict__ vcache, const int* __restrict__ pos_ptr,
+                                                        const float* __restrict__ rope_cos,
+                                                        const float* __restrict__ rope_sin,
+                                                        float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                        int* __restrict__ cnt, float* __restrict__ attn_out, int nq,
+                                                        int nkv, int max_ctx, int max_splits, float scale,
+                                                        int nsplit, int* __restrict__ done_ctr, int done_target,
+                                                        int* __restrict__ err_flag, const uint16_t* __restrict__ Wo,
+                                                        int N, int K, float* __restrict__ out) {
+    const int n_attn = nkv * nsplit;
+    if ((int)blockIdx.x < n_attn) {
+        const int h = blockIdx.x % nkv, sp = blockIdx.x / nkv;
+        const bool merged = dec_attn_block(h, sp, nsplit, qkv, kcache, vcache, pos_ptr, rope_cos, rope_sin, part_o,
+                                           part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
+        if (merged) {  // block-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    __shared__ float red[4 * R];
+    const int n0 = ((int)blockIdx.x - n_attn) * R;
+    const uint16_t* rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rows[r] = Wo + (size_t)min(n0 + r, N - 1) * K;
+    uint4 w[R][NJ];
+    gemv_issue<NJ, R>(rows, K, w);
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_target < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) {  // ~seconds: never hang the device on a protocol bug
+                __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    float xr[NJ][8];
+    load_x<NJ>(attn_out, K, xr);
+    float acc[R];
+    gemv_fma<NJ, R>(w, xr, acc);
+    block256_sum<R>(acc, red);
+    if (threadIdx.x < R && n0 + threadIdx.x < N) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = acc[r];
+        out[n0 + threadIdx.x] = v;
     }
 }
 
@@ -537,7 +624,7 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
 // ---- K_G: global argmax (lowest index on ties, as torch.argmax), bookkeeping, and the
 // next step's input embedding (vita_arch.py:155-175 decode early-exit + embed_tokens).
 __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ blk_val, const int* __restrict__ blk_idx,
-                                                    int nblk, const uint16_t* __restrict__ embed, int H,
+                                                    int nblk, const uint16_t* __restrict__ embed, int H, int vocab,
                                                     float* __restrict__ x_next, int* __restrict__ pos_ptr,
                                                     int* __restrict__ ngen_ptr, int* __restrict__ out_tokens,
                                                     int max_out, int mode, int set_pos) {
@@ -559,7 +646,8 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ bl
         }
         __syncthreads();
     }
-    const int tok = i_s[0];
+    // all-NaN logits leave the sentinel index: never gather outside the table
+    const int tok = (i_s[0] >= 0 && i_s[0] < vocab) ? i_s[0] : 0;
     if (threadIdx.x == 0) {
         // mode 1: decode step (append, pos++); mode 0: end of prefill (first token, pos = set_pos)
         const int n = mode ? *ngen_ptr : 0;
@@ -632,6 +720,33 @@ int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int 
     });
 }
 
+// Fused attention + O-projection launch.  Returns 1 (nothing launched) when the launch could not be
+// fully co-resident or the shape is outside the fused instantiations: the caller then uses the two
+// separate kernels.
+int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
+                       const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
+                       float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
+                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out) {
+    constexpr int R = 16;
+    if (nq % nkv != 0 || nq / nkv > 4) return -1;
+    const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
+    if (nsplit < 1 || nsplit > max_splits) return -1;
+    const int n_oproj = (N + R - 1) / R;
+    // LDS (69.6 KB static) admits 2 blocks per CU; every block of the launch must be resident at once
+    const int cap = vh_tuning()->fuse_max_blocks > 0 ? vh_tuning()->fuse_max_blocks : 2 * vh_num_cus();
+    if (nkv * nsplit + n_oproj > cap || K > 4096 || (K % 8) != 0) return 1;
+    const dim3 grid(nkv * nsplit + n_oproj);
+    if (K <= 2048)
+        hipLaunchKernelGGL((k_dec_attn_oproj<1, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, pos_ptr, rope_cos,
+                           rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
+                           done_ctr, done_target, err_flag, Wo, N, K, out);
+    else
+        hipLaunchKernelGGL((k_dec_attn_oproj<2, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, pos_ptr, rope_cos,
+                           rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
+                           done_ctr, done_target, err_flag, Wo, N, K, out);
+    return 0;
+}
+
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid) {
@@ -679,8 +794,8 @@ int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const 
 }
 
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
-                   float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos) {
-    hipLaunchKernelGGL(k_dec_select, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, embed, H, x_next, pos_ptr,
+                   int vocab, float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos) {
+    hipLaunchKernelGGL(k_dec_select, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, embed, H, vocab, x_next, pos_ptr,
                        ngen_ptr, out_tokens, max_out, mode, set_pos);
     return 0;
 }

@@ -45,18 +45,24 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
     constexpr int NT = GLU ? 64 : 128;  // output columns per block
 
     // ---- which (n-tile, group, m-tile) is this block? -------------------------------
-    // 1-D grid.  Hardware block b runs on XCD b % 8 (own L2): remap b -> logical l so that each XCD
-    // owns a CONTIGUOUS range of l (bijective for any grid size), and let the m-tiles of one weight
-    // tile be adjacent in l.  All m-tiles that stream the same W[n-tile] rows then run back to back
-    // on one XCD: W leaves HBM once and is re-read from that XCD's L2.
+    // 1-D grid.  order 0 (default): n-tiles fastest — blocks that run together share the activation
+    // tile, which stays L2-resident.  order 1: hardware block b runs on XCD b % 8, remap b -> logical l
+    // so each XCD owns a CONTIGUOUS range of l (bijective for any grid size) with the m-tiles of one
+    // weight tile adjacent.  Measured on the S=552 MoE gate|up GEMM: order 0 877-900 us, order 1
+    // 985-1030 us (the weight re-reads it saves were not the bound), so 0 is the default.
     const int mt = p.mt_slots;
-    int l;
-    {
+    int n_tile, slot;
+    if (p.order == 0) {
+        const int ntl = gridDim.x / mt;
+        slot = blockIdx.x / ntl;
+        n_tile = blockIdx.x - slot * ntl;
+    } else {
         const int nwg = gridDim.x, b = blockIdx.x;
         const int xcd = b & 7, idx = b >> 3, q = nwg >> 3, r = nwg & 7;
-        l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        n_tile = l / mt;
+        slot = l - n_tile * mt;
     }
-    const int n_tile = l / mt, slot = l - n_tile * mt;
     int m_begin, m_end;
     const uint16_t* Wb = p.W;
     const uint16_t* Wu = p.W_up;
@@ -220,6 +226,7 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
     g.mt_slots = (a.M + GM_BM - 1) / GM_BM + (a.group_off ? a.ngroups : 0);  // grouped: upper bound on m-tiles
+    g.order = vh_tuning()->gemm_order;
     if (a.W_up) {
         hipLaunchKernelGGL(k_gemm<true>, dim3(((a.N + 63) / 64) * g.mt_slots), dim3(256), 0, st, g);
     } else {

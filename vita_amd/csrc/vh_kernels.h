@@ -9,6 +9,11 @@
 struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
+    int prefill_moe_gemm = 1; // MoE prefill GEMMs: 1 = general kernel (faster: 877+510 us vs 933+793 us at S=552), 0 = pre-split skinny kernel
+    int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
+    int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
+    int gemm_order = 0;       // general GEMM block order: 0 = n-tiles fastest, 1 = XCD-contiguous m-fastest
+    int ps_ablate = 0;        // timing experiments on vh_gemm_ps (wrong results when non-zero)
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
 };
 VhTuning* vh_tuning();
@@ -20,6 +25,10 @@ int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale);
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out);
+int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
+                       const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
+                       float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
+                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid);
@@ -28,7 +37,7 @@ int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const 
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
                    const int* ngen_ptr, int hist_rows);
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
-                   float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
+                   int vocab, float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
 
 // ---- GEMM (vh_gemm.hip) -------------------------------------------------------------
 // C[orow(m), n] = epilogue( sum_k A[arow(m,k), k] * W[n, k] )
@@ -44,8 +53,28 @@ struct VhGemmArgs {
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
     int mt_slots;                             // set by the launcher: m-tile slots per n-tile
+    int order;                                // set by the launcher: block -> tile order (vh_tune gemm_order)
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
+
+// ---- pre-split skinny GEMM (vh_gemm_ps.hip) ------------------------------------------
+// C[orow(m), n] = epilogue( sum_k (A_hi + A_lo)[arow(m), k] * W[n, k] ), A as bf16 hi/lo planes.  K % 64 == 0.
+struct VhGemmPsArgs {
+    const uint16_t* A_hi; const uint16_t* A_lo; long lda;   // planes [rows][lda] bf16
+    const int* a_rowidx;                                     // nullable gather: source row of logical row m
+    const uint16_t* W; const uint16_t* W_up; long ldw; long w_group_stride;   // W_up != null => SiLU(A W^T) * (A W_up^T)
+    const int* group_off; int ngroups;                       // nullable: device int[ngroups+1] sorted-row offsets
+    float* C; long ldc;                                      // nullable fp32 output
+    uint16_t* C_hi; uint16_t* C_lo; long ldc_split;          // nullable split output planes
+    const int* c_rowidx;
+    const float* bias; const float* scale; const float* resid; long ldr;
+    int M, N, K, act;
+    int ablate;                                              // debug: 1 skip A loads, 2 skip W loads, 4 skip MFMA
+    int wide;                                                // plain mode: 256-column tiles (512 threads) instead of 128
+};
+int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
+int vhk_split_planes(hipStream_t st, const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows,
+                     int cols);
 
 // ---- attention (vh_attn.hip) --------------------------------------------------------
 struct VhAttnArgs {

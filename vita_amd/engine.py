@@ -68,7 +68,7 @@ class MixtralEngine:
         # zero-copy views of the engine state living inside the workspace
         base = self.workspace.data_ptr()
         self.tokens = self.workspace[self._tok_ptr - base: self._tok_ptr - base + 4 * max(max_new, 1)].view(torch.int32)
-        self.counters = self.workspace[self._cnt_ptr - base: self._cnt_ptr - base + 8].view(torch.int32)
+        self.counters = self.workspace[self._cnt_ptr - base: self._cnt_ptr - base + 16].view(torch.int32)
         self.logit_rows = max(1, logit_rows)
         self.logits_all = self.workspace[self._logit_ptr - base: self._logit_ptr - base +
                                          4 * t.vocab_size * self.logit_rows].view(torch.float32).view(
@@ -144,5 +144,7 @@ class MixtralEngine:
 
     def generated(self):
         """(synchronising) list of token ids generated so far."""
-        n = int(self.counters[1].item())
-        return self.tokens[:min(n, self.max_new)].tolist()
+        c = self.counters.tolist()
+        if c[3] != 0:
+            raise _lib.VitaHipError("device-side hand-off timeout in the fused decode kernel (error flag set)")
+        return self.tokens[:min(c[1], self.max_new)].tolist()

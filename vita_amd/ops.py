@@ -173,3 +173,49 @@ def embed_splice(kind, idx, embed, img, aud, H):
     check(_lib.load().vh_embed_splice(_p(kind), _p(idx), _p(embed), _p(img), _p(aud), _p(out), S, H, _stream()),
           "vh_embed_splice")
     return out
+
+
+def split_planes(x):
+    """fp32 [rows, cols] -> (hi, lo) bf16 planes with x = hi + lo to 2^-17 (the pre-split GEMM operand)."""
+    _dev(x)
+    _f32(_c(x, "x"), "x")
+    rows, cols = x.shape
+    hi = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().vh_split_planes(_p(x), x.stride(0), _p(hi), _p(lo), cols, rows, cols, _stream()),
+          "vh_split_planes")
+    return hi, lo
+
+
+def gemm_ps(a_hi, a_lo, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=None, out_split=False,
+            a_rowidx=None, m=None, c_rowidx=None, group_off=None, ngroups=0, w_group_stride=0, wide=False):
+    """Skinny-M GEMM on pre-split activations (vh_gemm_ps).  Returns fp32 out, or (hi, lo) planes when
+    out_split=True."""
+    _dev(a_hi, a_lo, w)
+    _bf16(a_hi, "a_hi"); _bf16(a_lo, "a_lo"); _bf16(w, "w")
+    g = _lib.GemmPsArgs()
+    N, K = int(w.shape[-2]), int(w.shape[-1])
+    g.A_hi, g.A_lo, g.lda = a_hi.data_ptr(), a_lo.data_ptr(), int(a_hi.stride(0))
+    g.a_rowidx = a_rowidx.data_ptr() if a_rowidx is not None else None
+    g.W = w.data_ptr(); g.W_up = w_up.data_ptr() if w_up is not None else None
+    g.ldw, g.w_group_stride = K, int(w_group_stride)
+    g.group_off = group_off.data_ptr() if group_off is not None else None
+    g.ngroups = int(ngroups)
+    M = int(m if m is not None else (a_rowidx.shape[0] if a_rowidx is not None else a_hi.shape[0]))
+    planes = None
+    if out_split:
+        planes = (torch.empty((M, N), dtype=torch.bfloat16, device=w.device),
+                  torch.empty((M, N), dtype=torch.bfloat16, device=w.device))
+        g.C_hi, g.C_lo, g.ldc_split = planes[0].data_ptr(), planes[1].data_ptr(), N
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=w.device)
+        g.C, g.ldc = out.data_ptr(), int(out.stride(0))
+    g.c_rowidx = c_rowidx.data_ptr() if c_rowidx is not None else None
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.scale = scale.data_ptr() if scale is not None else None
+    if resid is not None:
+        g.resid, g.ldr = resid.data_ptr(), int(resid.stride(0))
+    g.M, g.N, g.K, g.act, g.wide = M, N, K, ACT[act], int(bool(wide))
+    check(_lib.load().vh_gemm_ps(C.byref(g), _stream()), "vh_gemm_ps")
+    return planes if out_split else out
