@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --one-device is the 1-GPU functional check of the N>1 path")
+    ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0 (invalid as a measurement)")
     ap.add_argument("--tune", default="", help="debug: kernel-variant knobs key=val[,key=val] (vh_tune)")
     args = ap.parse_args()
 
@@ -110,12 +113,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+            args.collective = "torch"      # RCCL refuses two ranks on one device; gloo stages through the host
 
     from vita_amd.checkpoint import synth_mixtral_device, synth_state_dict
     from vita_amd.config import VitaConfig, audio_token_count
@@ -264,6 +273,8 @@ def main():
             out["INVALID_debug_layers"] = args.layers
         if args.tune:
             out["tune"] = args.tune
+        if args.one_device or args.backend != "nccl":
+            out["INVALID_debug_backend"] = f"{args.backend}, one_device={args.one_device}"
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(VitaConfig())

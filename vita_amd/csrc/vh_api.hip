@@ -46,6 +46,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
     if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
     if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
+    if (!strcmp(key, "gemm_tall")) { g_tuning.gemm_tall = value; return VH_OK; }
     if (!strcmp(key, "gemm_order")) { g_tuning.gemm_order = value; return VH_OK; }
     if (!strcmp(key, "ps_ablate")) { g_tuning.ps_ablate = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
 // of its KV head and wrote attn_out rows [h*G*128, (h+1)*G*128) (block-uniform).
 __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const int nsplit,
                                                const float* __restrict__ qkv, float* __restrict__ kcache,
-                                               float* __restrict__ vcache, const int* __restrict__ pos_ptr,
+                                               float* __restrict__ vcache, const int pos,
                                                const float* __restrict__ rope_cos,
                                                const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                float* __restrict__ part_ml, int* __restrict__ cnt,
@@ -188,7 +188,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int G = nq / nkv;
-    const int pos = *pos_ptr;
+    // the position comes from the host mirror (it sized this grid): no dependent load before the K/V tiles
     const int k0 = sp * DA_KT;
     const int k1 = min(pos + 1, k0 + DA_KT);
     const int head = h * G + wid;
@@ -318,13 +318,13 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
 }
 
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                                  float* __restrict__ vcache, const int* __restrict__ pos_ptr,
+                                                  float* __restrict__ vcache, const int pos,
                                                   const float* __restrict__ rope_cos,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
                                                   int max_splits, float scale) {
-    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos_ptr, rope_cos, rope_sin, part_o,
+    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, rope_cos, rope_sin, part_o,
                    part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
 }
 
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
 // block is scheduled no matter in which order the dispatcher places blocks.
 template <int NJ, int R>
 __global__ __launch_bounds__(256) void k_dec_attn_oproj(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                                        float* __restrict__ vcache, const int* __restrict__ pos_ptr,
+                                                        float* __restrict__ vcache, const int pos,
                                                         const float* __restrict__ rope_cos,
                                                         const float* __restrict__ rope_sin,
                                                         float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_dec_attn_oproj(const float* __restrict_
     const int n_attn = nkv * nsplit;
     if ((int)blockIdx.x < n_attn) {
         const int h = blockIdx.x % nkv, sp = blockIdx.x / nkv;
-        const bool merged = dec_attn_block(h, sp, nsplit, qkv, kcache, vcache, pos_ptr, rope_cos, rope_sin, part_o,
+        const bool merged = dec_attn_block(h, sp, nsplit, qkv, kcache, vcache, pos, rope_cos, rope_sin, part_o,
                                            part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
         if (merged) {  // block-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -706,7 +706,7 @@ int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache,
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits) return -1;
-    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, pos_ptr, rope_cos,
+    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
                        rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
     return 0;
 }
@@ -737,11 +737,11 @@ int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* v
     if (nkv * nsplit + n_oproj > cap || K > 4096 || (K % 8) != 0) return 1;
     const dim3 grid(nkv * nsplit + n_oproj);
     if (K <= 2048)
-        hipLaunchKernelGGL((k_dec_attn_oproj<1, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, pos_ptr, rope_cos,
+        hipLaunchKernelGGL((k_dec_attn_oproj<1, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
                            rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
                            done_ctr, done_target, err_flag, Wo, N, K, out);
     else
-        hipLaunchKernelGGL((k_dec_attn_oproj<2, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, pos_ptr, rope_cos,
+        hipLaunchKernelGGL((k_dec_attn_oproj<2, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
                            rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
                            done_ctr, done_target, err_flag, Wo, N, K, out);
     return 0;

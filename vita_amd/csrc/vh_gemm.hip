@@ -34,65 +34,103 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset in 
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <bool GLU>
-__global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_ahi[GM_BM * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_alo[GM_BM * 128];
+// BM = 64 : 256 threads, waves 2 (M) x 2 (N) — the general case (encoders, QKV / O projections).
+// BM = 256: 512 threads, waves 4 (M) x 2 (N) — the top-2 MoE grouped GEMMs.  rocprof PMC showed the
+//           BM = 64 kernel fabric-bound there: FETCH_SIZE = 2.76x the weight bytes at 5.9 TB/s, because
+//           an expert's ~S/4 rows span three 64-row m-tiles and each re-streams the expert's weights.
+//           One 256-row m-tile holds all rows of an expert up to S ~ 900, so the weights leave HBM once;
+//           row tiles past the group's rows are neither loaded nor multiplied (wave-uniform skip).
+template <bool GLU, int BM, int MINW>
+__global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGemmArgs p) {
+    constexpr int THREADS = BM == 64 ? 256 : 512;
+    constexpr int WMW = BM == 64 ? 2 : 4;            // waves along M (2 along N in both shapes)
+    constexpr int MI = BM / WMW / 16;                // 16-row tiles per wave: 2 / 4
+    constexpr int AF4 = BM * 16 / THREADS;           // float4 of A per thread per K-tile: 4 / 8
+    constexpr int ATPR = 16 / AF4;                   // threads per A row: 4 / 2
+    constexpr int WU4 = GM_BN * 8 / THREADS;         // uint4 of W per thread per K-tile: 4 / 2
+    constexpr int WTPR = 8 / WU4;                    // threads per W row: 2 / 4
+    __shared__ __attribute__((aligned(16))) unsigned char lds_ahi[BM * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_alo[BM * 128];
     __shared__ __attribute__((aligned(16))) unsigned char lds_w[GM_BN * 128];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid & 1, wn = wid >> 1;
+    const int wm = wid % WMW, wn = wid / WMW;
     constexpr int NT = GLU ? 64 : 128;  // output columns per block
 
     // ---- which (n-tile, group, m-tile) is this block? -------------------------------
     // 1-D grid.  order 0 (default): n-tiles fastest — blocks that run together share the activation
     // tile, which stays L2-resident.  order 1: hardware block b runs on XCD b % 8, remap b -> logical l
     // so each XCD owns a CONTIGUOUS range of l (bijective for any grid size) with the m-tiles of one
-    // weight tile adjacent.  Measured on the S=552 MoE gate|up GEMM: order 0 877-900 us, order 1
-    // 985-1030 us (the weight re-reads it saves were not the bound), so 0 is the default.
+    // weight tile adjacent.  Measured on the S=552 MoE gate|up GEMM (BM = 64): order 0 877-900 us at
+    // FETCH 2.76x W, order 1 985-1030 us at FETCH 3.5x W (the activation tiles stop hitting L2), so 0
+    // is the default.
     const int mt = p.mt_slots;
-    int n_tile, slot;
-    if (p.order == 0) {
-        const int ntl = gridDim.x / mt;
-        slot = blockIdx.x / ntl;
-        n_tile = blockIdx.x - slot * ntl;
-    } else {
+    const int ntl = gridDim.x / mt;                  // n-tiles
+    int n_tile, slot = 0, l = blockIdx.x;
+    if (p.order != 0) {
         const int nwg = gridDim.x, b = blockIdx.x;
         const int xcd = b & 7, idx = b >> 3, q = nwg >> 3, r = nwg & 7;
-        const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        n_tile = l / mt;
-        slot = l - n_tile * mt;
+        l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     int m_begin, m_end;
     const uint16_t* Wb = p.W;
     const uint16_t* Wu = p.W_up;
-    if (p.group_off) {
-        int tile = slot, e = 0;
+    if (p.group_off && p.order == 2) {
+        // group-major, then n-tile, the group's m-tiles fastest: with the XCD-contiguous remap one XCD
+        // works through (mostly) one expert, so its few activation tiles stay in that XCD's L2 AND the
+        // m-tiles sharing a weight tile run back to back on it — the weight leaves HBM once.
+        int e = 0, nt = 0;
         for (; e < p.ngroups; ++e) {
             const int cnt = p.group_off[e + 1] - p.group_off[e];
-            const int nt = (cnt + GM_BM - 1) / GM_BM;
-            if (tile < nt) break;
-            tile -= nt;
+            nt = (cnt + BM - 1) / BM;
+            if (l < nt * ntl) break;
+            l -= nt * ntl;
         }
         if (e == p.ngroups) return;
-        m_begin = p.group_off[e] + tile * GM_BM;
+        n_tile = l / nt;
+        const int tile = l - n_tile * nt;
+        m_begin = p.group_off[e] + tile * BM;
         m_end = p.group_off[e + 1];
         Wb += (size_t)e * p.w_group_stride;
         if (GLU) Wu += (size_t)e * p.w_group_stride;
     } else {
-        m_begin = slot * GM_BM;
-        m_end = p.M;
-        if (m_begin >= m_end) return;
+        if (p.order == 0) {
+            slot = l / ntl;
+            n_tile = l - slot * ntl;
+        } else {
+            n_tile = l / mt;
+            slot = l - n_tile * mt;
+        }
+        if (p.group_off) {
+            int tile = slot, e = 0;
+            for (; e < p.ngroups; ++e) {
+                const int cnt = p.group_off[e + 1] - p.group_off[e];
+                const int nt = (cnt + BM - 1) / BM;
+                if (tile < nt) break;
+                tile -= nt;
+            }
+            if (e == p.ngroups) return;
+            m_begin = p.group_off[e] + tile * BM;
+            m_end = p.group_off[e + 1];
+            Wb += (size_t)e * p.w_group_stride;
+            if (GLU) Wu += (size_t)e * p.w_group_stride;
+        } else {
+            m_begin = slot * BM;
+            m_end = p.M;
+            if (m_begin >= m_end) return;
+        }
     }
     const int n_begin = n_tile * NT;
+    const int rows_here = min(m_end - m_begin, BM);
+    const int nrt = (rows_here + 15) >> 4;           // 16-row tiles that hold data
 
     // ---- staging assignments -------------------------------------------------------
-    const int arow = tid >> 2, achunk0 = (tid & 3) * 2;  // 16 floats = 2 chunks
+    const int arow = tid / ATPR, achunk0 = (tid % ATPR) * (AF4 / 2);  // AF4/2 chunks of 8 floats
     const int am = m_begin + arow;
     const bool a_valid_m = am < m_end;
     const int a_src = a_valid_m ? (p.a_rowidx ? p.a_rowidx[am] : am) : 0;
 
-    const int wrow = tid >> 1, wchunk0 = (tid & 1) * 4;  // 32 bf16 = 4 chunks
+    const int wrow = tid / WTPR, wchunk0 = (tid % WTPR) * WU4;
     const uint16_t* wptr;
     bool w_valid;
     if (GLU) {
@@ -105,8 +143,8 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
         wptr = Wb + (size_t)(w_valid ? n : 0) * p.ldw + wchunk0 * 8;
     }
 
-    float4 ra[4];
-    uint4 rw[4];
+    float4 ra[AF4];
+    uint4 rw[WU4];
     auto load_tile = [&](int kt) {
         const int k0 = kt * GM_BK;
         const int seg = k0 / p.seglen;
@@ -114,20 +152,24 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
         const int srow = a_src + p.segrow[seg];
         if (a_valid_m && srow >= 0 && srow < p.a_rows) {
             const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)srow * p.lda + koff + achunk0 * 8);
-            ra[0] = ap[0]; ra[1] = ap[1]; ra[2] = ap[2]; ra[3] = ap[3];
+#pragma unroll
+            for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
         } else {
-            ra[0] = ra[1] = ra[2] = ra[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < AF4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (w_valid) {
             const uint4* wp = reinterpret_cast<const uint4*>(wptr + k0);
-            rw[0] = wp[0]; rw[1] = wp[1]; rw[2] = wp[2]; rw[3] = wp[3];
+#pragma unroll
+            for (int i = 0; i < WU4; ++i) rw[i] = wp[i];
         } else {
-            rw[0] = rw[1] = rw[2] = rw[3] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WU4; ++i) rw[i] = make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < AF4 / 2; ++c) {
             const float4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
             const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
             uint32_t hi[8], lo[8];
@@ -142,12 +184,12 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
             *reinterpret_cast<uint4*>(lds_alo + off) = pl;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
+        for (int c = 0; c < WU4; ++c) *reinterpret_cast<uint4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -161,13 +203,7 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + (lane >> 4);
-            bf16x8_t ah[2], al[2], bw[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = lds_off(wm * 32 + i * 16 + (lane & 15), chunk);
-                ah[i] = *reinterpret_cast<const bf16x8_t*>(lds_ahi + off);
-                al[i] = *reinterpret_cast<const bf16x8_t*>(lds_alo + off);
-            }
+            bf16x8_t bw[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int r;
@@ -176,21 +212,30 @@ __global__ __launch_bounds__(256) void k_gemm(const VhGemmArgs p) {
                 bw[j] = *reinterpret_cast<const bf16x8_t*>(lds_w + lds_off(r + (lane & 15), chunk));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i) {
+                const int rt = wm + WMW * i;          // row tiles interleaved over the M waves
+                if (rt < nrt) {                       // wave-uniform
+                    const int off = lds_off(rt * 16 + (lane & 15), chunk);
+                    const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(lds_ahi + off);
+                    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(lds_alo + off);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bw[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bw[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bw[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bw[j], acc[i][j], 0, 0, 0);
+                    }
                 }
+            }
         }
     }
 
     // ---- epilogue: D layout col = lane&15, row = (lane>>4)*4 + r ---------------------
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
+        const int rt = wm + WMW * i;
+        if (rt >= nrt) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m_begin + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+            const int m = m_begin + rt * 16 + (lane >> 4) * 4 + r;
             if (m >= m_end) continue;
             const long orow = p.c_rowidx ? p.c_rowidx[m] : m;
             if (GLU) {
@@ -225,12 +270,20 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
         return -1;
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
-    g.mt_slots = (a.M + GM_BM - 1) / GM_BM + (a.group_off ? a.ngroups : 0);  // grouped: upper bound on m-tiles
     g.order = vh_tuning()->gemm_order;
+    // tall m-tiles for the grouped (MoE) GEMMs: one tile per expert, weights streamed once
+    const bool tall = a.group_off != nullptr && vh_tuning()->gemm_tall != 0;
+    const int bm = tall ? 256 : GM_BM;
+    g.mt_slots = a.group_off ? (a.M / bm + a.ngroups) : (a.M + bm - 1) / bm;  // grouped: upper bound on m-tiles
+    const int nt_glu = (a.N + 63) / 64, nt = (a.N + GM_BN - 1) / GM_BN;
     if (a.W_up) {
-        hipLaunchKernelGGL(k_gemm<true>, dim3(((a.N + 63) / 64) * g.mt_slots), dim3(256), 0, st, g);
+        if (tall && vh_tuning()->gemm_tall == 2) hipLaunchKernelGGL((k_gemm<true, 256, 4>), dim3(nt_glu * g.mt_slots), dim3(512), 0, st, g);
+        else if (tall) hipLaunchKernelGGL((k_gemm<true, 256, 1>), dim3(nt_glu * g.mt_slots), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<true, 64, 1>), dim3(nt_glu * g.mt_slots), dim3(256), 0, st, g);
     } else {
-        hipLaunchKernelGGL(k_gemm<false>, dim3(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots), dim3(256), 0, st, g);
+        if (tall && vh_tuning()->gemm_tall == 2) hipLaunchKernelGGL((k_gemm<false, 256, 4>), dim3(nt * g.mt_slots), dim3(512), 0, st, g);
+        else if (tall) hipLaunchKernelGGL((k_gemm<false, 256, 1>), dim3(nt * g.mt_slots), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<false, 64, 1>), dim3(nt * g.mt_slots), dim3(256), 0, st, g);
     }
     return 0;
 }

@@ -12,6 +12,7 @@ struct VhTuning {
     int prefill_moe_gemm = 1; // MoE prefill GEMMs: 1 = general kernel (faster: 877+510 us vs 933+793 us at S=552), 0 = pre-split skinny kernel
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
     int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
+    int gemm_tall = 0;        // grouped GEMMs: 256-row m-tiles (0 = 64-row tiles everywhere)
     int gemm_order = 0;       // general GEMM block order: 0 = n-tiles fastest, 1 = XCD-contiguous m-fastest
     int ps_ablate = 0;        // timing experiments on vh_gemm_ps (wrong results when non-zero)
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
