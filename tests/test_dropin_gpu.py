@@ -124,6 +124,23 @@ def test_demo_sequence_image_audio(ckpt, dev):
     assert isinstance(text, str)
 
 
+def test_hf_path_audio_side_files(tmp_path, dev):
+    """HF-path checkpoint layout: CMVN + fbank configuration come from <mm_audio_encoder>/global_cmvn and
+    train.yaml (dither and the random chunk mask are overridden, with warnings)."""
+    from vita_amd.config import VitaConfig
+    d = str(tmp_path)
+    sd = tiny_ckpt.write(d, seed=22, audio_side_files=True)
+    wav = os.path.join(d, "q.wav")
+    tiny_ckpt.write_wav(wav, seconds=0.9, seed=5)
+    with pytest.warns(UserWarning, match="audio encoder"):
+        model, ids, pix, audios, got, scores, _ = _demo(d, None, wav, "what is this sound", max_new_tokens=6)
+    assert model.get_audio_encoder().audio_processor.dataset_conf["fbank_conf"]["dither"] == 0.0
+    exp, exp_scores = _expected(sd, VitaConfig.tiny(), ids, pix, audios, 6)
+    assert got == exp[:len(got)], (got, exp)
+    err = max(float((scores[i] - exp_scores[i]).abs().max()) for i in range(len(got)))
+    assert err < 1e-4, err     # CMVN statistics went through the Kaldi text file (float64 -> float32)
+
+
 def test_demo_sequence_text_only(ckpt, dev):
     """text-only prompt: the demo still feeds a zero image and a 400-frame zero clip (video_audio_demo.py:188-195,227-231)."""
     d, sd, _, _ = ckpt

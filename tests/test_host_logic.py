@@ -141,3 +141,39 @@ def test_ops_refuse_cpu_tensors():
     from vita_amd import _lib, ops
     with pytest.raises(_lib.VitaHipError):
         ops.gemm(torch.zeros(4, 64), torch.zeros(8, 64, dtype=torch.bfloat16))
+
+
+def test_audio_side_files_match_reference_loaders(tmp_path):
+    """train.yaml + global_cmvn (JSON and Kaldi text) parsed as the reference's whale/cmvn.py does."""
+    import json
+    import numpy as np
+    from vita_amd.audio_config import load_cmvn, read_audio_encoder_dir
+    rng = np.random.default_rng(4)
+    n, d = 12345.0, 80
+    s1 = rng.standard_normal(d) * 40 * n
+    s2 = (rng.random(d) * 30 + (s1 / n) ** 2) * n
+    pj, pk = tmp_path / "cmvn.json", tmp_path / "global_cmvn"
+    pj.write_text(json.dumps({"mean_stat": s1.tolist(), "var_stat": s2.tolist(), "frame_num": n}))
+    pk.write_text("[\n " + " ".join(repr(float(x)) for x in s1) + f" {n!r}\n " + " ".join(repr(float(x)) for x in s2) + " 0 ]\n")
+    mean = s1 / n
+    istd = 1.0 / np.sqrt(np.maximum(s2 / n - mean * mean, 1e-20))
+    for path, is_json in ((pj, True), (pk, False)):
+        m, i = load_cmvn(str(path), is_json)
+        np.testing.assert_allclose(m, mean, rtol=1e-6); np.testing.assert_allclose(i, istd, rtol=1e-6)
+    if os.path.isdir("/root/reference/vita"):
+        from oracle import ref_harness as rh
+        rh.install()
+        import logging, sys, math  # noqa: F401  (the reference's kaldi loader uses names it never imports)
+        from vita.model.multimodal_encoder.whale import cmvn as rc
+        rc.logging, rc.sys = logging, sys
+        for path, is_json in ((pj, True), (pk, False)):
+            rm, ri = rc.load_cmvn(str(path), is_json)
+            m, i = load_cmvn(str(path), is_json)
+            np.testing.assert_allclose(m, rm, rtol=1e-6); np.testing.assert_allclose(i, ri, rtol=1e-6)
+    (tmp_path / "train.yaml").write_text(
+        "input_dim: 80\nis_json_cmvn: false\ndataset_conf:\n  resample_conf: {resample_rate: 16000}\n"
+        "  fbank_conf: {num_mel_bins: 80, frame_length: 25, frame_shift: 10, dither: 1.0}\n"
+        "encoder_conf:\n  transformer-dynamic-chunks: true\n")
+    side = read_audio_encoder_dir(str(tmp_path))
+    assert side["dataset_conf"]["fbank_conf"]["dither"] == 0.0 and len(side["overridden"]) == 2
+    np.testing.assert_allclose(side["mean"], mean, rtol=1e-6)

@@ -1,0 +1,78 @@
+"""vLLM-shaped surface: the app-side contract of web_demo/web_ability_demo.py:203-232 —
+one placeholder id per image / clip, PIL images and CMVN-normalised features in multi_modal_data,
+SamplingParams(temperature=0.01) == greedy — must produce the SAME tokens as the HF-flavour path on the
+same request (whose parity with the reference is pinned in test_model_gpu.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from tests import tiny_ckpt
+
+pytestmark = pytest.mark.gpu
+IMG_ID, AUD_ID = 990, 991      # stand-ins for 51000 / 51001 inside the tiny 1000-entry vocabulary
+
+
+@pytest.fixture(scope="module")
+def served(tmp_path_factory):
+    from vita_amd.serving import LLM
+    d = str(tmp_path_factory.mktemp("vita_tiny_serving"))
+    sd = tiny_ckpt.write(d, seed=31)
+    cj = os.path.join(d, "config.json")
+    with open(cj) as f:
+        j = json.load(f)
+    j.update(image_token_index=IMG_ID, audio_token_index=AUD_ID, min_dynamic_patch=1, max_dynamic_patch=12,
+             use_thumbnail=True)
+    with open(cj, "w") as f:
+        json.dump(j, f)
+    return LLM(model=d, dtype="float16", tensor_parallel_size=1, limit_mm_per_prompt={"image": 256, "audio": 50},
+               max_new_tokens=32), sd, d
+
+
+def test_generate_image_audio_request(served, dev):
+    from vita_amd.audio_frontend import WhaleFeatureExtractor, kaldi_fbank
+    from vita_amd.config import VitaConfig
+    from vita_amd.host.image_processing import dynamic_preprocess
+    from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
+    from vita_amd.serving import SamplingParams, audio_feature_size
+    llm, sd, d = served
+    rng = np.random.default_rng(3)
+    img = Image.fromarray(rng.integers(0, 255, size=(70, 170, 3), dtype=np.uint8))     # wide: several tiles + thumbnail
+    wav = 0.1 * rng.standard_normal(16000)
+    feats = WhaleFeatureExtractor()(wav[None], sampling_rate=16000, return_tensors="pt")["input_features"][0]
+    ids = [1, 5, 6, 7, IMG_ID, 8, 9, AUD_ID, 10]
+    outs = llm.generate({"prompt_token_ids": ids, "multi_modal_data": {"image": [img], "audio": [feats]}},
+                        sampling_params=SamplingParams(temperature=0.01, max_tokens=10, best_of=1,
+                                                       skip_special_tokens=False))
+    got = outs[0].outputs[0].token_ids
+    assert isinstance(outs[0].outputs[0].text, str) and 1 <= len(got) <= 10
+
+    # the same request through the HF-flavour boundary: raw fbank (CMVN inside the encoder), one sentinel per tile
+    cfg = VitaConfig.tiny()
+    m = VITAMixtralForCausalLM(cfg, sd, device="cuda:0", max_new_tokens=32, max_prefill=2048)
+    m.get_vision_tower().load_model()
+    tiles, _ = dynamic_preprocess(img, min_num=1, max_num=12, image_size=cfg.vision.image_size, use_thumbnail=True)
+    assert len(tiles) > 1
+    pix = m.process_images(tiles, m.config).to("cuda:0")
+    raw = torch.from_numpy(kaldi_fbank(wav * (1 << 15), 16000))
+    sent = [1, 5, 6, 7] + [-200] * len(tiles) + [8, 9, -500, 10]
+    ref = m.generate(torch.tensor([sent], device="cuda:0"), images=pix,
+                     audios={"audios": raw[None].to("cuda:0"), "lengths": torch.tensor([raw.shape[0]], device="cuda:0")},
+                     do_sample=False, num_beams=1, return_dict_in_generate=True, max_new_tokens=10)
+    exp = ref.sequences[0, len(sent):].tolist()
+    assert got == exp, (got, exp)
+    assert audio_feature_size(raw.shape[0]) == m.get_audio_encoder()(raw[None], torch.tensor([raw.shape[0]]))["inputs_embeds"].shape[1]
+
+
+def test_text_only_and_errors(served, dev):
+    from vita_amd.serving import SamplingParams
+    llm, _, _ = served
+    out = llm.generate({"prompt_token_ids": [1, 5, 6, 7, 8]}, sampling_params=SamplingParams(max_tokens=4))
+    assert 1 <= len(out[0].outputs[0].token_ids) <= 4
+    with pytest.raises(ValueError):          # placeholder without data (mixtral.py:244-247)
+        llm.generate({"prompt_token_ids": [1, IMG_ID, 5]}, sampling_params=SamplingParams(max_tokens=2))
+    with pytest.raises(NotImplementedError):
+        llm.generate({"prompt_token_ids": [1, 5]}, sampling_params=SamplingParams(temperature=0.8))

@@ -34,7 +34,7 @@ def write_tokenizer(path, vocab_size):
         json.dump({"bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>"}, f)
 
 
-def write(path, cfg: VitaConfig = None, seed=0):
+def write(path, cfg: VitaConfig = None, seed=0, audio_side_files=False):
     from safetensors.torch import save_file
     cfg = cfg or VitaConfig.tiny()
     os.makedirs(path, exist_ok=True)
@@ -54,11 +54,30 @@ def write(path, cfg: VitaConfig = None, seed=0):
             "audio_config": {"input_dim": a.input_dim, "hidden_size": a.hidden_size,
                              "num_hidden_layers": a.num_hidden_layers, "num_attention_heads": a.num_attention_heads,
                              "intermediate_size": a.intermediate_size, "layer_norm_eps": a.layer_norm_eps}}
+    sd = synth_state_dict(cfg, seed=seed, rich=True)
+    skip = set()
+    if audio_side_files:
+        # HF-path layout (multimodal_encoder/builder.py:44-59): CMVN statistics and the fbank configuration
+        # live in <mm_audio_encoder>/{global_cmvn, train.yaml}, not in the safetensors
+        conf["mm_audio_encoder"] = "audio-encoder"
+        d = os.path.join(path, "audio-encoder")
+        os.makedirs(d, exist_ok=True)
+        mean = sd["model.audio_encoder.encoder.global_cmvn.mean"].astype(np.float64)
+        istd = sd["model.audio_encoder.encoder.global_cmvn.istd"].astype(np.float64)
+        n = 1.0e6
+        s1, s2 = mean * n, (1.0 / (istd * istd) + mean * mean) * n
+        with open(os.path.join(d, "global_cmvn"), "w") as f:
+            f.write("[\n " + " ".join(repr(float(x)) for x in s1) + f" {n!r}\n " +
+                    " ".join(repr(float(x)) for x in s2) + " 0 ]\n")
+        with open(os.path.join(d, "train.yaml"), "w") as f:
+            f.write("input_dim: 80\nis_json_cmvn: false\ndataset_conf:\n  resample_conf: {resample_rate: 16000}\n"
+                    "  fbank_conf: {num_mel_bins: 80, frame_length: 25, frame_shift: 10, dither: 1.0}\n"
+                    "encoder_conf:\n  transformer-dynamic-chunks: true\n")
+        skip = {k for k in sd if "global_cmvn" in k}
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(conf, f, indent=1)
-    sd = synth_state_dict(cfg, seed=seed, rich=True)
     # two shards, as HF writes large checkpoints; bf16 is the released dtype (values are bf16-exact)
-    keys = sorted(sd)
+    keys = sorted(k for k in sd if k not in skip)
     half = len(keys) // 2
     from vita_amd.checkpoint import round_bf16
 

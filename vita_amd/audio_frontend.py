@@ -103,3 +103,48 @@ class AudioEncoderProcessor:
         mat = kaldi_fbank(wavef * (1 << 15), sample_rate=sr, num_mel_bins=fb["num_mel_bins"],
                           frame_length_ms=fb["frame_length"], frame_shift_ms=fb["frame_shift"], dither=fb["dither"])
         return torch.from_numpy(mat), audio_token_count(mat.shape[0])
+
+
+class WhaleFeatureExtractor:
+    """The vLLM-flavour extractor (web_demo/vllm_tools/model_weight_file/processor_whale.py): fbank followed by
+    CMVN with the PRELOADED means / inverse stds (utterance_cmvn with cmvn_means/cmvn_istds, :211-233), so the
+    audio tower receives normalised features.  Call: extractor(waveform [1, n] or [n] in [-1, 1),
+    sampling_rate=16000, return_tensors="pt") -> {"input_features": [1, T, 80], "attention_mask": [1, T]}.
+    dither is pinned to 0 (the shipped preprocessor_config.json says 1.0 = random noise per call)."""
+
+    def __init__(self, sampling_rate=16000, num_mel_bins=80, frame_length=25, frame_shift=10, cmvn_means=None,
+                 cmvn_istds=None, **_):
+        from .checkpoint import vendored_cmvn
+        self.sampling_rate, self.num_mel_bins = sampling_rate, num_mel_bins
+        self.frame_length, self.frame_shift = frame_length, frame_shift
+        if cmvn_means is None or cmvn_istds is None:
+            cmvn_means, cmvn_istds = vendored_cmvn(num_mel_bins)
+        self.cmvn_means = np.asarray(cmvn_means, np.float32)
+        self.cmvn_istds = np.asarray(cmvn_istds, np.float32)
+
+    @classmethod
+    def from_pretrained(cls, model_path, subfolder="feature_extractor", **_):
+        import json
+        import os
+        with open(os.path.join(model_path, subfolder, "preprocessor_config.json")) as f:
+            j = json.load(f)
+        return cls(sampling_rate=j.get("sampling_rate", 16000), num_mel_bins=j.get("num_mel_bins", 80),
+                   frame_length=j.get("frame_length", 25), frame_shift=j.get("frame_shift", 10),
+                   cmvn_means=j.get("cmvn_means"), cmvn_istds=j.get("cmvn_istds"))
+
+    def __call__(self, raw_speech, sampling_rate=None, return_tensors=None, **_):
+        import torch
+        x = raw_speech.detach().cpu().numpy() if hasattr(raw_speech, "detach") else np.asarray(raw_speech)
+        x = np.squeeze(x).astype(np.float64)
+        if sampling_rate is not None and sampling_rate != self.sampling_rate:
+            from scipy.signal import resample_poly
+            g = math.gcd(int(sampling_rate), int(self.sampling_rate))
+            x = resample_poly(x, self.sampling_rate // g, sampling_rate // g)
+        feats = kaldi_fbank(x * (1 << 15), self.sampling_rate, self.num_mel_bins, self.frame_length, self.frame_shift,
+                            dither=0.0)
+        feats = ((feats - self.cmvn_means[None]) * self.cmvn_istds[None]).astype(np.float32)
+        mask = np.ones((1, feats.shape[0]), np.int32)
+        out = {"input_features": feats[None], "attention_mask": mask}
+        if return_tensors == "pt":
+            out = {k: torch.from_numpy(v) for k, v in out.items()}
+        return out

@@ -90,6 +90,7 @@ def load_pretrained_model(model_path, model_base, model_name, model_type, load_8
     dev = "cuda:0" if device == "cuda" else device
     sd = _LazyShards(model_path)
     model = VITAMixtralForCausalLM(cfg, sd, device=dev, **kwargs)
+    _apply_audio_side_files(model, os.path.join(model_path, "config.json"), model_path)
     model.resize_token_embeddings(len(tokenizer))
     tower = model.get_vision_tower()
     if not tower.is_loaded:
@@ -99,6 +100,33 @@ def load_pretrained_model(model_path, model_base, model_name, model_type, load_8
     if model.generation_config.pad_token_id is None:
         model.generation_config.pad_token_id = model.generation_config.eos_token_id
     return tokenizer, model, image_processor, context_len
+
+
+def _apply_audio_side_files(model, config_json, model_path):
+    """config.mm_audio_encoder names a directory with train.yaml + global_cmvn
+    (multimodal_encoder/builder.py:44-59): take the fbank configuration from it, and its CMVN
+    statistics when the checkpoint itself carries none."""
+    from ..audio_config import read_audio_encoder_dir
+    from ..audio_frontend import AudioEncoderProcessor
+    with open(config_json) as f:
+        j = json.load(f)
+    d = j.get("mm_audio_encoder")
+    if not d:
+        return
+    if not os.path.isabs(d):
+        d = os.path.join(model_path, d)
+    if not os.path.isfile(os.path.join(d, "train.yaml")):
+        return
+    side = read_audio_encoder_dir(d)
+    enc = model.get_audio_encoder()
+    enc.audio_processor = AudioEncoderProcessor(side["dataset_conf"])
+    if side["input_dim"] != enc.acfg.input_dim:
+        raise ValueError(f"train.yaml input_dim {side['input_dim']} != model {enc.acfg.input_dim}")
+    if side["mean"] is not None and enc.w is not None and not getattr(enc, "cmvn_from_checkpoint", False):
+        enc.w["mean"] = torch.from_numpy(side["mean"]).to(enc.device)
+        enc.w["istd"] = torch.from_numpy(side["istd"]).to(enc.device)
+    for msg in side["overridden"]:
+        warnings.warn("audio encoder: " + msg)
 
 
 def build_synthetic_model(cfg: VitaConfig = None, seed=0, device="cuda:0", rich=True, **kwargs):

@@ -218,6 +218,7 @@ class WhaleAudioEncoder(_HipModule):
         self.llm_dim = llm_dim
         self.audio_processor = AudioEncoderProcessor()
         self.chunk, self.left = 0, -1
+        self.normalized_input = False   # True: features already CMVN-normalised (vLLM-flavour extractor)
         self.w = None
         if sd is not None:
             self.load(sd, device)
@@ -231,7 +232,13 @@ class WhaleAudioEncoder(_HipModule):
         C, Fq = a.hidden_size, a.sub_freq
         g = lambda k: _get(sd, AUD + k)
         c = "encoder.enc.0.core."
-        w = {"mean": _f32(g("encoder.global_cmvn.mean"), dev), "istd": _f32(g("encoder.global_cmvn.istd"), dev),
+        has_cmvn = (AUD + "encoder.global_cmvn.mean") in sd
+        self.cmvn_from_checkpoint = has_cmvn
+        if has_cmvn:
+            mean, istd = g("encoder.global_cmvn.mean"), g("encoder.global_cmvn.istd")
+        else:  # the HF-path checkpoint keeps CMVN in <mm_audio_encoder>/global_cmvn (loaded by the builder)
+            mean, istd = torch.zeros(a.input_dim), torch.ones(a.input_dim)
+        w = {"mean": _f32(mean, dev), "istd": _f32(istd, dev),
              "c1_w": _bf(g(c + "conv.0.weight").reshape(C, 9), dev), "c1_b": _f32(g(c + "conv.0.bias"), dev),
              # [Cout, Cin, kh, kw] -> [Cout, (kh, kw, Cin)]: each (kh,kw) is a contiguous channel run
              "c2_w": _bf(g(c + "conv.2.weight").permute(0, 2, 3, 1).reshape(C, 9 * C), dev),
@@ -296,7 +303,13 @@ class WhaleAudioEncoder(_HipModule):
         feats = feats.to(device=self._device, dtype=torch.float32).contiguous()
         T = feats.shape[0]
         length = T if length is None else int(length)
-        y1, T1, F1 = ops.audio_conv1(feats, w["mean"], w["istd"], w["c1_w"], w["c1_b"])        # [T1*F1, C]
+        if self.normalized_input:
+            if "mean0" not in w:
+                w["mean0"], w["istd1"] = torch.zeros_like(w["mean"]), torch.ones_like(w["istd"])
+            mean, istd = w["mean0"], w["istd1"]
+        else:
+            mean, istd = w["mean"], w["istd"]
+        y1, T1, F1 = ops.audio_conv1(feats, mean, istd, w["c1_w"], w["c1_b"])                  # [T1*F1, C]
         rows, T2, F2, segrow = self._conv2_rows(T1, F1)
         y2 = ops.gemm(y1, w["c2_w"], bias=w["c2_b"], act="relu", a_rowidx=rows, segrow=segrow, seglen=C)
         y = ops.gemm(y2.view(T2, F2 * C), w["out_w"], bias=w["out_b"])                          # [T2, C]

@@ -1,0 +1,176 @@
+"""vLLM-shaped serving surface (SURVEY §8(b) flavour 2 / §8(f)#1) over the HIP engine.
+
+What the reference's web demo does with vLLM (web_demo/web_ability_demo.py:132-243,340-351):
+
+    llm = LLM(model=path, dtype="float16", tensor_parallel_size=2, limit_mm_per_prompt={...})
+    sampling_params = SamplingParams(temperature=0.01, max_tokens=512, best_of=1, skip_special_tokens=False)
+    out = llm.generate({"prompt_token_ids": ids, "multi_modal_data": {"image": [PIL...], "audio": [Tensor[T,80]...]}},
+                       sampling_params=sampling_params)
+    text = out[0].outputs[0].text
+
+keeps working with `from vita_amd.serving import LLM, SamplingParams`.  The prompt carries ONE
+`image_token_index` (51000) per image and ONE `audio_token_index` (51001) per clip; like the plugin's
+input processor (web_demo/vllm_tools/vllm_file/mixtral.py:194-311) we tile each image with
+dynamic_preprocess (+thumbnail), expand its placeholder to 256 tokens per tile and each audio placeholder to
+`((T-1)//2-1)//2 -> (.-1)//2+1` tokens.  Audio features arrive CMVN-normalised by WhaleFeatureExtractor (the
+vLLM audio tower has no global_cmvn: mixtral.py:1245-1247), so the encoder is run with `normalized=True`.
+temperature <= 0.01 is greedy (the demo's setting); other sampling is not implemented.
+
+Not here (out of scope for this path): vLLM's paged KV cache / continuous batching scheduler — requests
+are served one at a time, as the offline demo does."""
+import json
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from .host.constants import AUDIO_TOKEN_INDEX, IMAGE_TOKEN_INDEX
+from .host.image_processing import dynamic_preprocess
+
+
+@dataclass
+class SamplingParams:
+    temperature: float = 0.01
+    max_tokens: int = 512
+    best_of: int = 1
+    skip_special_tokens: bool = False
+    stop_token_ids: Optional[List[int]] = None
+    top_p: float = 1.0
+    top_k: int = -1
+
+
+@dataclass
+class CompletionOutput:
+    index: int
+    text: str
+    token_ids: List[int]
+    finish_reason: str = "length"
+
+
+@dataclass
+class RequestOutput:
+    request_id: str
+    prompt_token_ids: List[int]
+    outputs: List[CompletionOutput] = field(default_factory=list)
+    finished: bool = True
+    metrics: dict = field(default_factory=dict)
+
+
+def audio_feature_size(n_frames: int) -> int:
+    """mixtral.py:283-287."""
+    down = ((int(n_frames) - 1) // 2 - 1) // 2
+    return (down - 1) // 2 + 1
+
+
+class LLM:
+    def __init__(self, model, dtype=None, tensor_parallel_size=1, trust_remote_code=True, gpu_memory_utilization=None,
+                 disable_custom_all_reduce=True, limit_mm_per_prompt=None, max_new_tokens=1024, device="cuda", **_):
+        from .model.builder import load_pretrained_model
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if tensor_parallel_size != 1 and tensor_parallel_size != world:
+            raise RuntimeError(
+                f"tensor_parallel_size={tensor_parallel_size}: vita_amd runs one process per GPU — launch this program "
+                f"with `python -m torch.distributed.run --nproc-per-node {tensor_parallel_size} ...` (WORLD_SIZE={world})")
+        self.limit_mm = dict(limit_mm_per_prompt or {"image": 256, "audio": 50})
+        kw = {}
+        if world > 1:
+            kw.update(rank=int(os.environ.get("RANK", "0")), world=world)
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        self.tokenizer, self.model, self.image_processor, _ = load_pretrained_model(
+            model, None, os.path.basename(str(model).rstrip("/")), "mixtral-8x7b", device=device,
+            max_new_tokens=max_new_tokens, **kw)
+        with open(os.path.join(model, "config.json")) as f:
+            j = json.load(f)
+        self.image_token_index = int(j.get("image_token_index", 51000))
+        self.audio_token_index = int(j.get("audio_token_index", 51001))
+        self.min_dynamic_patch = int(j.get("min_dynamic_patch", 1))
+        self.max_dynamic_patch = int(j.get("max_dynamic_patch", 12))
+        self.use_thumbnail = bool(j.get("use_thumbnail", True))
+        self._n = 0
+
+    def get_tokenizer(self):
+        return self.tokenizer
+
+    # ---- one request ----------------------------------------------------------------------------
+    def _expand(self, ids, images, audios):
+        """placeholders -> sentinels of the HF-flavour splice: one IMAGE sentinel per TILE, one AUDIO per clip."""
+        n_img, n_aud = ids.count(self.image_token_index), ids.count(self.audio_token_index)
+        if n_img != len(images) or n_aud != len(audios):
+            raise ValueError(f"prompt has {n_img} image / {n_aud} audio placeholders but multi_modal_data holds "
+                             f"{len(images)} / {len(audios)}")                # mixtral.py:244-247,1110-1124
+        if len(images) > self.limit_mm.get("image", 256) or len(audios) > self.limit_mm.get("audio", 50):
+            raise ValueError("limit_mm_per_prompt exceeded")
+        size = self.image_processor.crop_size["height"]
+        tiles, out, ii = [], [], 0
+        for t in ids:
+            if t == self.image_token_index:
+                ts, _ = dynamic_preprocess(images[ii], min_num=self.min_dynamic_patch, max_num=self.max_dynamic_patch,
+                                           image_size=size, use_thumbnail=self.use_thumbnail)
+                tiles += ts
+                out += [IMAGE_TOKEN_INDEX] * len(ts)
+                ii += 1
+            elif t == self.audio_token_index:
+                out.append(AUDIO_TOKEN_INDEX)
+            else:
+                out.append(int(t))
+        return out, tiles
+
+    @torch.no_grad()
+    def _one(self, inp, sp: SamplingParams):
+        if isinstance(inp, str):
+            inp = {"prompt": inp}
+        ids = inp.get("prompt_token_ids")
+        if ids is None:
+            ids = list(self.tokenizer(inp["prompt"]).input_ids)
+        ids = [int(x) for x in (ids.tolist() if hasattr(ids, "tolist") else ids)]
+        mm = inp.get("multi_modal_data") or {}
+        images = mm.get("image", [])
+        images = images if isinstance(images, list) else [images]
+        audios = mm.get("audio", [])
+        audios = audios if isinstance(audios, list) else [audios]
+        if sp.temperature is not None and sp.temperature > 0.011:
+            raise NotImplementedError("vita_amd serves greedy decoding (temperature <= 0.01, the reference demo's setting)")
+        dev = self.model.device
+        sent, tiles = self._expand(ids, images, audios)
+        size = self.image_processor.crop_size["height"]
+        if tiles:
+            pix = self.image_processor.preprocess(tiles, return_tensors="pt")["pixel_values"].to(dev)
+        else:
+            pix = torch.zeros((1, 3, size, size), device=dev)                  # the demo's dummy image
+        enc = self.model.get_audio_encoder()
+        if audios:
+            if len(audios) > 1:
+                T = max(int(a.shape[0]) for a in audios)
+                feats = torch.zeros((len(audios), T, audios[0].shape[1]))
+                for i, a in enumerate(audios):
+                    feats[i, :a.shape[0]] = a.float()
+            else:
+                feats = audios[0].float()[None]
+            lens = torch.tensor([int(a.shape[0]) for a in audios])
+            if len({int(a.shape[0]) for a in audios}) > 1:
+                raise NotImplementedError("clips of different lengths in one request are not batched yet")
+            enc.normalized_input = True      # WhaleFeatureExtractor already applied CMVN
+        else:
+            feats, lens = torch.zeros((1, 400, enc.acfg.input_dim)), torch.tensor([400])
+            enc.normalized_input = False
+        try:
+            out = self.model.generate(torch.tensor([sent], dtype=torch.long, device=dev), images=pix,
+                                      audios={"audios": feats.to(dev), "lengths": lens.to(dev)}, do_sample=False,
+                                      num_beams=1, return_dict_in_generate=True, max_new_tokens=int(sp.max_tokens),
+                                      eos_token_id=list({self.model.generation_config.eos_token_id,
+                                                         *(sp.stop_token_ids or [])}))
+        finally:
+            enc.normalized_input = False
+        gen = out.sequences[0, len(sent):].tolist()
+        eos = {self.model.generation_config.eos_token_id, *(sp.stop_token_ids or [])}
+        reason = "stop" if gen and gen[-1] in eos else "length"
+        text = self.tokenizer.decode(gen, skip_special_tokens=sp.skip_special_tokens)
+        self._n += 1
+        return RequestOutput(request_id=str(self._n - 1), prompt_token_ids=ids,
+                             outputs=[CompletionOutput(0, text, gen, reason)], metrics=dict(self.model.last_timing))
+
+    def generate(self, prompts, sampling_params: SamplingParams = None, use_tqdm=False, **_):
+        sp = sampling_params or SamplingParams()
+        batch = prompts if isinstance(prompts, list) else [prompts]
+        return [self._one(p, sp) for p in batch]
