@@ -194,7 +194,7 @@ def test_rccl_binding_single_rank(dev):
         eng.close()
 
 
-@pytest.mark.parametrize("knob,value", [("fuse_attn_oproj", 1), ("prefill_moe_gemm", 0), ("gemm_order", 1)])
+@pytest.mark.parametrize("knob,value", [("fuse_attn_oproj", 1), ("prefill_moe_gemm", 0), ("prefill_moe_gemm", 2), ("gemm_order", 1)])
 def test_alternative_paths(dev, knob, value):
     """the non-default code paths stay correct: two-kernel attention / O-projection (also the fallback
     for contexts too long to co-schedule), the pre-split skinny MoE GEMM, the XCD-contiguous GEMM order."""

@@ -40,7 +40,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset in 
 //           an expert's ~S/4 rows span three 64-row m-tiles and each re-streams the expert's weights.
 //           One 256-row m-tile holds all rows of an expert up to S ~ 900, so the weights leave HBM once;
 //           row tiles past the group's rows are neither loaded nor multiplied (wave-uniform skip).
-template <bool GLU, int BM, int MINW>
+template <bool GLU, int BM, int MINW, int PF, bool PS>
 __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGemmArgs p) {
     constexpr int THREADS = BM == 64 ? 256 : 512;
     constexpr int WMW = BM == 64 ? 2 : 4;            // waves along M (2 along N in both shapes)
@@ -143,17 +143,28 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
         wptr = Wb + (size_t)(w_valid ? n : 0) * p.ldw + wchunk0 * 8;
     }
 
-    float4 ra[AF4];
-    uint4 rw[WU4];
-    auto load_tile = [&](int kt) {
+    float4 ra0[AF4], ra1[AF4];
+    uint4 rw0[WU4], rw1[WU4];
+    auto load_tile = [&](int kt, float4 (&ra)[AF4], uint4 (&rw)[WU4]) {
         const int k0 = kt * GM_BK;
         const int seg = k0 / p.seglen;
         const int koff = k0 - seg * p.seglen;
         const int srow = a_src + p.segrow[seg];
         if (a_valid_m && srow >= 0 && srow < p.a_rows) {
-            const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)srow * p.lda + koff + achunk0 * 8);
+            if (PS) {   // pre-split planes: AF4/2 chunks of 8 bf16 from each plane, no conversion work
+                const uint4* hp = reinterpret_cast<const uint4*>(p.A_hi + (size_t)srow * p.lda + koff + achunk0 * 8);
+                const uint4* lp = reinterpret_cast<const uint4*>(p.A_lo + (size_t)srow * p.lda + koff + achunk0 * 8);
 #pragma unroll
-            for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
+                for (int i = 0; i < AF4 / 2; ++i) {
+                    const uint4 h = hp[i], l = lp[i];
+                    ra[i] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z), __uint_as_float(h.w));
+                    ra[AF4 / 2 + i] = make_float4(__uint_as_float(l.x), __uint_as_float(l.y), __uint_as_float(l.z), __uint_as_float(l.w));
+                }
+            } else {
+                const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)srow * p.lda + koff + achunk0 * 8);
+#pragma unroll
+                for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < AF4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,21 +178,33 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
             for (int i = 0; i < WU4; ++i) rw[i] = make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const float4 (&ra)[AF4], const uint4 (&rw)[WU4]) {
+        if (PS) {
 #pragma unroll
-        for (int c = 0; c < AF4 / 2; ++c) {
-            const float4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
-            const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-            uint32_t hi[8], lo[8];
+            for (int c = 0; c < AF4 / 2; ++c) {
+                const float4 h = ra[c], l = ra[AF4 / 2 + c];
+                const int off = lds_off(arow, achunk0 + c);
+                *reinterpret_cast<uint4*>(lds_ahi + off) =
+                    make_uint4(__float_as_uint(h.x), __float_as_uint(h.y), __float_as_uint(h.z), __float_as_uint(h.w));
+                *reinterpret_cast<uint4*>(lds_alo + off) =
+                    make_uint4(__float_as_uint(l.x), __float_as_uint(l.y), __float_as_uint(l.z), __float_as_uint(l.w));
+            }
+        } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) split_bf16(v[i], hi[i], lo[i]);
-            const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
-                                        hi[6] | (hi[7] << 16));
-            const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
-                                        lo[6] | (lo[7] << 16));
-            const int off = lds_off(arow, achunk0 + c);
-            *reinterpret_cast<uint4*>(lds_ahi + off) = ph;
-            *reinterpret_cast<uint4*>(lds_alo + off) = pl;
+            for (int c = 0; c < AF4 / 2; ++c) {
+                const float4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
+                const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                uint32_t hi[8], lo[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) split_bf16(v[i], hi[i], lo[i]);
+                const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
+                                            hi[6] | (hi[7] << 16));
+                const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
+                                            lo[6] | (lo[7] << 16));
+                const int off = lds_off(arow, achunk0 + c);
+                *reinterpret_cast<uint4*>(lds_ahi + off) = ph;
+                *reinterpret_cast<uint4*>(lds_alo + off) = pl;
+            }
         }
 #pragma unroll
         for (int c = 0; c < WU4; ++c) *reinterpret_cast<uint4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
@@ -193,13 +216,7 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = p.K / GM_BK;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();  // previous tile's fragment reads are done
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight during the MFMAs below
+    auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + (lane >> 4);
@@ -225,6 +242,28 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
                     }
                 }
             }
+        }
+    };
+
+    // Two K-tiles of operands are kept in flight in registers (sets 0 / 1): a K-tile iteration is
+    // otherwise bounded by one global-load round trip (~1-2 us under load), which is what made every
+    // small-M GEMM of the encoders cost ~2 us per 64 of K regardless of its size.
+    const int nkt = p.K / GM_BK;
+    load_tile(0, ra0, rw0);
+    if (PF == 2 && nkt > 1) load_tile(1, ra1, rw1);
+    for (int kt = 0; kt < nkt; kt += PF) {
+        __syncthreads();  // previous tile's fragment reads are done
+        store_tile(ra0, rw0);
+        __syncthreads();
+        if (kt + PF < nkt) load_tile(kt + PF, ra0, rw0);  // in flight during the MFMAs below (and the next tile)
+        mfma_tile();
+        if (PF == 2) {
+            if (kt + 1 >= nkt) break;
+            __syncthreads();
+            store_tile(ra1, rw1);
+            __syncthreads();
+            if (kt + 3 < nkt) load_tile(kt + 3, ra1, rw1);
+            mfma_tile();
         }
     }
 
@@ -268,22 +307,33 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.K <= 0 || a.K % GM_BK != 0 || a.nseg < 1 || a.nseg > 16 || a.seglen % GM_BK != 0 ||
         a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0)
         return -1;
+    const bool ps = a.A_hi != nullptr;
+    if (ps ? (!a.A_lo || (a.lda % 8) != 0) : (a.A == nullptr)) return -1;
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
     g.order = vh_tuning()->gemm_order;
-    // tall m-tiles for the grouped (MoE) GEMMs: one tile per expert, weights streamed once
-    const bool tall = a.group_off != nullptr && vh_tuning()->gemm_tall != 0;
+    // experiments (vh_tune): 256-row m-tiles for the grouped GEMMs; operand prefetch depth
+    const int tall = a.group_off != nullptr && !ps ? vh_tuning()->gemm_tall : 0;
     const int bm = tall ? 256 : GM_BM;
     g.mt_slots = a.group_off ? (a.M / bm + a.ngroups) : (a.M + bm - 1) / bm;  // grouped: upper bound on m-tiles
-    const int nt_glu = (a.N + 63) / 64, nt = (a.N + GM_BN - 1) / GM_BN;
+    const dim3 grid_glu(((a.N + 63) / 64) * g.mt_slots), grid(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots);
+    // two K-tiles in flight pays for the small plain GEMMs (encoders: -4..-6 %), not for the grouped ones (+3 %)
+    const bool pf2 = vh_tuning()->gemm_prefetch == 2 && a.group_off == nullptr;
+#define VH_LAUNCH(GLU_, BM_, MINW_, PF_, PS_, GRID_, THR_) \
+    hipLaunchKernelGGL((k_gemm<GLU_, BM_, MINW_, PF_, PS_>), GRID_, dim3(THR_), 0, st, g)
     if (a.W_up) {
-        if (tall && vh_tuning()->gemm_tall == 2) hipLaunchKernelGGL((k_gemm<true, 256, 4>), dim3(nt_glu * g.mt_slots), dim3(512), 0, st, g);
-        else if (tall) hipLaunchKernelGGL((k_gemm<true, 256, 1>), dim3(nt_glu * g.mt_slots), dim3(512), 0, st, g);
-        else hipLaunchKernelGGL((k_gemm<true, 64, 1>), dim3(nt_glu * g.mt_slots), dim3(256), 0, st, g);
+        if (tall == 2) VH_LAUNCH(true, 256, 4, 1, false, grid_glu, 512);
+        else if (tall) VH_LAUNCH(true, 256, 1, 1, false, grid_glu, 512);
+        else if (ps) VH_LAUNCH(true, 64, 1, 1, true, grid_glu, 256);
+        else if (pf2) VH_LAUNCH(true, 64, 1, 2, false, grid_glu, 256);
+        else VH_LAUNCH(true, 64, 1, 1, false, grid_glu, 256);
     } else {
-        if (tall && vh_tuning()->gemm_tall == 2) hipLaunchKernelGGL((k_gemm<false, 256, 4>), dim3(nt * g.mt_slots), dim3(512), 0, st, g);
-        else if (tall) hipLaunchKernelGGL((k_gemm<false, 256, 1>), dim3(nt * g.mt_slots), dim3(512), 0, st, g);
-        else hipLaunchKernelGGL((k_gemm<false, 64, 1>), dim3(nt * g.mt_slots), dim3(256), 0, st, g);
+        if (tall == 2) VH_LAUNCH(false, 256, 4, 1, false, grid, 512);
+        else if (tall) VH_LAUNCH(false, 256, 1, 1, false, grid, 512);
+        else if (ps) VH_LAUNCH(false, 64, 1, 1, true, grid, 256);
+        else if (pf2) VH_LAUNCH(false, 64, 1, 2, false, grid, 256);
+        else VH_LAUNCH(false, 64, 1, 1, false, grid, 256);
     }
+#undef VH_LAUNCH
     return 0;
 }
