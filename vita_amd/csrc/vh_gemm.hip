@@ -40,10 +40,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset in 
 //           an expert's ~S/4 rows span three 64-row m-tiles and each re-streams the expert's weights.
 //           One 256-row m-tile holds all rows of an expert up to S ~ 900, so the weights leave HBM once;
 //           row tiles past the group's rows are neither loaded nor multiplied (wave-uniform skip).
+// MINW pins the register-allocation target: hipcc otherwise chases the occupancy the 32 KB of LDS would
+// allow (5 blocks/CU) and parks the prefetched weight registers in SCRATCH to get under ~96 VGPRs, which
+// turns the asynchronous prefetch into a synchronous round trip (seen in the ISA: global_load -> s_waitcnt
+// -> scratch_store right after the loads).
 template <bool GLU, int BM, int MINW, int PF, bool PS>
-__global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGemmArgs p) {
-    constexpr int THREADS = BM == 64 ? 256 : 512;
-    constexpr int WMW = BM == 64 ? 2 : 4;            // waves along M (2 along N in both shapes)
+__global__ __launch_bounds__(BM == 256 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_gemm(const VhGemmArgs p) {
+    constexpr int THREADS = BM == 256 ? 512 : 256;
+    constexpr int WMW = BM == 256 ? 4 : 2;           // waves along M (2 along N in every shape)
     constexpr int MI = BM / WMW / 16;                // 16-row tiles per wave: 2 / 4
     constexpr int AF4 = BM * 16 / THREADS;           // float4 of A per thread per K-tile: 4 / 8
     constexpr int ATPR = 16 / AF4;                   // threads per A row: 4 / 2
@@ -143,60 +148,55 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
         wptr = Wb + (size_t)(w_valid ? n : 0) * p.ldw + wchunk0 * 8;
     }
 
-    float4 ra0[AF4], ra1[AF4];
-    uint4 rw0[WU4], rw1[WU4];
-    auto load_tile = [&](int kt, float4 (&ra)[AF4], uint4 (&rw)[WU4]) {
+    uint4 ra0[AF4], ra1[AF4];     // raw 16-byte pieces of the A row (fp32 x4, or bf16 x8 of a plane)
+    u32x4 rw0[WU4], rw1[WU4];    // native vector type: the HIP uint4 struct kept this array in scratch memory
+    uint32_t keep0 = 0, keep1 = 0;   // all-ones where the logical A row exists (applied when the tile is consumed)
+    auto load_tile = [&](int kt, uint4 (&ra)[AF4], u32x4 (&rw)[WU4], uint32_t& keep) __attribute__((always_inline)) {
         const int k0 = kt * GM_BK;
         const int seg = k0 / p.seglen;
         const int koff = k0 - seg * p.seglen;
         const int srow = a_src + p.segrow[seg];
-        if (a_valid_m && srow >= 0 && srow < p.a_rows) {
-            if (PS) {   // pre-split planes: AF4/2 chunks of 8 bf16 from each plane, no conversion work
-                const uint4* hp = reinterpret_cast<const uint4*>(p.A_hi + (size_t)srow * p.lda + koff + achunk0 * 8);
-                const uint4* lp = reinterpret_cast<const uint4*>(p.A_lo + (size_t)srow * p.lda + koff + achunk0 * 8);
+        // UNCONDITIONAL loads from clamped addresses, masked to zero WHEN CONSUMED where the logical row
+        // does not exist: with the loads under a branch hipcc cannot count them and waits vmcnt(0) before every
+        // use, which drains the NEXT tile's prefetch too (seen in the ISA of the two-tile variant).
+        const bool a_ok = a_valid_m && srow >= 0 && srow < p.a_rows;
+        const size_t a_at = (size_t)(a_ok ? srow : 0) * p.lda + koff + achunk0 * 8;
+        keep = a_ok ? 0xffffffffu : 0u;
+        if (PS) {   // pre-split planes: AF4/2 chunks of 8 bf16 from each plane, no conversion work
+            const uint4* hp = reinterpret_cast<const uint4*>(p.A_hi + a_at);
+            const uint4* lp = reinterpret_cast<const uint4*>(p.A_lo + a_at);
 #pragma unroll
-                for (int i = 0; i < AF4 / 2; ++i) {
-                    const uint4 h = hp[i], l = lp[i];
-                    ra[i] = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z), __uint_as_float(h.w));
-                    ra[AF4 / 2 + i] = make_float4(__uint_as_float(l.x), __uint_as_float(l.y), __uint_as_float(l.z), __uint_as_float(l.w));
-                }
-            } else {
-                const float4* ap = reinterpret_cast<const float4*>(p.A + (size_t)srow * p.lda + koff + achunk0 * 8);
-#pragma unroll
-                for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
+            for (int i = 0; i < AF4 / 2; ++i) {
+                ra[i] = hp[i];
+                ra[AF4 / 2 + i] = lp[i];
             }
         } else {
+            const uint4* ap = reinterpret_cast<const uint4*>(p.A + a_at);
 #pragma unroll
-            for (int i = 0; i < AF4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
         }
-        if (w_valid) {
-            const uint4* wp = reinterpret_cast<const uint4*>(wptr + k0);
+        const u32x4* wp = reinterpret_cast<const u32x4*>(wptr + k0);   // rows past N are clamped; their columns are never stored
 #pragma unroll
-            for (int i = 0; i < WU4; ++i) rw[i] = wp[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < WU4; ++i) rw[i] = make_uint4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < WU4; ++i) rw[i] = wp[i];
     };
-    auto store_tile = [&](const float4 (&ra)[AF4], const uint4 (&rw)[WU4]) {
+    auto store_tile = [&](const uint4 (&ra)[AF4], const u32x4 (&rw)[WU4], const uint32_t keep) __attribute__((always_inline)) {
         if (PS) {
 #pragma unroll
             for (int c = 0; c < AF4 / 2; ++c) {
-                const float4 h = ra[c], l = ra[AF4 / 2 + c];
+                const uint4 h = ra[c], l = ra[AF4 / 2 + c];
                 const int off = lds_off(arow, achunk0 + c);
-                *reinterpret_cast<uint4*>(lds_ahi + off) =
-                    make_uint4(__float_as_uint(h.x), __float_as_uint(h.y), __float_as_uint(h.z), __float_as_uint(h.w));
-                *reinterpret_cast<uint4*>(lds_alo + off) =
-                    make_uint4(__float_as_uint(l.x), __float_as_uint(l.y), __float_as_uint(l.z), __float_as_uint(l.w));
+                *reinterpret_cast<uint4*>(lds_ahi + off) = make_uint4(h.x & keep, h.y & keep, h.z & keep, h.w & keep);
+                *reinterpret_cast<uint4*>(lds_alo + off) = make_uint4(l.x & keep, l.y & keep, l.z & keep, l.w & keep);
             }
         } else {
 #pragma unroll
             for (int c = 0; c < AF4 / 2; ++c) {
-                const float4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
-                const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                const uint4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
+                const uint32_t v[8] = {f0.x & keep, f0.y & keep, f0.z & keep, f0.w & keep,
+                                       f1.x & keep, f1.y & keep, f1.z & keep, f1.w & keep};
                 uint32_t hi[8], lo[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) split_bf16(v[i], hi[i], lo[i]);
+                for (int i = 0; i < 8; ++i) split_bf16(__uint_as_float(v[i]), hi[i], lo[i]);
                 const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
                                             hi[6] | (hi[7] << 16));
                 const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
             }
         }
 #pragma unroll
-        for (int c = 0; c < WU4; ++c) *reinterpret_cast<uint4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
+        for (int c = 0; c < WU4; ++c) *reinterpret_cast<u32x4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
     };
 
     f32x4 acc[MI][4];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mfma_tile = [&]() {
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + (lane >> 4);
@@ -249,20 +249,23 @@ __global__ __launch_bounds__(BM == 64 ? 256 : 512, MINW) void k_gemm(const VhGem
     // otherwise bounded by one global-load round trip (~1-2 us under load), which is what made every
     // small-M GEMM of the encoders cost ~2 us per 64 of K regardless of its size.
     const int nkt = p.K / GM_BK;
-    load_tile(0, ra0, rw0);
-    if (PF == 2 && nkt > 1) load_tile(1, ra1, rw1);
+    // loads are issued UNCONDITIONALLY (the tile index is clamped, the last tile is simply re-read): a
+    // load under `if (kt + PF < nkt)` makes the number of outstanding loads unknown to hipcc, which then
+    // waits vmcnt(0) and drains the younger tile as well
+    load_tile(0, ra0, rw0, keep0);
+    if (PF == 2) load_tile(min(1, nkt - 1), ra1, rw1, keep1);
     for (int kt = 0; kt < nkt; kt += PF) {
         __syncthreads();  // previous tile's fragment reads are done
-        store_tile(ra0, rw0);
+        store_tile(ra0, rw0, keep0);
         __syncthreads();
-        if (kt + PF < nkt) load_tile(kt + PF, ra0, rw0);  // in flight during the MFMAs below (and the next tile)
+        load_tile(min(kt + PF, nkt - 1), ra0, rw0, keep0);  // in flight during the MFMAs below (and the next tile)
         mfma_tile();
         if (PF == 2) {
             if (kt + 1 >= nkt) break;
             __syncthreads();
-            store_tile(ra1, rw1);
+            store_tile(ra1, rw1, keep1);
             __syncthreads();
-            if (kt + 3 < nkt) load_tile(kt + 3, ra1, rw1);
+            load_tile(min(kt + 3, nkt - 1), ra1, rw1, keep1);
             mfma_tile();
         }
     }
@@ -313,26 +316,28 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     VhGemmArgs g = a;
     g.order = vh_tuning()->gemm_order;
     // experiments (vh_tune): 256-row m-tiles for the grouped GEMMs; operand prefetch depth
-    const int tall = a.group_off != nullptr && !ps ? vh_tuning()->gemm_tall : 0;
-    const int bm = tall ? 256 : GM_BM;
+    const int tall = a.group_off != nullptr && !ps ? vh_tuning()->gemm_tall : 0;   // 0: 64, 1/2: 256, 3: 128 rows
+    const int bm = tall == 3 ? 128 : (tall ? 256 : GM_BM);
     g.mt_slots = a.group_off ? (a.M / bm + a.ngroups) : (a.M + bm - 1) / bm;  // grouped: upper bound on m-tiles
     const dim3 grid_glu(((a.N + 63) / 64) * g.mt_slots), grid(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots);
     // two K-tiles in flight pays for the small plain GEMMs (encoders: -4..-6 %), not for the grouped ones (+3 %)
-    const bool pf2 = vh_tuning()->gemm_prefetch == 2 && a.group_off == nullptr;
+    const bool pf2 = vh_tuning()->gemm_prefetch == 3 || (vh_tuning()->gemm_prefetch == 2 && a.group_off == nullptr);
 #define VH_LAUNCH(GLU_, BM_, MINW_, PF_, PS_, GRID_, THR_) \
     hipLaunchKernelGGL((k_gemm<GLU_, BM_, MINW_, PF_, PS_>), GRID_, dim3(THR_), 0, st, g)
     if (a.W_up) {
-        if (tall == 2) VH_LAUNCH(true, 256, 4, 1, false, grid_glu, 512);
-        else if (tall) VH_LAUNCH(true, 256, 1, 1, false, grid_glu, 512);
-        else if (ps) VH_LAUNCH(true, 64, 1, 1, true, grid_glu, 256);
-        else if (pf2) VH_LAUNCH(true, 64, 1, 2, false, grid_glu, 256);
-        else VH_LAUNCH(true, 64, 1, 1, false, grid_glu, 256);
+        if (tall == 3) VH_LAUNCH(true, 128, 3, 1, false, grid_glu, 256);
+        else if (tall == 2) VH_LAUNCH(true, 256, 4, 1, false, grid_glu, 512);
+        else if (tall) VH_LAUNCH(true, 256, 2, 1, false, grid_glu, 512);
+        else if (ps) VH_LAUNCH(true, 64, 4, 1, true, grid_glu, 256);
+        else if (pf2) VH_LAUNCH(true, 64, 3, 2, false, grid_glu, 256);
+        else VH_LAUNCH(true, 64, 4, 1, false, grid_glu, 256);
     } else {
-        if (tall == 2) VH_LAUNCH(false, 256, 4, 1, false, grid, 512);
-        else if (tall) VH_LAUNCH(false, 256, 1, 1, false, grid, 512);
-        else if (ps) VH_LAUNCH(false, 64, 1, 1, true, grid, 256);
-        else if (pf2) VH_LAUNCH(false, 64, 1, 2, false, grid, 256);
-        else VH_LAUNCH(false, 64, 1, 1, false, grid, 256);
+        if (tall == 3) VH_LAUNCH(false, 128, 3, 1, false, grid, 256);
+        else if (tall == 2) VH_LAUNCH(false, 256, 4, 1, false, grid, 512);
+        else if (tall) VH_LAUNCH(false, 256, 2, 1, false, grid, 512);
+        else if (ps) VH_LAUNCH(false, 64, 4, 1, true, grid, 256);
+        else if (pf2) VH_LAUNCH(false, 64, 3, 2, false, grid, 256);
+        else VH_LAUNCH(false, 64, 4, 1, false, grid, 256);
     }
 #undef VH_LAUNCH
     return 0;
