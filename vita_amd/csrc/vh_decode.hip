@@ -98,6 +98,50 @@ __device__ __forceinline__ float scale_by_norm_weight(const float* __restrict__ 
     return ss;
 }
 
+// x = x_in + delta (optionally stored to x_out by block 0), then x <- x * w_norm; returns this thread's
+// share of sum(x^2).  The three activation-side vectors are loaded TOGETHER (one L2 round trip, not three
+// dependent ones: the separate load_x / add_x / scale_by_norm_weight sequence cost ~1 us per kernel).
+template <int NJ>
+__device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, const float* __restrict__ delta,
+                                               const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
+                                               float (&xr)[NJ][8]) {
+    f32x4 xa[NJ][2], da[NJ][2], na[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const int cc = (c * 8 < K) ? c : 0;   // clamped: unconditional loads, masked below
+        xa[j][0] = reinterpret_cast<const f32x4*>(x_in)[cc * 2];
+        xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
+        na[j][0] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2];
+        na[j][1] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + 1];
+        if (delta) {   // block-uniform
+            da[j][0] = reinterpret_cast<const f32x4*>(delta)[cc * 2];
+            da[j][1] = reinterpret_cast<const f32x4*>(delta)[cc * 2 + 1];
+        } else {
+            da[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            da[j][1] = da[j][0];
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const bool ok = c * 8 < K;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 v = xa[j][hh] + da[j][hh];
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (x_out && blockIdx.x == 0 && ok) reinterpret_cast<f32x4*>(x_out)[c * 2 + hh] = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ss = fmaf(v[i], v[i], ss);
+                xr[j][hh * 4 + i] = v[i] * na[j][hh][i];
+            }
+        }
+    }
+    return ss;
+}
+
 // R rows of W (bf16) against the register-resident x, in two phases so the weight loads are in
 // flight BEFORE the (L2-resident) activation loads and prologue math.  rows[r] must be valid
 // pointers (callers clamp out-of-range rows and drop the result).
@@ -140,11 +184,13 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
     gemv_issue<NJ, R>(rows, K, w);
 
     float xr[NJ][8];
-    load_x<NJ>(x_in, K, xr);
-    if (delta) add_x<NJ>(delta, K, xr);
-    if (blockIdx.x == 0 && x_out) store_x<NJ>(x_out, K, xr);
     float vals[R + 1];
-    vals[R] = NORM ? scale_by_norm_weight<NJ>(norm_w, K, xr) : 0.f;
+    if (NORM) {
+        vals[R] = load_add_norm<NJ>(x_in, delta, norm_w, x_out, K, xr);
+    } else {
+        load_x<NJ>(x_in, K, xr);
+        vals[R] = 0.f;
+    }
     float acc[R];
     gemv_fma<NJ, R>(w, xr, acc);
 #pragma unroll
@@ -193,20 +239,18 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     const int k1 = min(pos + 1, k0 + DA_KT);
     const int head = h * G + wid;
 
-    // 1. put the K/V tile loads in flight first (8 float4 each per thread)
-    float4 kreg[8], vreg[8];
+    // 1. put the K/V tile loads in flight first (8 x 16 B each per thread).  Unconditional loads from
+    // clamped rows into NATIVE vector registers: with the loads under a branch and the HIP float4 struct
+    // as the staging type, hipcc parked the K registers in scratch memory and waited after every K/V pair
+    // (8 dependent round trips instead of 16 loads in flight).  Rows that do not exist are zeroed in step 3.
+    f32x4 kreg[8], vreg[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * 256;
         const int row = idx >> 5, c4 = idx & 31;
-        const int key = k0 + row;
-        if (key < k1 && key != pos) {
-            kreg[i] = reinterpret_cast<const float4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
-            vreg[i] = reinterpret_cast<const float4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
-        } else {
-            kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vreg[i] = kreg[i];
-        }
+        const int key = min(k0 + row, max_ctx - 1);
+        kreg[i] = reinterpret_cast<const f32x4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
+        vreg[i] = reinterpret_cast<const f32x4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
     }
 
     // 2. rotate-half RoPE (modeling_mixtral.py:203-241): out = x*cos + rotate_half(x)*sin
@@ -232,18 +276,22 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     }
     __syncthreads();
 
-    // 3. tiles -> LDS (the new token's row comes from LDS, not from the cache)
+    // 3. tiles -> LDS (the new token's row comes from LDS, not from the cache; rows past the context are 0)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * 256;
         const int row = idx >> 5, c4 = idx & 31;
-        float4 kv = kreg[i], vv = vreg[i];
-        if (k0 + row == pos) {
-            kv = reinterpret_cast<const float4*>(kn_s)[c4];
-            vv = reinterpret_cast<const float4*>(vn_s)[c4];
+        const int key = k0 + row;
+        f32x4 kv = kreg[i], vv = vreg[i];
+        if (key == pos) {
+            kv = reinterpret_cast<const f32x4*>(kn_s)[c4];
+            vv = reinterpret_cast<const f32x4*>(vn_s)[c4];
+        } else if (key >= k1) {
+            kv = f32x4{0.f, 0.f, 0.f, 0.f};
+            vv = kv;
         }
-        *reinterpret_cast<float4*>(&Kt[row * DA_KSTR + c4 * 4]) = kv;
-        *reinterpret_cast<float4*>(&Vt[row * 128 + c4 * 4]) = vv;
+        *reinterpret_cast<f32x4*>(&Kt[row * DA_KSTR + c4 * 4]) = kv;
+        *reinterpret_cast<f32x4*>(&Vt[row * 128 + c4 * 4]) = vv;
     }
     __syncthreads();
 
@@ -426,11 +474,8 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
         for (int e = 0; e < 8; ++e) rrows[e] = Wg + (size_t)min(e, E - 1) * K;
         uint4 wr[8][NJ];
         gemv_issue<NJ, 8>(rrows, K, wr);
-        load_x<NJ>(x_in, K, xr);
-        if (delta) add_x<NJ>(delta, K, xr);
-        if (blockIdx.x == 0 && x_out) store_x<NJ>(x_out, K, xr);
         float vals[9];
-        vals[8] = scale_by_norm_weight<NJ>(norm_w, K, xr);
+        vals[8] = load_add_norm<NJ>(x_in, delta, norm_w, x_out, K, xr);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
 #pragma unroll
@@ -582,9 +627,7 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
     const uint16_t* rows[LM_R];
     if (it < n_iter) { rows_of(it, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
     float xr[NJ][8];
-    load_x<NJ>(x_in, K, xr);
-    if (delta) add_x<NJ>(delta, K, xr);
-    const float ss = scale_by_norm_weight<NJ>(norm_w, K, xr);
+    const float ss = load_add_norm<NJ>(x_in, delta, norm_w, nullptr, K, xr);
     float inv = 0.f;
     float best = -INFINITY;
     int besti = 0x7fffffff;
