@@ -96,8 +96,10 @@ int vh_attention(const vh_attn_args* a, void* stream) {
     g.causal = a->causal; g.q_off = a->q_off; g.klen = a->klen; g.chunk = a->chunk; g.left = a->left;
     g.scale = a->scale;
     if (a->P && (!a->bias_u || !a->bias_v)) return fail(VH_E_ARG, "vh_attention: rel-pos needs bias_u/bias_v");
-    if ((a->ldk % 2) || (a->ldv % 2) || (a->hsk % 2) || (a->hsv % 2) || (a->bsk % 2))
-        return fail(VH_E_SHAPE, "vh_attention: K/V strides must be even (8-byte loads)");
+    if ((a->ldk % 4) || (a->ldv % 4) || (a->hsk % 4) || (a->hsv % 4) || (a->bsk % 4) ||
+        (reinterpret_cast<uintptr_t>(a->K) & 15) || (reinterpret_cast<uintptr_t>(a->V) & 15) ||
+        (a->P && ((a->ldp % 4) || (a->hsp % 4) || (reinterpret_cast<uintptr_t>(a->P) & 15))))
+        return fail(VH_E_SHAPE, "vh_attention: K/V/P rows must be 16-byte aligned (strides multiples of 4 floats)");
     return check_launch("vh_attention", vhk_attn(S(stream), g));
 }
 

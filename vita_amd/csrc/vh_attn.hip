@@ -88,22 +88,49 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt0 = 0; kt0 < kloop; kt0 += AT_KT) {
-        // ---- stage K, V (and P) tiles ---------------------------------------------
-        for (int idx = tid; idx < AT_KT * (D / 2); idx += 256) {
-            const int row = idx / (D / 2), c2 = idx % (D / 2);
-            const int key = kt0 + row;
-            float2 kv = make_float2(0.f, 0.f), vv = kv, pv = kv;
-            if (key < p.Sk) {
-                kv = reinterpret_cast<const float2*>(Kb + (size_t)key * p.ldk)[c2];
-                vv = reinterpret_cast<const float2*>(Vb + (size_t)key * p.ldv)[c2];
-                if (REL) pv = reinterpret_cast<const float2*>(Pb + (size_t)key * p.ldp)[c2];
-            }
-            *reinterpret_cast<float2*>(&Kt[row * KSTR + c2 * 2]) = kv;
-            *reinterpret_cast<float2*>(&Vt[row * VSTR + c2 * 2]) = vv;
-            if (REL) *reinterpret_cast<float2*>(&Pt[row * KSTR + c2 * 2]) = pv;
+    // K/V(/P) tiles are prefetched one tile ahead into NATIVE vector registers with unconditional, clamped
+    // 16-byte loads (rows past Sk are zeroed when the tile is written to LDS): the loads of tile t+1 are in
+    // flight during the MFMAs of tile t.  (The first version loaded 8 bytes at a time under a branch inside
+    // the staging loop: every tile began with a synchronous global round trip.)
+    constexpr int F4 = AT_KT * (D / 4) / 256;   // 16-byte pieces per thread per operand: 2 (D=64) / 4 (D=128)
+    f32x4 kr[F4], vr[F4], pr[REL ? F4 : 1];
+    auto load_tile = [&](int kt0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (D / 4), c4 = idx % (D / 4);
+            const int key = min(kt0 + row, p.Sk - 1);
+            kr[i] = reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk)[c4];
+            vr[i] = reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv)[c4];
+            if (REL) pr[i] = reinterpret_cast<const f32x4*>(Pb + (size_t)key * p.ldp)[c4];
         }
+    };
+    auto store_tile = [&](int kt0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (D / 4), c4 = idx % (D / 4);
+            const bool ok = kt0 + row < p.Sk;
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 kv = ok ? kr[i] : z, vv = ok ? vr[i] : z;
+            float* kd = &Kt[row * KSTR + c4 * 4];          // KSTR = D + 2: 8-byte aligned rows
+            *reinterpret_cast<float2*>(kd) = make_float2(kv[0], kv[1]);
+            *reinterpret_cast<float2*>(kd + 2) = make_float2(kv[2], kv[3]);
+            *reinterpret_cast<f32x4*>(&Vt[row * VSTR + c4 * 4]) = vv;   // VSTR = D + 16: 16-byte aligned rows
+            if (REL) {
+                const f32x4 pv = ok ? pr[i] : z;
+                float* pd = &Pt[row * KSTR + c4 * 4];
+                *reinterpret_cast<float2*>(pd) = make_float2(pv[0], pv[1]);
+                *reinterpret_cast<float2*>(pd + 2) = make_float2(pv[2], pv[3]);
+            }
+        }
+    };
+
+    if (kloop > 0) load_tile(0);
+    for (int kt0 = 0; kt0 < kloop; kt0 += AT_KT) {
+        store_tile(kt0);
         __syncthreads();
+        load_tile(min(kt0 + AT_KT, max(kloop - 1, 0)));   // always issued (clamped): counted by the compiler
 
         // ---- S = Q K^T (+ Qv P^T) for two 16-key sub-tiles ---------------------------
         f32x4 sacc[2];
