@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device is the 1-GPU functional check of the N>1 path")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0 (invalid as a measurement)")
+    ap.add_argument("--emulate-tp", type=int, default=0,
+                    help="debug: run ONE rank's 1/N shard on one GPU with the collective skipped — per-rank compute "
+                         "time of TP=N without communication (tokens are meaningless, result marked invalid)")
+    ap.add_argument("--text-tokens", type=int, default=32, help="debug: length of the user text (default 32 = configs[2])")
     ap.add_argument("--tune", default="", help="debug: kernel-variant knobs key=val[,key=val] (vh_tune)")
     args = ap.parse_args()
 
@@ -145,10 +149,10 @@ def main():
 
     # ---- model: random-init weights of the released geometry --------------------------------------
     t0 = time.time()
-    packed = synth_mixtral_device(cfg, dev, seed=0, rank=rank, world=world)
+    packed = synth_mixtral_device(cfg, dev, seed=0, rank=rank, world=args.emulate_tp or world)
     sd_enc = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
     model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=K + Wm + 8,
-                                   max_prefill=1024, rank=rank, world=world, keep_scores=False)
+                                   max_prefill=max(1024, args.text_tokens + 1024), rank=rank, world=world, keep_scores=False)
     model.get_vision_tower().load_model()
     eng = model.engine
     collective = "none"
@@ -182,7 +186,7 @@ def main():
     n_aud_tok = audio_token_count(feats.shape[0])
     rng = np.random.default_rng(1)
     sys_ids = rng.integers(3, 51000, size=139).tolist()              # stand-in for the ~140-token system prompt
-    txt_ids = rng.integers(3, 51000, size=32).tolist()
+    txt_ids = rng.integers(3, 51000, size=args.text_tokens).tolist()
     ids = [t.bos_token_id] + sys_ids + [IMAGE_TOKEN_INDEX] + txt_ids + [AUDIO_TOKEN_INDEX]
     input_ids = torch.tensor([ids], dtype=torch.long, device=dev)
     audios = {"audios": torch.from_numpy(feats)[None].to(dev), "lengths": torch.tensor([feats.shape[0]], device=dev)}
@@ -273,6 +277,10 @@ def main():
             out["INVALID_debug_layers"] = args.layers
         if args.tune:
             out["tune"] = args.tune
+        if args.emulate_tp:
+            out["INVALID_emulated_tp_rank_compute_only"] = args.emulate_tp
+        if args.text_tokens != 32:
+            out["INVALID_debug_text_tokens"] = args.text_tokens
         if args.one_device or args.backend != "nccl":
             out["INVALID_debug_backend"] = f"{args.backend}, one_device={args.one_device}"
         if not args.no_cpu_baseline:
