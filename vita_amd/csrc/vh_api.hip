@@ -46,9 +46,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
     if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
     if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
-    if (!strcmp(key, "gemm_tall")) { g_tuning.gemm_tall = value; return VH_OK; }
     if (!strcmp(key, "gemm_prefetch")) { g_tuning.gemm_prefetch = value; return VH_OK; }
-    if (!strcmp(key, "gemm_order")) { g_tuning.gemm_order = value; return VH_OK; }
     if (!strcmp(key, "ps_ablate")) { g_tuning.ps_ablate = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
@@ -57,7 +55,7 @@ int vh_tune(const char* key, int value) {
 int vh_gemm(const vh_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->C) return fail(VH_E_ARG, "vh_gemm: null pointer");
     VhGemmArgs g;
-    g.A = a->A; g.lda = a->lda; g.a_rows = a->a_rows; g.a_rowidx = a->a_rowidx; g.A_hi = nullptr; g.A_lo = nullptr;
+    g.A = a->A; g.lda = a->lda; g.a_rows = a->a_rows; g.a_rowidx = a->a_rowidx;
     g.nseg = a->nseg; g.seglen = a->seglen;
     for (int i = 0; i < 16; ++i) g.segrow[i] = a->segrow[i];
     g.W = a->W; g.W_up = a->W_up; g.ldw = a->ldw; g.w_group_stride = a->w_group_stride;
@@ -453,24 +451,17 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
             d.C = m->py; d.ldc = H; d.c_rowidx = m->psslot; d.M = 2 * Sn; d.N = H; d.K = I;
             VH_TRY(vhk_gemm_ps(st, d), "down gemm");
         } else {
-            // general kernel; mode 2 feeds it activations split once into bf16 hi/lo planes, which removes
-            // the per-block split (the VALU work rivalled the MFMA work: every n-tile block re-split its A tile)
-            const bool ps = vh_tuning()->prefill_moe_gemm == 2;
-            if (ps) VH_TRY(vhk_split_planes(st, m->pxn, H, m->pxn_hi, m->pxn_lo, H, Sn, H), "split planes");
             {
                 VhGemmArgs g{};
                 g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.a_rowidx = m->pstok; g.nseg = 1; g.seglen = H;
-                if (ps) { g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; }
                 g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
                 g.group_off = m->pgoff; g.ngroups = E;
                 g.C = m->ph; g.ldc = I; g.M = 2 * Sn; g.N = I; g.K = H;
                 VH_TRY(vhk_gemm(st, g), "gate/up gemm");
             }
-            if (ps) VH_TRY(vhk_split_planes(st, m->ph, I, m->ph_hi, m->ph_lo, I, 2 * Sn, I), "split planes");
             {
                 VhGemmArgs g{};
                 g.A = m->ph; g.lda = I; g.a_rows = 2 * Sn; g.nseg = 1; g.seglen = I;
-                if (ps) { g.A_hi = m->ph_hi; g.A_lo = m->ph_lo; }
                 g.W = w.w2; g.ldw = I; g.w_group_stride = (long)H * I;
                 g.group_off = m->pgoff; g.ngroups = E;
                 g.C = m->py; g.ldc = H; g.c_rowidx = m->psslot; g.M = 2 * Sn; g.N = H; g.K = I;

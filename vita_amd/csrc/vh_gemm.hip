@@ -12,12 +12,12 @@
 // wave tile 32 x 64 = 2x4 MFMA tiles (8 accumulators).  LDS rows are 128 B (64 bf16) with
 // the 16-byte chunk index XOR-swizzled by (row>>1)&7 so that every ds_read_b128 lane group
 // (rows {0-3,12-15} at chunk c and rows {4-11} at chunk c^1) hits 16 distinct 16-B slots.
-// Global->LDS is register staged and issued one K-tile ahead of the MFMAs.
+// Global->LDS is register staged and issued one K-tile ahead of the MFMAs (two for the plain GEMMs).
 //
 // A addressing is generalised so convolutions and the MoE gather need no im2col copy:
 //   source row(m, k) = a_rowidx[m] (or m) + segrow[k / seglen],  column = k % seglen.
 // Grouped mode (top-2 MoE): rows are pre-sorted by expert, group_off[e..e+1] bounds expert
-// e's rows and W advances by w_group_stride per expert; blockIdx.y enumerates (expert,
+// e's rows and W advances by w_group_stride per expert; the 1-D grid enumerates (expert,
 // m-tile) pairs on device so no host sync is needed to size the launch.
 #include "vh_common.h"
 #include "vh_kernels.h"
@@ -34,26 +34,22 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset in 
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// BM = 64 : 256 threads, waves 2 (M) x 2 (N) — the general case (encoders, QKV / O projections).
-// BM = 256: 512 threads, waves 4 (M) x 2 (N) — the top-2 MoE grouped GEMMs.  rocprof PMC showed the
-//           BM = 64 kernel fabric-bound there: FETCH_SIZE = 2.76x the weight bytes at 5.9 TB/s, because
-//           an expert's ~S/4 rows span three 64-row m-tiles and each re-streams the expert's weights.
-//           One 256-row m-tile holds all rows of an expert up to S ~ 900, so the weights leave HBM once;
-//           row tiles past the group's rows are neither loaded nor multiplied (wave-uniform skip).
+// 256 threads, waves 2 (M) x 2 (N), block tile 64 x 128 (GLU: 64 gate + 64 up weight rows -> 64 outputs).
+// Tile shapes that trade occupancy for size were all measured slower on this structure (DESIGN.md §6.2:
+// 128- and 256-row m-tiles, pre-split operand planes, XCD-contiguous block orders) and were removed again.
 // MINW pins the register-allocation target: hipcc otherwise chases the occupancy the 32 KB of LDS would
-// allow (5 blocks/CU) and parks the prefetched weight registers in SCRATCH to get under ~96 VGPRs, which
-// turns the asynchronous prefetch into a synchronous round trip (seen in the ISA: global_load -> s_waitcnt
-// -> scratch_store right after the loads).
-template <bool GLU, int BM, int MINW, int PF, bool PS>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+// allow (5 blocks/CU) and parks prefetched weight registers in SCRATCH to get under ~96 VGPRs, which turns
+// the asynchronous prefetch into a synchronous round trip.
+template <bool GLU, int PF, int MINW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_gemm(const VhGemmArgs p) {
-    constexpr int THREADS = BM == 256 ? 512 : 256;
-    constexpr int WMW = BM == 256 ? 4 : 2;           // waves along M (2 along N in every shape)
-    constexpr int MI = BM / WMW / 16;                // 16-row tiles per wave: 2 / 4
-    constexpr int AF4 = BM * 16 / THREADS;           // float4 of A per thread per K-tile: 4 / 8
-    constexpr int ATPR = 16 / AF4;                   // threads per A row: 4 / 2
-    constexpr int WU4 = GM_BN * 8 / THREADS;         // uint4 of W per thread per K-tile: 4 / 2
-    constexpr int WTPR = 8 / WU4;                    // threads per W row: 2 / 4
+    constexpr int BM = GM_BM;
+    constexpr int WMW = 2;                           // waves along M (2 along N)
+    constexpr int MI = BM / WMW / 16;                // 16-row tiles per wave
+    constexpr int AF4 = BM * 16 / 256;               // 16-byte pieces of A per thread per K-tile (4)
+    constexpr int ATPR = 16 / AF4;                   // threads per A row (4)
+    constexpr int WU4 = GM_BN * 8 / 256;             // 16-byte pieces of W per thread per K-tile (4)
+    constexpr int WTPR = 8 / WU4;                    // threads per W row (2)
     __shared__ __attribute__((aligned(16))) unsigned char lds_ahi[BM * 128];
     __shared__ __attribute__((aligned(16))) unsigned char lds_alo[BM * 128];
     __shared__ __attribute__((aligned(16))) unsigned char lds_w[GM_BN * 128];
@@ -62,68 +58,31 @@ void k_gemm(const VhGemmArgs p) {
     const int wm = wid % WMW, wn = wid / WMW;
     constexpr int NT = GLU ? 64 : 128;  // output columns per block
 
-    // ---- which (n-tile, group, m-tile) is this block? -------------------------------
-    // 1-D grid.  order 0 (default): n-tiles fastest — blocks that run together share the activation
-    // tile, which stays L2-resident.  order 1: hardware block b runs on XCD b % 8, remap b -> logical l
-    // so each XCD owns a CONTIGUOUS range of l (bijective for any grid size) with the m-tiles of one
-    // weight tile adjacent.  Measured on the S=552 MoE gate|up GEMM (BM = 64): order 0 877-900 us at
-    // FETCH 2.76x W, order 1 985-1030 us at FETCH 3.5x W (the activation tiles stop hitting L2), so 0
-    // is the default.
+    // ---- which (n-tile, group, m-tile) is this block?  1-D grid, n-tiles fastest: blocks that run
+    // together share the activation tile, which stays L2-resident ------------------------------------
     const int mt = p.mt_slots;
-    const int ntl = gridDim.x / mt;                  // n-tiles
-    int n_tile, slot = 0, l = blockIdx.x;
-    if (p.order != 0) {
-        const int nwg = gridDim.x, b = blockIdx.x;
-        const int xcd = b & 7, idx = b >> 3, q = nwg >> 3, r = nwg & 7;
-        l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int ntl = gridDim.x / mt;
+    const int slot = blockIdx.x / ntl, n_tile = blockIdx.x - slot * ntl;
     int m_begin, m_end;
     const uint16_t* Wb = p.W;
     const uint16_t* Wu = p.W_up;
-    if (p.group_off && p.order == 2) {
-        // group-major, then n-tile, the group's m-tiles fastest: with the XCD-contiguous remap one XCD
-        // works through (mostly) one expert, so its few activation tiles stay in that XCD's L2 AND the
-        // m-tiles sharing a weight tile run back to back on it — the weight leaves HBM once.
-        int e = 0, nt = 0;
+    if (p.group_off) {
+        int tile = slot, e = 0;
         for (; e < p.ngroups; ++e) {
             const int cnt = p.group_off[e + 1] - p.group_off[e];
-            nt = (cnt + BM - 1) / BM;
-            if (l < nt * ntl) break;
-            l -= nt * ntl;
+            const int nt = (cnt + BM - 1) / BM;
+            if (tile < nt) break;
+            tile -= nt;
         }
         if (e == p.ngroups) return;
-        n_tile = l / nt;
-        const int tile = l - n_tile * nt;
         m_begin = p.group_off[e] + tile * BM;
         m_end = p.group_off[e + 1];
         Wb += (size_t)e * p.w_group_stride;
         if (GLU) Wu += (size_t)e * p.w_group_stride;
     } else {
-        if (p.order == 0) {
-            slot = l / ntl;
-            n_tile = l - slot * ntl;
-        } else {
-            n_tile = l / mt;
-            slot = l - n_tile * mt;
-        }
-        if (p.group_off) {
-            int tile = slot, e = 0;
-            for (; e < p.ngroups; ++e) {
-                const int cnt = p.group_off[e + 1] - p.group_off[e];
-                const int nt = (cnt + BM - 1) / BM;
-                if (tile < nt) break;
-                tile -= nt;
-            }
-            if (e == p.ngroups) return;
-            m_begin = p.group_off[e] + tile * BM;
-            m_end = p.group_off[e + 1];
-            Wb += (size_t)e * p.w_group_stride;
-            if (GLU) Wu += (size_t)e * p.w_group_stride;
-        } else {
-            m_begin = slot * BM;
-            m_end = p.M;
-            if (m_begin >= m_end) return;
-        }
+        m_begin = slot * BM;
+        m_end = p.M;
+        if (m_begin >= m_end) return;
     }
     const int n_begin = n_tile * NT;
     const int rows_here = min(m_end - m_begin, BM);
@@ -148,7 +107,7 @@ void k_gemm(const VhGemmArgs p) {
         wptr = Wb + (size_t)(w_valid ? n : 0) * p.ldw + wchunk0 * 8;
     }
 
-    uint4 ra0[AF4], ra1[AF4];     // raw 16-byte pieces of the A row (fp32 x4, or bf16 x8 of a plane)
+    uint4 ra0[AF4], ra1[AF4];     // raw 16-byte pieces of the A row (fp32 x4)
     u32x4 rw0[WU4], rw1[WU4];    // native vector type: the HIP uint4 struct kept this array in scratch memory
     uint32_t keep0 = 0, keep1 = 0;   // all-ones where the logical A row exists (applied when the tile is consumed)
     auto load_tile = [&](int kt, uint4 (&ra)[AF4], u32x4 (&rw)[WU4], uint32_t& keep) __attribute__((always_inline)) {
@@ -162,49 +121,29 @@ void k_gemm(const VhGemmArgs p) {
         const bool a_ok = a_valid_m && srow >= 0 && srow < p.a_rows;
         const size_t a_at = (size_t)(a_ok ? srow : 0) * p.lda + koff + achunk0 * 8;
         keep = a_ok ? 0xffffffffu : 0u;
-        if (PS) {   // pre-split planes: AF4/2 chunks of 8 bf16 from each plane, no conversion work
-            const uint4* hp = reinterpret_cast<const uint4*>(p.A_hi + a_at);
-            const uint4* lp = reinterpret_cast<const uint4*>(p.A_lo + a_at);
+        const uint4* ap = reinterpret_cast<const uint4*>(p.A + a_at);
 #pragma unroll
-            for (int i = 0; i < AF4 / 2; ++i) {
-                ra[i] = hp[i];
-                ra[AF4 / 2 + i] = lp[i];
-            }
-        } else {
-            const uint4* ap = reinterpret_cast<const uint4*>(p.A + a_at);
-#pragma unroll
-            for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
-        }
+        for (int i = 0; i < AF4; ++i) ra[i] = ap[i];
         const u32x4* wp = reinterpret_cast<const u32x4*>(wptr + k0);   // rows past N are clamped; their columns are never stored
 #pragma unroll
         for (int i = 0; i < WU4; ++i) rw[i] = wp[i];
     };
     auto store_tile = [&](const uint4 (&ra)[AF4], const u32x4 (&rw)[WU4], const uint32_t keep) __attribute__((always_inline)) {
-        if (PS) {
 #pragma unroll
-            for (int c = 0; c < AF4 / 2; ++c) {
-                const uint4 h = ra[c], l = ra[AF4 / 2 + c];
-                const int off = lds_off(arow, achunk0 + c);
-                *reinterpret_cast<uint4*>(lds_ahi + off) = make_uint4(h.x & keep, h.y & keep, h.z & keep, h.w & keep);
-                *reinterpret_cast<uint4*>(lds_alo + off) = make_uint4(l.x & keep, l.y & keep, l.z & keep, l.w & keep);
-            }
-        } else {
+        for (int c = 0; c < AF4 / 2; ++c) {
+            const uint4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
+            const uint32_t v[8] = {f0.x & keep, f0.y & keep, f0.z & keep, f0.w & keep,
+                                   f1.x & keep, f1.y & keep, f1.z & keep, f1.w & keep};
+            uint32_t hi[8], lo[8];
 #pragma unroll
-            for (int c = 0; c < AF4 / 2; ++c) {
-                const uint4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
-                const uint32_t v[8] = {f0.x & keep, f0.y & keep, f0.z & keep, f0.w & keep,
-                                       f1.x & keep, f1.y & keep, f1.z & keep, f1.w & keep};
-                uint32_t hi[8], lo[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) split_bf16(__uint_as_float(v[i]), hi[i], lo[i]);
-                const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
-                                            hi[6] | (hi[7] << 16));
-                const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
-                                            lo[6] | (lo[7] << 16));
-                const int off = lds_off(arow, achunk0 + c);
-                *reinterpret_cast<uint4*>(lds_ahi + off) = ph;
-                *reinterpret_cast<uint4*>(lds_alo + off) = pl;
-            }
+            for (int i = 0; i < 8; ++i) split_bf16(__uint_as_float(v[i]), hi[i], lo[i]);
+            const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
+                                        hi[6] | (hi[7] << 16));
+            const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
+                                        lo[6] | (lo[7] << 16));
+            const int off = lds_off(arow, achunk0 + c);
+            *reinterpret_cast<uint4*>(lds_ahi + off) = ph;
+            *reinterpret_cast<uint4*>(lds_alo + off) = pl;
         }
 #pragma unroll
         for (int c = 0; c < WU4; ++c) *reinterpret_cast<u32x4*>(lds_w + lds_off(wrow, wchunk0 + c)) = rw[c];
@@ -308,37 +247,21 @@ void k_gemm(const VhGemmArgs p) {
 
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.K <= 0 || a.K % GM_BK != 0 || a.nseg < 1 || a.nseg > 16 || a.seglen % GM_BK != 0 ||
-        a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0)
+        a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0 || a.A == nullptr)
         return -1;
-    const bool ps = a.A_hi != nullptr;
-    if (ps ? (!a.A_lo || (a.lda % 8) != 0) : (a.A == nullptr)) return -1;
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
-    g.order = vh_tuning()->gemm_order;
-    // experiments (vh_tune): 256-row m-tiles for the grouped GEMMs; operand prefetch depth
-    const int tall = a.group_off != nullptr && !ps ? vh_tuning()->gemm_tall : 0;   // 0: 64, 1/2: 256, 3: 128 rows
-    const int bm = tall == 3 ? 128 : (tall ? 256 : GM_BM);
-    g.mt_slots = a.group_off ? (a.M / bm + a.ngroups) : (a.M + bm - 1) / bm;  // grouped: upper bound on m-tiles
+    g.mt_slots = a.group_off ? (a.M / GM_BM + a.ngroups) : (a.M + GM_BM - 1) / GM_BM;  // grouped: upper bound
     const dim3 grid_glu(((a.N + 63) / 64) * g.mt_slots), grid(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots);
-    // two K-tiles in flight pays for the small plain GEMMs (encoders: -4..-6 %), not for the grouped ones (+3 %)
-    const bool pf2 = vh_tuning()->gemm_prefetch == 3 || (vh_tuning()->gemm_prefetch == 2 && a.group_off == nullptr);
-#define VH_LAUNCH(GLU_, BM_, MINW_, PF_, PS_, GRID_, THR_) \
-    hipLaunchKernelGGL((k_gemm<GLU_, BM_, MINW_, PF_, PS_>), GRID_, dim3(THR_), 0, st, g)
+    // two K-tiles in flight pays for the small plain GEMMs (encoders: -5..-9 %), not for the grouped ones (+-0)
+    const int pf = vh_tuning()->gemm_prefetch;
+    const bool pf2 = pf == 3 || (pf == 2 && a.group_off == nullptr);
     if (a.W_up) {
-        if (tall == 3) VH_LAUNCH(true, 128, 3, 1, false, grid_glu, 256);
-        else if (tall == 2) VH_LAUNCH(true, 256, 4, 1, false, grid_glu, 512);
-        else if (tall) VH_LAUNCH(true, 256, 2, 1, false, grid_glu, 512);
-        else if (ps) VH_LAUNCH(true, 64, 4, 1, true, grid_glu, 256);
-        else if (pf2) VH_LAUNCH(true, 64, 3, 2, false, grid_glu, 256);
-        else VH_LAUNCH(true, 64, 4, 1, false, grid_glu, 256);
+        if (pf2) hipLaunchKernelGGL((k_gemm<true, 2, 3>), grid_glu, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<true, 1, 4>), grid_glu, dim3(256), 0, st, g);
     } else {
-        if (tall == 3) VH_LAUNCH(false, 128, 3, 1, false, grid, 256);
-        else if (tall == 2) VH_LAUNCH(false, 256, 4, 1, false, grid, 512);
-        else if (tall) VH_LAUNCH(false, 256, 2, 1, false, grid, 512);
-        else if (ps) VH_LAUNCH(false, 64, 4, 1, true, grid, 256);
-        else if (pf2) VH_LAUNCH(false, 64, 3, 2, false, grid, 256);
-        else VH_LAUNCH(false, 64, 4, 1, false, grid, 256);
+        if (pf2) hipLaunchKernelGGL((k_gemm<false, 2, 3>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_gemm<false, 1, 4>), grid, dim3(256), 0, st, g);
     }
-#undef VH_LAUNCH
     return 0;
 }

@@ -9,12 +9,10 @@
 struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
-    int prefill_moe_gemm = 1; // MoE prefill GEMMs: 1 = general kernel on fp32 A (fastest), 2 = general kernel on pre-split planes (+20 %), 0 = skinny glds kernel (vh_gemm_ps)
+    int prefill_moe_gemm = 1; // MoE prefill GEMMs: 1 = general kernel (fastest), 0 = pre-split skinny glds kernel (vh_gemm_ps)
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
     int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
-    int gemm_tall = 0;        // grouped GEMMs: 256-row m-tiles (0 = 64-row tiles everywhere)
-    int gemm_prefetch = 2;    // general GEMM: K-tiles of operands in flight in registers (1 or 2)
-    int gemm_order = 0;       // general GEMM block order: 0 = n-tiles fastest, 1 = XCD-contiguous m-fastest
+    int gemm_prefetch = 2;    // general GEMM: 1 = one K-tile in flight, 2 = two for plain GEMMs (default), 3 = two everywhere
     int ps_ablate = 0;        // timing experiments on vh_gemm_ps (wrong results when non-zero)
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
 };
@@ -46,7 +44,6 @@ int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int
 //   A fp32, W bf16 [N][K] (torch Linear layout), C fp32.  K % 64 == 0.
 struct VhGemmArgs {
     const float* A; long lda; int a_rows;     // a_rows: source rows outside [0,a_rows) read as zero
-    const uint16_t* A_hi; const uint16_t* A_lo; // nullable: A given as pre-split bf16 planes [rows][lda] (then A is unused)
     const int* a_rowidx;                      // nullable: source row of logical row m (else m)
     int nseg, seglen; int segrow[16];         // K = nseg*seglen; segment s reads source row + segrow[s]
     const uint16_t* W; const uint16_t* W_up;  // W_up != null => GLU: out = silu(A W^T) * (A W_up^T)
@@ -56,7 +53,6 @@ struct VhGemmArgs {
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
     int mt_slots;                             // set by the launcher: m-tile slots per n-tile
-    int order;                                // set by the launcher: block -> tile order (vh_tune gemm_order)
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
 
