@@ -178,7 +178,7 @@ class VITAMixtralForCausalLM(_HipModule):
     def generate(self, input_ids=None, images=None, audios=None, do_sample=False, temperature=None, top_p=None,
                  num_beams=1, output_scores=False, return_dict_in_generate=False, max_new_tokens=None,
                  use_cache=True, stopping_criteria=None, inputs_embeds=None, attention_mask=None,
-                 eos_token_id=None, **kwargs):
+                 eos_token_id=None, streamer=None, **kwargs):
         if do_sample or num_beams != 1:
             raise NotImplementedError("vita_amd implements greedy decoding (do_sample=False, num_beams=1)")
         max_new = int(max_new_tokens or self.generation_config.max_new_tokens or 20)
@@ -207,6 +207,7 @@ class VITAMixtralForCausalLM(_HipModule):
             # so stopping is decided exactly as a token-by-token loop would
             torch.cuda.current_stream().synchronize()
             new = eng.tokens[n_checked:eng.n_gen].tolist()
+            n_before = len(generated)
             for tok in new:
                 generated.append(tok)
                 n_checked += 1
@@ -214,6 +215,11 @@ class VITAMixtralForCausalLM(_HipModule):
                 if tok in eos_set or len(generated) >= max_new or any(c(seq, None) for c in crit):
                     done = True
                     break
+            # streaming hook (duplex serving): receives the tokens accepted in this window, returns False to
+            # interrupt the generation (web_interactive_demo.py:340-352 breaks out of its stream the same way)
+            if streamer is not None and len(generated) > n_before:
+                if streamer(generated[n_before:]) is False:
+                    done = True
             if not done:
                 eng.decode(min(self.lookahead, max_new - eng.n_gen))
         ev[2].record()

@@ -117,7 +117,7 @@ class LLM:
         return out, tiles
 
     @torch.no_grad()
-    def _one(self, inp, sp: SamplingParams):
+    def _one(self, inp, sp: SamplingParams, streamer=None):
         if isinstance(inp, str):
             inp = {"prompt": inp}
         ids = inp.get("prompt_token_ids")
@@ -159,7 +159,7 @@ class LLM:
                                       audios={"audios": feats.to(dev), "lengths": lens.to(dev)}, do_sample=False,
                                       num_beams=1, return_dict_in_generate=True, max_new_tokens=int(sp.max_tokens),
                                       eos_token_id=list({self.model.generation_config.eos_token_id,
-                                                         *(sp.stop_token_ids or [])}))
+                                                         *(sp.stop_token_ids or [])}), streamer=streamer)
         finally:
             enc.normalized_input = False
         gen = out.sequences[0, len(sent):].tolist()
@@ -169,6 +169,49 @@ class LLM:
         self._n += 1
         return RequestOutput(request_id=str(self._n - 1), prompt_token_ids=ids,
                              outputs=[CompletionOutput(0, text, gen, reason)], metrics=dict(self.model.last_timing))
+
+    def generate_stream(self, inputs, sampling_params: SamplingParams = None, request_id=None, should_stop=None):
+        """Generator of RequestOutput with the CUMULATIVE text after every decode window — the shape of
+        AsyncLLMEngine.generate's async iterator as web_interactive_demo.py:315-328 consumes it.  `should_stop()`
+        is polled between windows; returning True interrupts the request (the duplex monitor hand-off)."""
+        import queue
+        import threading
+        sp = sampling_params or SamplingParams()
+        q = queue.Queue()
+        state = {"toks": []}
+
+        def streamer(new):
+            state["toks"] += list(new)
+            q.put(list(state["toks"]))
+            return not (should_stop is not None and should_stop())
+
+        result = {}
+
+        def run():
+            try:
+                result["out"] = self._one(inputs, sp, streamer=streamer)
+            except BaseException as e:  # surfaced to the consumer
+                result["err"] = e
+            q.put(None)
+
+        old_la = self.model.lookahead
+        self.model.lookahead = 2                       # short windows: the interrupt is seen within 2 tokens
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                yield RequestOutput(request_id=str(request_id), prompt_token_ids=[], finished=False,
+                                    outputs=[CompletionOutput(0, self.tokenizer.decode(
+                                        item, skip_special_tokens=sp.skip_special_tokens), item, "")])
+        finally:
+            th.join()
+            self.model.lookahead = old_la
+        if "err" in result:
+            raise result["err"]
+        yield result["out"]
 
     def generate(self, prompts, sampling_params: SamplingParams = None, use_tqdm=False, **_):
         sp = sampling_params or SamplingParams()
