@@ -19,8 +19,8 @@
 // c = t + 256*j of every row (a wave reads 1 KiB contiguous per load instruction),
 // keeps its slice of the fp32 activation vector in registers and puts all R*NJ weight
 // loads in flight before anything else (deep vmcnt, no LDS round trip — guide §5 "GEMV /
-// M<=16 decode weights"); persistent variants keep the NEXT row group's loads in flight
-// while the current group is reduced.  Output rows are reduced wave->LDS->thread, no
+// M<=16 decode weights"); the persistent kernels (gate|up, LM head) loop over row groups and rely on
+// the co-resident blocks of a CU to overlap one block's reduction with another's loads.  Output rows are reduced wave->LDS->thread, no
 // atomics, so results are deterministic.  Residual adds are deferred into the consumer's
 // prologue ("delta" buffers) so that under tensor parallelism the same kernels run
 // unchanged with an all-reduce on the delta buffer between them.
@@ -51,55 +51,9 @@ __device__ __forceinline__ void load_x(const float* __restrict__ x, int K, float
     }
 }
 
-template <int NJ>
-__device__ __forceinline__ void add_x(const float* __restrict__ d, int K, float (&xr)[NJ][8]) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = threadIdx.x + j * 256;
-        if (c * 8 < K) {
-            const float4 a = reinterpret_cast<const float4*>(d)[c * 2];
-            const float4 b = reinterpret_cast<const float4*>(d)[c * 2 + 1];
-            xr[j][0] += a.x; xr[j][1] += a.y; xr[j][2] += a.z; xr[j][3] += a.w;
-            xr[j][4] += b.x; xr[j][5] += b.y; xr[j][6] += b.z; xr[j][7] += b.w;
-        }
-    }
-}
-
-template <int NJ>
-__device__ __forceinline__ void store_x(float* __restrict__ x, int K, const float (&xr)[NJ][8]) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = threadIdx.x + j * 256;
-        if (c * 8 < K) {
-            reinterpret_cast<float4*>(x)[c * 2] = make_float4(xr[j][0], xr[j][1], xr[j][2], xr[j][3]);
-            reinterpret_cast<float4*>(x)[c * 2 + 1] = make_float4(xr[j][4], xr[j][5], xr[j][6], xr[j][7]);
-        }
-    }
-}
-
-// x <- x * w_norm (elementwise); returns this thread's share of sum(x^2).  The scalar
-// rsqrt(mean(x^2)+eps) of MixtralRMSNorm (modeling_mixtral.py:143-148) commutes with the GEMV,
-// so it is applied to the reduced dot products: one block reduction instead of two.
-template <int NJ>
-__device__ __forceinline__ float scale_by_norm_weight(const float* __restrict__ w, int K, float (&xr)[NJ][8]) {
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = threadIdx.x + j * 256;
-        if (c * 8 < K) {
-            const float4 a = reinterpret_cast<const float4*>(w)[c * 2];
-            const float4 b = reinterpret_cast<const float4*>(w)[c * 2 + 1];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ss = fmaf(xr[j][i], xr[j][i], ss);
-            xr[j][0] *= a.x; xr[j][1] *= a.y; xr[j][2] *= a.z; xr[j][3] *= a.w;
-            xr[j][4] *= b.x; xr[j][5] *= b.y; xr[j][6] *= b.z; xr[j][7] *= b.w;
-        }
-    }
-    return ss;
-}
-
 // x = x_in + delta (optionally stored to x_out by block 0), then x <- x * w_norm; returns this thread's
-// share of sum(x^2).  The three activation-side vectors are loaded TOGETHER (one L2 round trip, not three
+// share of sum(x^2).  The scalar rsqrt(mean(x^2)+eps) of MixtralRMSNorm (modeling_mixtral.py:143-148) commutes
+// with the GEMV, so callers apply it to the reduced dot products: one block reduction instead of two.  The three activation-side vectors are loaded TOGETHER (one L2 round trip, not three
 // dependent ones: the separate load_x / add_x / scale_by_norm_weight sequence cost ~1 us per kernel).
 template <int NJ>
 __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, const float* __restrict__ delta,
@@ -746,6 +700,7 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale) {
+    (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits) return -1;
@@ -771,6 +726,7 @@ int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* v
                        float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
                        int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out) {
     constexpr int R = 16;
+    (void)pos_ptr;
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits) return -1;
