@@ -148,6 +148,42 @@ def test_demo_sequence_text_only(ckpt, dev):
     assert (ids < 0).sum().item() == 0 and 1 <= len(got) <= 6
 
 
+def test_demo_sequence_video(ckpt, dev, tmp_path):
+    """video prompt (video_audio_demo.py:199-212): frames sampled at 1 fps, clamped to [4, 16], one <image> per frame."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    try:
+        from decord import VideoReader, cpu
+        from vita.constants import DEFAULT_AUDIO_TOKEN, DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX
+        from vita.conversation import conv_templates
+        from vita.model.builder import load_pretrained_model
+        from vita.util.mm_utils import tokenizer_image_audio_token
+    finally:
+        sys.path.pop(0)
+    from vita_amd.host.video import get_rawvideo
+    d, sd, wav, _ = ckpt
+    path = str(tmp_path / "clip.npz")
+    np.savez(path, frames=np.random.default_rng(2).integers(0, 255, size=(66, 40, 60, 3), dtype=np.uint8), fps=6.0)
+    tokenizer, model, image_processor, _ = load_pretrained_model(d, None, "vita-tiny", "mixtral-8x7b")
+    frames, slice_len = get_rawvideo(VideoReader(path, ctx=cpu(0)), image_processor,
+                                     image_aspect_ratio=getattr(model.config, "image_aspect_ratio", None))
+    assert slice_len == 11 and frames.shape[0] == 11                 # 66 frames at 6 fps -> one per second
+    audio, _ = model.get_audio_encoder().audio_processor.process(wav)
+    audios = {"audios": audio[None].half().cuda(), "lengths": torch.tensor([audio.shape[0]]).half().cuda()}
+    qs = DEFAULT_IMAGE_TOKEN * slice_len + "\n" + "what happens in this video" + DEFAULT_AUDIO_TOKEN
+    conv = conv_templates["mixtral_two"].copy()
+    conv.append_message(conv.roles[0], qs)
+    conv.append_message(conv.roles[1], None)
+    input_ids = tokenizer_image_audio_token(conv.get_prompt("video"), tokenizer, IMAGE_TOKEN_INDEX,
+                                            return_tensors="pt").unsqueeze(0).cuda()
+    assert (input_ids == IMAGE_TOKEN_INDEX).sum().item() == slice_len
+    out = model.generate(input_ids, images=frames.to(dtype=model.dtype, device="cuda"), audios=audios, do_sample=False,
+                         num_beams=1, return_dict_in_generate=True, max_new_tokens=6, use_cache=True)
+    assert (input_ids != out.sequences[:, :input_ids.shape[1]]).sum().item() == 0
+    assert model.last_timing["prompt_tokens"] == input_ids.shape[1] - slice_len - 1 + slice_len * 4 + \
+        model.get_audio_encoder()(audios["audios"], audios["lengths"])["inputs_embeds"].shape[1]
+
+
 def test_load_pretrained_rejects_unknown_type(ckpt):
     from vita_amd.model import load_pretrained_model
     with pytest.raises(ValueError):

@@ -177,3 +177,40 @@ def test_audio_side_files_match_reference_loaders(tmp_path):
     side = read_audio_encoder_dir(str(tmp_path))
     assert side["dataset_conf"]["fbank_conf"]["dither"] == 0.0 and len(side["overridden"]) == 2
     np.testing.assert_allclose(side["mean"], mean, rtol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vita"), reason="reference tree only exists in the build container")
+def test_video_front_end_matches_reference_function(tmp_path):
+    """The reference's OWN `_get_rawvideo_dec` (video_audio_demo.py:30-118), imported from its demo script with
+    compat/ serving `vita.*` and `decord`, against vita_amd.host.video on the same synthetic frame container."""
+    import importlib.util
+    import sys
+    import numpy as np
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    mine = lambda k: k in ("vita", "decord") or k.startswith(("vita.", "decord."))   # may be oracle/ref_harness stubs
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if mine(k)}
+    try:
+        spec = importlib.util.spec_from_file_location("ref_video_audio_demo", "/root/reference/video_audio_demo.py")
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)                      # module level only defines functions + imports
+        from decord import VideoReader, cpu
+        from vita_amd.host.image_processing import make_image_processor
+        from vita_amd.host.video import get_rawvideo, sample_positions
+        rng = np.random.default_rng(0)
+        proc = make_image_processor(56)
+        for T, fps, kw in ((70, 5.0, {}), (9, 3.0, {}), (400, 10.0, {}), (120, 4.0, {"s": 3, "e": 11})):
+            path = str(tmp_path / f"v{T}.npz")
+            np.savez(path, frames=rng.integers(0, 255, size=(T, 40, 60, 3), dtype=np.uint8), fps=fps)
+            want, n_want = ref._get_rawvideo_dec(path, proc, max_frames=16, min_frames=4, video_framerate=1,
+                                                 image_aspect_ratio="pad", **kw)
+            got, n_got = get_rawvideo(VideoReader(path, ctx=cpu(0)), proc, **kw)
+            assert n_got == n_want and 4 <= n_got <= 16
+            assert torch.equal(got, want)
+        assert sample_positions(3, 30.0) == [0, 0, 0, 0]                     # shorter than a second: frame 0 repeated
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if mine(k)]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)
