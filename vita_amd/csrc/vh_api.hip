@@ -432,8 +432,8 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
                 VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
             }
         }
-        VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.ffn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
-        VH_TRY(vhk_moe_route(st, m->pxn, w.wrouter, Sn, H, E, m->pids, m->pwts), "route");
+        VH_TRY(vhk_rmsnorm_route(st, m->px, m->pxn, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter, E, m->pids, m->pwts),
+               "rmsnorm + route");
         VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
         if (vh_tuning()->prefill_moe_gemm == 0) {
             // pre-split path: activations split once, one 192-row m-tile per expert, weights read once

@@ -64,6 +64,73 @@ __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, 
     }
 }
 
+// ---- Mixtral prefill: post-attention RMSNorm fused with the top-2 router ------------------
+// One wave per token: the normalised row stays in registers, the 8 router logits are wave
+// reductions over it (modeling_mixtral.py:96-111: logits = x_n Wg^T, fp32 softmax, top-2, renormalise;
+// ties resolve to the lowest expert index like torch.topk).  Replaces a separate routing kernel that
+// re-read x_n (34 us per layer at S=552).
+__global__ __launch_bounds__(256) void k_rmsnorm_route(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ w, int rows, int cols, float eps,
+                                                       const uint16_t* __restrict__ Wg, int E,
+                                                       int* __restrict__ ids, float* __restrict__ wts) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)row * cols);
+    f32x4 v[LN_MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = xp[c < nv ? c : 0];
+        if (c >= nv) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    }
+    const float inv = rsqrtf(wave_sum(q) / (float)cols + eps);
+    f32x4* yp = reinterpret_cast<f32x4*>(y + (size_t)row * cols);
+    float lg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lg[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 r = v[i] * inv * reinterpret_cast<const f32x4*>(w)[c];
+            yp[c] = r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < E) {
+                    const uint2 g = reinterpret_cast<const uint2*>(Wg + (size_t)e * cols)[c];
+                    lg[e] = fmaf(r[0], bf16_lo_to_f32(g.x), lg[e]);
+                    lg[e] = fmaf(r[1], bf16_hi_to_f32(g.x), lg[e]);
+                    lg[e] = fmaf(r[2], bf16_lo_to_f32(g.y), lg[e]);
+                    lg[e] = fmaf(r[3], bf16_hi_to_f32(g.y), lg[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lg[e] = wave_sum(lg[e]);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
+    float pr[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
+    int e0 = 0, e1 = 0;
+    float b0 = -1.f, b1 = -1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] /= sum; if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; } }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
+    if (lane == 0) {
+        const float t = b0 + b1;
+        ids[row * 2] = e0; ids[row * 2 + 1] = e1;
+        wts[row * 2] = b0 / t; wts[row * 2 + 1] = b1 / t;
+    }
+}
+
 __global__ void k_add(float* __restrict__ x, const float* __restrict__ y, long n4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<float4*>(x)[i];
@@ -202,46 +269,6 @@ __global__ __launch_bounds__(256) void k_embed_splice(const int* __restrict__ ki
     }
 }
 
-// ---- MoE routing for S tokens (modeling_mixtral.py:96-111): one wave per token ----------
-__global__ __launch_bounds__(256) void k_moe_route(const float* __restrict__ xn, const uint16_t* __restrict__ Wg,
-                                                   int S, int H, int E, int* __restrict__ ids,
-                                                   float* __restrict__ wts) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int s = blockIdx.x * 4 + wid;
-    if (s >= S) return;
-    float lg[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) lg[e] = 0.f;
-    const float* xr = xn + (size_t)s * H;
-    for (int c = lane; c * 8 < H; c += 64) {
-        float xv[8];
-        const float4 a = reinterpret_cast<const float4*>(xr)[c * 2], bq = reinterpret_cast<const float4*>(xr)[c * 2 + 1];
-        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = bq.x; xv[5] = bq.y; xv[6] = bq.z; xv[7] = bq.w;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (e < E) lg[e] += dot8_bf16_f32(reinterpret_cast<const uint4*>(Wg + (size_t)e * H)[c], xv);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) lg[e] = wave_sum(lg[e]);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
-    float pr[8], sum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
-    int e0 = 0, e1 = 0;
-    float b0 = -1.f, b1 = -1.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { pr[e] /= sum; if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; } }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
-    if (lane == 0) {
-        const float t = b0 + b1;
-        ids[s * 2] = e0; ids[s * 2 + 1] = e1;
-        wts[s * 2] = b0 / t; wts[s * 2 + 1] = b1 / t;
-    }
-}
-
 // counting sort of the 2S (token, slot) entries by expert: wave e owns expert e.
 // sorted order inside an expert is ascending entry index -> deterministic.
 __global__ void k_moe_sort(const int* __restrict__ ids, int S, int E, int* __restrict__ group_off,
@@ -368,10 +395,11 @@ int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, co
                        S, H);
     return 0;
 }
-int vhk_moe_route(hipStream_t st, const float* xn, const uint16_t* Wg, int S, int H, int E, int* ids, float* wts) {
-    if (E > 8 || E < 2 || H % 8 != 0) return -1;
-    if (S == 0) return 0;
-    hipLaunchKernelGGL(k_moe_route, dim3((S + 3) / 4), dim3(256), 0, st, xn, Wg, S, H, E, ids, wts);
+int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps,
+                      const uint16_t* Wg, int E, int* ids, float* wts) {
+    if (cols % 4 != 0 || cols > LN_MAXV * 256 || E < 2 || E > 8) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_rmsnorm_route, dim3((rows + 3) / 4), dim3(256), 0, st, x, y, w, rows, cols, eps, Wg, E, ids, wts);
     return 0;
 }
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot) {

@@ -107,7 +107,8 @@ int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, floa
                 const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx);
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
                      const float* img_feats, const float* aud_feats, float* out, int S, int H);
-int vhk_moe_route(hipStream_t st, const float* xn, const uint16_t* Wg, int S, int H, int E, int* ids, float* wts);
+int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps,
+                      const uint16_t* Wg, int E, int* ids, float* wts);
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot);
 int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H);
 int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n);
