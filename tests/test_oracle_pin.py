@@ -88,3 +88,24 @@ def test_live_vs_reference_modules():
         ref_a = rh.build_whale(cfg, sd)(torch.from_numpy(feats)[None], torch.tensor([77]))["inputs_embeds"][0].numpy()
     assert_close("live vit", oe.internvit_tower(sd, cfg.vision, pix), ref_v, atol=5e-6)
     assert_close("live whale", oe.whale_encoder(sd, cfg.audio, feats)[0], ref_a, atol=5e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vita"), reason="reference tree only exists in the build container")
+def test_live_whale_padded_batch_vs_reference():
+    """two clips of different lengths in ONE reference forward (pad mask in attention, zeroing before the adapter,
+    adpter mask) against the oracle run per clip with `length`."""
+    import torch
+    from oracle import ref_harness as rh
+    cfg = VitaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=13)
+    rng = np.random.default_rng(14)
+    T, lens = 140, [140, 97]
+    feats = (rng.standard_normal((2, T, 80)) * 3 + 12).astype(np.float32)
+    with torch.no_grad():
+        ref = rh.build_whale(cfg, sd)(torch.from_numpy(feats), torch.tensor(lens))
+    for b in range(2):
+        z, mask = oe.whale_encoder(sd, cfg.audio, feats[b], length=lens[b])
+        rmask = ref["attention_mask"][b].numpy().astype(bool)
+        assert mask.tolist() == rmask.tolist()
+        # rows the reference marks valid must agree; padded rows are whatever the adapter makes of zeros in both
+        assert_close(f"padded whale clip {b}", z[rmask], ref["inputs_embeds"][b].numpy()[rmask], atol=5e-6)
