@@ -687,14 +687,22 @@ inline int pick_nj(int K, F&& f) {
 }  // namespace
 
 // ---- launchers (declared in vh_kernels.h) -------------------------------------------
-int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out) {
-    constexpr int R = 8;
+template <int R, bool NORM>
+static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w,
+                           float eps, const uint16_t* W, int N, int K, float* out) {
     return pick_nj(K, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, true>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
+        hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
                            delta, x_out, norm_w, eps, W, N, K, out);
         return 0;
     });
+}
+
+int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
+                const uint16_t* W, int N, int K, float* out) {
+    const int r = vh_tuning()->gemv_rows;   // rows per block: 4 (default), 8 or 16 (vh_tune)
+    if (r == 8) return launch_dec_gemv<8, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
+    if (r == 16 && K <= 4096) return launch_dec_gemv<16, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
+    return launch_dec_gemv<4, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
@@ -710,12 +718,10 @@ int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache,
 }
 
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out) {
-    constexpr int R = 8;
-    return pick_nj(K, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, false>), dim3((N + R - 1) / R), dim3(256), 0, st,
-                           attn_out, (const float*)nullptr, (float*)nullptr, (const float*)nullptr, 0.f, W, N, K, out);
-        return 0;
-    });
+    const int r = vh_tuning()->gemv_rows;
+    if (r == 8) return launch_dec_gemv<8, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out);
+    if (r == 16 && K <= 4096) return launch_dec_gemv<16, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out);
+    return launch_dec_gemv<4, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out);
 }
 
 // Fused attention + O-projection launch.  Returns 1 (nothing launched) when the launch could not be

@@ -8,6 +8,7 @@
 // ---- run-time tuning knobs (set through vh_tune(); defaults are the measured-best variants) ---
 struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
+    int gemv_rows = 4;        // rows per block of the decode QKV / O GEMVs: 4 (12.9 / 8.3 us), 8 (13.1 / 9.4), 16 (15.8 / 11.7)
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
     int prefill_moe_gemm = 1; // MoE prefill GEMMs: 1 = general kernel (fastest), 0 = pre-split skinny glds kernel (vh_gemm_ps)
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
