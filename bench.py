@@ -37,6 +37,44 @@ def pmc_traffic(kernel):
         return None
 
 
+def native_rccl_or_fallback(eng, rank, dist, dev, backend, timeout_s=180):
+    """Bring up the engine's own RCCL communicator (ncclAllReduce enqueued straight from the C layer loop).
+    The attempt is bounded and the ranks AGREE on the outcome: if any rank failed or timed out, every rank uses
+    torch.distributed's all-reduce through the callback hook instead (slower host side, same results) — a
+    bench line beats a hang.  Returns True when the native path is active on all ranks."""
+    import ctypes
+    import threading
+    from vita_amd import _lib
+    uid = ctypes.create_string_buffer(128)
+    ok = [0]
+    try:
+        if rank == 0:
+            _lib.check(_lib.load().vh_rccl_unique_id(uid), "vh_rccl_unique_id")
+        obj = [bytes(uid.raw)]
+        dist.broadcast_object_list(obj, src=0)
+
+        def run():
+            try:
+                torch.cuda.set_device(dev)      # HIP's current device is per thread; ncclCommInitRank binds to it
+                eng.use_rccl(obj[0])
+                ok[0] = 1
+            except Exception as e:
+                print(f"[bench] rank {rank}: native RCCL init failed: {e}", file=sys.stderr)
+
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            print(f"[bench] rank {rank}: native RCCL init still not done after {timeout_s}s", file=sys.stderr)
+            ok[0] = 0
+    except Exception as e:
+        print(f"[bench] rank {rank}: native RCCL setup failed: {e}", file=sys.stderr)
+        ok[0] = 0
+    flag = torch.tensor([ok[0]], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 def cpu_baseline(cfg, n_layers=2, ctx=64, n_tok=6):
     """The oracle (numpy port of the HF Mixtral arithmetic the reference calls) timed on this box's
     host cores: `n_layers` real-geometry decoder layers + LM head, decode steps at a short context,
@@ -103,6 +141,9 @@ def main():
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device is the 1-GPU functional check of the N>1 path")
+    ap.add_argument("--try-rccl", action="store_true",
+                    help="debug (with --backend gloo --one-device): attempt the native RCCL init anyway — it must "
+                         "fail (duplicate GPU) and every rank must agree on the torch fallback")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0 (invalid as a measurement)")
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="debug: run ONE rank's 1/N shard on one GPU with the collective skipped — per-rank compute "
@@ -128,7 +169,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend="gloo")
-            args.collective = "torch"      # RCCL refuses two ranks on one device; gloo stages through the host
+            if not args.try_rccl:
+                args.collective = "torch"  # RCCL refuses two ranks on one device; gloo stages through the host
 
     from vita_amd.checkpoint import synth_mixtral_device, synth_state_dict
     from vita_amd.config import VitaConfig, audio_token_count
@@ -159,19 +201,7 @@ def main():
     if world > 1:
         collective = args.collective
         if collective == "rccl":
-            try:
-                import ctypes
-                from vita_amd import _lib
-                uid = ctypes.create_string_buffer(128)
-                if rank == 0:
-                    _lib.check(_lib.load().vh_rccl_unique_id(uid), "vh_rccl_unique_id")
-                obj = [bytes(uid.raw)]
-                dist.broadcast_object_list(obj, src=0)
-                eng.use_rccl(obj[0])
-            except Exception as e:  # fall back to torch.distributed's RCCL communicator
-                if rank == 0:
-                    print(f"[bench] native RCCL path unavailable ({e}); using torch.distributed all_reduce", file=sys.stderr)
-                collective = "torch"
+            collective = "rccl" if native_rccl_or_fallback(eng, rank, dist, dev, args.backend) else "torch"
         if collective == "torch":
             eng.use_torch_allreduce()
     torch.cuda.synchronize()
@@ -283,7 +313,7 @@ def main():
             out["INVALID_debug_text_tokens"] = args.text_tokens
         if args.one_device or args.backend != "nccl":
             out["INVALID_debug_backend"] = f"{args.backend}, one_device={args.one_device}"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed once, at N=1 (torchrun also pins OMP to 1 thread)
             try:
                 out["cpu_baseline"] = cpu_baseline(VitaConfig())
             except Exception as e:  # never lose the GPU line to a host-side problem
