@@ -63,11 +63,12 @@ def worker_loop(llm_id, make_llm, sampling_params, inputs_queue, outputs_queue, 
         t_take = time.perf_counter()
         current = dict(inputs)
         results, pending, first_positive, t_first = [], "", True, None
-        previous = ""
+        previous, n_tokens = "", 0
         st = {"speaking": False}     # the stop flag only counts once this engine has taken the floor (:354)
         for out in llm.generate_stream(inputs, sampling_params, request_id=uuid.uuid4().hex,
                                        should_stop=lambda: st["speaking"] and stop_event.is_set()):
             text = out.outputs[0].text
+            n_tokens = len(out.outputs[0].token_ids)
             new = text[len(previous):]
             previous = text
             if new == "":
@@ -99,8 +100,10 @@ def worker_loop(llm_id, make_llm, sampling_params, inputs_queue, outputs_queue, 
             if history_limit and len(global_history) > history_limit:
                 del global_history[0]
         if stats_queue is not None:
+            t_end = time.perf_counter()
             stats_queue.put({"id": llm_id, "request": current.get("request_id"),
                              "take_to_first_chunk_s": None if t_first is None else t_first - t_take,
+                             "first_chunk_to_end_s": None if t_first is None else t_end - t_first, "n_tokens": n_tokens,
                              "interrupted": bool(stop_event.is_set()), "negative": first_positive,
                              "n_chunks": len(results)})
 
