@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="debug: run ONE rank's 1/N shard on one GPU with the collective skipped — per-rank compute "
                          "time of TP=N without communication (tokens are meaningless, result marked invalid)")
+    ap.add_argument("--frames", type=int, default=1,
+                    help="debug: number of 448x448 tiles / video frames in the prompt (default 1 = configs[2]; 4-16 is the "
+                         "video shape of configs[4])")
     ap.add_argument("--text-tokens", type=int, default=32, help="debug: length of the user text (default 32 = configs[2])")
     ap.add_argument("--tune", default="", help="debug: kernel-variant knobs key=val[,key=val] (vh_tune)")
     args = ap.parse_args()
@@ -208,7 +211,7 @@ def main():
     packed = synth_mixtral_device(cfg, dev, seed=0, rank=rank, world=args.emulate_tp or world)
     sd_enc = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
     model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=K + Wm + 8,
-                                   max_prefill=max(1024, args.text_tokens + 1024), rank=rank, world=world, keep_scores=False)
+                                   max_prefill=max(1024, args.text_tokens + 768 + 256 * args.frames), rank=rank, world=world, keep_scores=False)
     model.get_vision_tower().load_model()
     eng = model.engine
     collective = "none"
@@ -223,7 +226,7 @@ def main():
 
     # ---- synthetic request: 1 image tile + 10 s audio + text (configs[2]) -----------------------------
     g = torch.Generator(device="cpu").manual_seed(2)
-    image = ((torch.rand((1, 3, 448, 448), generator=g) - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+    image = ((torch.rand((args.frames, 3, 448, 448), generator=g) - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
              / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)).to(dev)
     wav = 0.1 * np.random.default_rng(3).standard_normal(160000)
     feats = kaldi_fbank(wav * (1 << 15), 16000)                      # [998, 80]
@@ -231,7 +234,7 @@ def main():
     rng = np.random.default_rng(1)
     sys_ids = rng.integers(3, 51000, size=139).tolist()              # stand-in for the ~140-token system prompt
     txt_ids = rng.integers(3, 51000, size=args.text_tokens).tolist()
-    ids = [t.bos_token_id] + sys_ids + [IMAGE_TOKEN_INDEX] + txt_ids + [AUDIO_TOKEN_INDEX]
+    ids = [t.bos_token_id] + sys_ids + [IMAGE_TOKEN_INDEX] * args.frames + txt_ids + [AUDIO_TOKEN_INDEX]
     input_ids = torch.tensor([ids], dtype=torch.long, device=dev)
     audios = {"audios": torch.from_numpy(feats)[None].to(dev), "lengths": torch.tensor([feats.shape[0]], device=dev)}
 
@@ -306,8 +309,10 @@ def main():
             "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16 weights, f32 activations/accumulate",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 1 image (448x448, 1 tile -> 256 tokens) + 10 s audio "
-                                   f"(998 fbank frames -> {n_aud_tok} tokens) + {len(ids) - 2} text ids, prefill S={S}, "
+            "config": {"workload": ("BASELINE configs[2]: 1 image (448x448, 1 tile -> 256 tokens)" if args.frames == 1 else
+                                    f"video-shaped prompt: {args.frames} frames (448x448, 1 tile each -> {256 * args.frames} tokens)")
+                                   + f" + 10 s audio (998 fbank frames -> {n_aud_tok} tokens) + "
+                                   f"{len(ids) - args.frames - 1} text ids, prefill S={S}, "
                                    "greedy decode, batch 1; VITA-Mixtral-8x7B geometry (32 layers, 8 experts top-2)",
                        "parallelism": f"tp{world}", "collective": collective, "prompt_tokens": int(S),
                        "layers": t.num_hidden_layers},
@@ -337,6 +342,8 @@ def main():
             out["INVALID_emulated_tp_rank_compute_only"] = args.emulate_tp
         if args.text_tokens != 32:
             out["INVALID_debug_text_tokens"] = args.text_tokens
+        if args.frames != 1:
+            out["OTHER_WORKLOAD_frames"] = args.frames      # not the metric's configuration: video-shaped prompt
         if args.one_device or args.backend != "nccl":
             out["INVALID_debug_backend"] = f"{args.backend}, one_device={args.one_device}"
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed once, at N=1 (torchrun also pins OMP to 1 thread)
