@@ -20,3 +20,52 @@ def test_pmc_traffic_reads_committed_profile():
     v = bench.pmc_traffic("k_dec_gateup")
     assert v is not None and 0.9 < v / 469827584 < 1.2     # HBM bytes per launch ~ the algorithmic bytes
     assert bench.pmc_traffic("no_such_kernel") is None
+
+
+# ---- N>1 bring-up: every rank must reach the SAME decision about the native RCCL communicator -----------------
+class _FakeEngine:
+    def __init__(self, fail):
+        self.fail, self.called = fail, False
+
+    def use_rccl(self, uid):
+        self.called = True
+        if self.fail:
+            raise RuntimeError("simulated ncclCommInitRank failure")
+
+
+def _bringup_worker(rank, world, port, fail_rank, ret):
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = _FakeEngine(fail=(rank == fail_rank))
+        ok = bench.native_rccl_or_fallback(eng, rank, dist, torch.device("cpu"), "gloo", timeout_s=20)
+        ret[rank] = (bool(ok), eng.called)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bringup(fail_rank):
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_bringup_worker, args=(2, _free_port(), fail_rank, ret), nprocs=2, join=True)
+    return dict(ret)
+
+
+def test_rccl_bringup_consensus_world2():
+    """One rank failing its native init (or rank 0 being unable to mint an id on a GPU-less host) must send BOTH
+    ranks to the torch fallback; nobody may be left believing the native communicator is active alone."""
+    r = _run_bringup(fail_rank=1)
+    assert r[0][0] is False and r[1][0] is False, r
+    r2 = _run_bringup(fail_rank=-1)
+    assert r2[0][0] == r2[1][0], r2            # agree either way (True only where librccl could mint an id)
