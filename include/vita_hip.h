@@ -64,10 +64,12 @@ typedef struct {
 } vh_gemm_args;
 int vh_gemm(const vh_gemm_args* args, void* stream);
 
-/* vh_gemm_ps: the same contraction for SKINNY M (Mixtral prefill, MoE grouped GEMMs: HF MixtralExperts,
- * modeling_mixtral.py:57-93) on activations already split into bf16 hi/lo planes (x = hi + lo to 2^-17;
- * vh_split_planes makes them, vh_gemm_ps can also emit them).  One m-tile covers up to 192 rows of a group
- * so each weight byte is read once; K % 64 == 0, lda % 8 == 0.  `wide` != 0 selects 256-column tiles. */
+/* vh_gemm_ps: the same contraction as a WEIGHT STREAM for skinny M (Mixtral prefill, MoE grouped GEMMs: HF
+ * MixtralExperts, modeling_mixtral.py:57-93) on activations already split into bf16 hi/lo planes (x = hi + lo
+ * to 2^-17; vh_split_planes makes them, vh_gemm_ps can also emit them).  One m-tile covers all rows of a group
+ * (up to 160 / 192; larger groups are cut into balanced m-tiles) so each weight byte is read once; K % 64 == 0,
+ * lda % 8 == 0.  ksplit > 1 (plain fp32 output only): K is cut into ksplit ranges whose partial sums are
+ * written to C + ks * c_split_stride (the caller adds the slabs).  `wide` is ignored (kept for ABI stability). */
 typedef struct {
     const uint16_t* A_hi; const uint16_t* A_lo; long lda; const int* a_rowidx;
     const uint16_t* W; const uint16_t* W_up; long ldw; long w_group_stride;
@@ -75,6 +77,7 @@ typedef struct {
     float* C; long ldc; uint16_t* C_hi; uint16_t* C_lo; long ldc_split; const int* c_rowidx;
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act, wide;
+    int ksplit; long c_split_stride;
 } vh_gemm_ps_args;
 int vh_gemm_ps(const vh_gemm_ps_args* args, void* stream);
 int vh_split_planes(const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows, int cols, void* stream);

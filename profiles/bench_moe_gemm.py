@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the prefill MoE GEMM pair at the released geometry (one layer: 8 experts, H 4096, I 14336),
+S tokens with random top-2 routing.  Times gate|up and down per launch with events on the launch stream, checks a
+sample of the output against an fp64 torch reference, and sweeps the kernel's tuning knobs.
+
+  python profiles/bench_moe_gemm.py [--S 552] [--iters 10] [--sweep]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vita_amd import _lib, ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--S", type=int, default=552)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--nocheck", action="store_true", help="ablated builds: skip the parity assertion")
+    ap.add_argument("--H", type=int, default=4096)
+    ap.add_argument("--I", type=int, default=14336)
+    ap.add_argument("--E", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=2, help="distinct weight sets cycled through (defeats cache reuse)")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    S, H, I, E = args.S, args.H, args.I, args.E
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def W(*shape):
+        return (torch.randn(shape, device=dev, generator=g, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+
+    layers = [dict(w1=W(E, I, H), w3=W(E, I, H), w2=W(E, H, I)) for _ in range(args.layers)]
+    x = torch.randn((S, H), device=dev, generator=g, dtype=torch.float32)
+    rng = np.random.default_rng(1)
+    ids = np.stack([rng.permutation(E)[:2] for _ in range(S)]).astype(np.int32)
+    flat = ids.reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    goff = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=E))]).astype(np.int32)).to(dev)
+    stok = torch.from_numpy((order // 2).astype(np.int32)).to(dev)
+    sslot = torch.from_numpy(order.astype(np.int32)).to(dev)
+    xh, xl = ops.split_planes(x)
+    rows = np.bincount(flat, minlength=E)
+    print("rows per expert:", rows.tolist(), flush=True)
+
+    def run_ps(L, ksplit):
+        hh, hl = ops.gemm_ps(xh, xl, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E,
+                             w_group_stride=I * H, m=2 * S, out_split=True)
+        y = torch.empty((ksplit, 2 * S, H), dtype=torch.float32, device=dev)
+        ops.gemm_ps(hh, hl, L["w2"], group_off=goff, ngroups=E, w_group_stride=H * I, c_rowidx=sslot,
+                    out=y if ksplit > 1 else y[0], ksplit=ksplit)
+        return hh, hl, y
+
+    def run_general(L):
+        h = ops.gemm(x, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E, w_group_stride=I * H, m=2 * S)
+        y = torch.empty((2 * S, H), dtype=torch.float32, device=dev)
+        ops.gemm(h, L["w2"], group_off=goff, ngroups=E, w_group_stride=H * I, c_rowidx=sslot, out=y)
+        return h, y
+
+    # ---- correctness on a sample (fp64 torch reference) ------------------------------------------------
+    L = layers[0]
+    hh, hl, y = run_ps(L, 2)
+    torch.cuda.synchronize()
+    h = hh.float() + hl.float()
+    ysum = y.sum(0)
+    err_h = err_y = 0.0
+    for p in list(range(0, 2 * S, max(1, (2 * S) // 24))) + [2 * S - 1]:
+        slot = int(order[p]); e = int(flat[slot]); t = slot // 2
+        xr = x[t].double()
+        gg = L["w1"][e].double() @ xr
+        uu = L["w3"][e].double() @ xr
+        href = gg / (1 + torch.exp(-gg)) * uu
+        err_h = max(err_h, float((h[p].double() - href).abs().max()))
+        yref = L["w2"][e].double() @ h[p].double()
+        err_y = max(err_y, float((ysum[slot].double() - yref).abs().max()))
+    print(f"max |err| gate/up {err_h:.3e}   down {err_y:.3e}", flush=True)
+    assert args.nocheck or (err_h < 5e-4 and err_y < 5e-4), "parity failure"
+
+    def timed(fn, iters):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+        for i in range(2):
+            fn(layers[i % len(layers)])
+        torch.cuda.synchronize()
+        ev[0].record()
+        for i in range(iters):
+            fn(layers[i % len(layers)])
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ts = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(iters)]
+        return float(np.median(ts)), float(np.min(ts))
+
+    def time_pair(ksplit):
+        hh, hl, _ = run_ps(layers[0], ksplit)
+        y = torch.empty((ksplit, 2 * S, H), dtype=torch.float32, device=dev)
+
+        def gu(L):
+            ops.gemm_ps(xh, xl, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E,
+                        w_group_stride=I * H, m=2 * S, out_split=True)
+
+        def dn(L):
+            ops.gemm_ps(hh, hl, L["w2"], group_off=goff, ngroups=E, w_group_stride=H * I, c_rowidx=sslot,
+                        out=y if ksplit > 1 else y[0], ksplit=ksplit)
+
+        return timed(gu, args.iters), timed(dn, args.iters)
+
+    out = {"S": S, "rows": rows.tolist()}
+    gu_bytes = 2 * E * I * H * 2
+    dn_bytes = E * I * H * 2
+
+    def report(tag, gu, dn):
+        print(f"{tag:34s} gate|up {gu[0]:8.1f} us (min {gu[1]:8.1f}) = {gu_bytes / gu[0] / 1e6:5.2f} TB/s | "
+              f"down {dn[0]:8.1f} us (min {dn[1]:8.1f}) = {dn_bytes / dn[0] / 1e6:5.2f} TB/s", flush=True)
+        out[tag] = {"gateup_us": gu[0], "gateup_min_us": gu[1], "down_us": dn[0], "down_min_us": dn[1]}
+
+    gu, dn = time_pair(2)
+    report("stream ksplit=2 (default)", gu, dn)
+    if args.sweep:
+        gu, dn = time_pair(1)
+        report("stream ksplit=1", gu, dn)
+        for cfg in (0, 1):
+            _lib.tune("ps_cfg", cfg)
+            gu, dn = time_pair(2)
+            report(f"stream cfg={cfg}", gu, dn)
+        _lib.tune("ps_cfg", -1)
+        _lib.tune("ps_nt", 0)
+        gu, dn = time_pair(2)
+        report("stream, default-policy weight loads", gu, dn)
+        _lib.tune("ps_nt", 1)
+        for grid in (128, 248):
+            _lib.tune("ps_grid", grid)
+            gu, dn = time_pair(2)
+            report(f"stream grid={grid}", gu, dn)
+        _lib.tune("ps_grid", 0)
+
+        def ggu(L):
+            ops.gemm(x, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E, w_group_stride=I * H, m=2 * S)
+
+        h0, _ = run_general(layers[0])
+        yy = torch.empty((2 * S, H), dtype=torch.float32, device=dev)
+
+        def gdn(L):
+            ops.gemm(h0, L["w2"], group_off=goff, ngroups=E, w_group_stride=H * I, c_rowidx=sslot, out=yy)
+
+        report("general kernel (round 1)", timed(ggu, args.iters), timed(gdn, args.iters))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

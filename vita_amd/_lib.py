@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvita_hip.so")
+# VITA_AMD_LIB: load another build of the same library (profiling experiments, e.g. profiles/ablate_ps.sh)
+LIB_PATH = os.environ.get("VITA_AMD_LIB") or os.path.join(_HERE, "lib", "libvita_hip.so")
 
 VH_ACT_NONE, VH_ACT_GELU, VH_ACT_RELU, VH_ACT_SILU = 0, 1, 2, 3
 
@@ -34,6 +35,7 @@ class GemmPsArgs(C.Structure):
         ("C", c_void_p), ("ldc", c_long), ("C_hi", c_void_p), ("C_lo", c_void_p), ("ldc_split", c_long),
         ("c_rowidx", c_void_p), ("bias", c_void_p), ("scale", c_void_p), ("resid", c_void_p), ("ldr", c_long),
         ("M", c_int), ("N", c_int), ("K", c_int), ("act", c_int), ("wide", c_int),
+        ("ksplit", c_int), ("c_split_stride", c_long),
     ]
 
 

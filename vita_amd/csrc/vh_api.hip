@@ -48,7 +48,10 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
     if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
     if (!strcmp(key, "gemm_prefetch")) { g_tuning.gemm_prefetch = value; return VH_OK; }
-    if (!strcmp(key, "ps_ablate")) { g_tuning.ps_ablate = value; return VH_OK; }
+    if (!strcmp(key, "ps_cfg")) { g_tuning.ps_cfg = value; return VH_OK; }
+    if (!strcmp(key, "ps_grid")) { g_tuning.ps_grid = value; return VH_OK; }
+    if (!strcmp(key, "ps_nt")) { g_tuning.ps_nt = value; return VH_OK; }
+    if (!strcmp(key, "moe_ksplit")) { g_tuning.moe_ksplit = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
@@ -76,7 +79,10 @@ int vh_gemm_ps(const vh_gemm_ps_args* a, void* stream) {
     g.group_off = a->group_off; g.ngroups = a->ngroups;
     g.C = a->C; g.ldc = a->ldc; g.C_hi = a->C_hi; g.C_lo = a->C_lo; g.ldc_split = a->ldc_split;
     g.c_rowidx = a->c_rowidx; g.bias = a->bias; g.scale = a->scale; g.resid = a->resid; g.ldr = a->ldr;
-    g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act; g.wide = a->wide; g.ablate = 0;
+    g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act;
+    g.ksplit = a->ksplit; g.c_split_stride = a->c_split_stride;
+    if ((size_t)a->lda * 2 * (size_t)(a->M > 0 ? a->M : 1) >= (1ull << 32))
+        return fail(VH_E_SHAPE, "vh_gemm_ps: activation plane above the 32-bit offset range");
     return check_launch("vh_gemm_ps", vhk_gemm_ps(S(stream), g));
 }
 int vh_split_planes(const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows, int cols, void* stream) {
@@ -227,7 +233,7 @@ struct vh_mixtral {
         px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
         pqkv = cv.take<float>(Sm * nqkv);
         pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
-        ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(2 * Sm * H);
+        ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(2 * 2 * Sm * H);   // py: up to 2 K-split slabs
         pxn_hi = cv.take<uint16_t>(Sm * H); pxn_lo = cv.take<uint16_t>(Sm * H);
         ph_hi = cv.take<uint16_t>(2 * Sm * I); ph_lo = cv.take<uint16_t>(2 * Sm * I);
         ptmp = cv.take<float>(Sm * H);
@@ -433,25 +439,37 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
                 VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
             }
         }
-        VH_TRY(vhk_rmsnorm_route(st, m->px, m->pxn, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter, E, m->pids, m->pwts),
-               "rmsnorm + route");
-        VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
-        if (vh_tuning()->prefill_moe_gemm == 0) {
-            // pre-split path: activations split once, one 192-row m-tile per expert, weights read once
-            VH_TRY(vhk_split_planes(st, m->pxn, H, m->pxn_hi, m->pxn_lo, H, Sn, H), "split planes");
+        const bool stream_moe = vh_tuning()->prefill_moe_gemm == 0;
+        int nslab = 1;
+        const long slab = (long)2 * m->c.max_prefill * H;
+        if (stream_moe) {
+            // weight-streaming path: the norm kernel emits the bf16 hi/lo planes directly, one tall m-tile per
+            // expert (weights cross the fabric once), gate|up emits the planes of h, the down projection is
+            // K-split into `nslab` partial slabs that the combine kernel adds
+            VH_TRY(vhk_rmsnorm_route(st, m->px, nullptr, m->pxn_hi, m->pxn_lo, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter,
+                                     E, m->pids, m->pwts), "rmsnorm + route");
+            VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
             VhGemmPsArgs g{};
             g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; g.lda = H; g.a_rowidx = m->pstok;
             g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
             g.group_off = m->pgoff; g.ngroups = E;
-            g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * Sn; g.N = I; g.K = H;
+            g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * Sn; g.N = I; g.K = H; g.ksplit = 1;
             VH_TRY(vhk_gemm_ps(st, g), "gate/up gemm");
+            nslab = vh_tuning()->moe_ksplit;
+            if (nslab < 1) nslab = 1;
+            if (nslab > 2) nslab = 2;
+            if (nslab > (I >> 6)) nslab = 1;
             VhGemmPsArgs d{};
             d.A_hi = m->ph_hi; d.A_lo = m->ph_lo; d.lda = I;
             d.W = w.w2; d.ldw = I; d.w_group_stride = (long)H * I;
             d.group_off = m->pgoff; d.ngroups = E;
             d.C = m->py; d.ldc = H; d.c_rowidx = m->psslot; d.M = 2 * Sn; d.N = H; d.K = I;
+            d.ksplit = nslab; d.c_split_stride = slab;
             VH_TRY(vhk_gemm_ps(st, d), "down gemm");
         } else {
+            VH_TRY(vhk_rmsnorm_route(st, m->px, m->pxn, nullptr, nullptr, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter, E,
+                                     m->pids, m->pwts), "rmsnorm + route");
+            VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
             {
                 VhGemmArgs g{};
                 g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.a_rowidx = m->pstok; g.nseg = 1; g.seglen = H;
@@ -472,11 +490,11 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
         if (tp) {
             if (hipMemsetAsync(m->ptmp, 0, (size_t)Sn * H * sizeof(float), st) != hipSuccess)
                 return fail(VH_E_HIP, "memset failed");
-            VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H), "combine");
+            VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H, nslab, slab), "combine");
             if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
             VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
         } else {
-            VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H), "combine");
+            VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H, nslab, slab), "combine");
         }
         if (hidden_dbg)
             hipMemcpyAsync(hidden_dbg + (size_t)l * Sn * H, m->px, (size_t)Sn * H * sizeof(float),

@@ -65,66 +65,86 @@ __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, 
 }
 
 // ---- Mixtral prefill: post-attention RMSNorm fused with the top-2 router ------------------
-// One wave per token: the normalised row stays in registers, the 8 router logits are wave
-// reductions over it (modeling_mixtral.py:96-111: logits = x_n Wg^T, fp32 softmax, top-2, renormalise;
-// ties resolve to the lowest expert index like torch.topk).  Replaces a separate routing kernel that
-// re-read x_n (34 us per layer at S=552).
+// One 256-thread block per token: thread t owns the 16-byte chunks t + 256 j of the row, the sum of squares and
+// the 8 router logits are one block reduction (9 values), thread 0 does the fp32 softmax / top-2 / renormalise
+// (modeling_mixtral.py:96-111; ties resolve to the lowest expert index like torch.topk).  The normalised row
+// is written as fp32 and/or as the bf16 hi/lo planes the weight-streaming MoE GEMM consumes (x = hi + lo to
+// 2^-17), so no separate split pass runs.  (Round 1 used one WAVE per row with a serial 8-expert FMA chain:
+// 138 blocks, 75 us for a 9 MB read; this shape is 552 blocks x 128 FMAs per thread.)
+#define RR_MAXJ 4   // chunks per thread -> cols <= 4096
 __global__ __launch_bounds__(256) void k_rmsnorm_route(const float* __restrict__ x, float* __restrict__ y,
+                                                       uint16_t* __restrict__ y_hi, uint16_t* __restrict__ y_lo,
                                                        const float* __restrict__ w, int rows, int cols, float eps,
                                                        const uint16_t* __restrict__ Wg, int E,
                                                        int* __restrict__ ids, float* __restrict__ wts) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wid;
-    if (row >= rows) return;
+    __shared__ float red[4 * 9];
+    const int row = blockIdx.x;
     const int nv = cols >> 2;
     const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)row * cols);
-    f32x4 v[LN_MAXV];
-    float q = 0.f;
+    f32x4 v[RR_MAXJ], g[RR_MAXJ];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + i * 64;
-        v[i] = xp[c < nv ? c : 0];
-        if (c >= nv) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    for (int j = 0; j < RR_MAXJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const int cc = c < nv ? c : 0;
+        v[j] = xp[cc];
+        g[j] = reinterpret_cast<const f32x4*>(w)[cc];
+        if (c >= nv) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float inv = rsqrtf(wave_sum(q) / (float)cols + eps);
-    f32x4* yp = reinterpret_cast<f32x4*>(y + (size_t)row * cols);
-    float lg[8];
+    float vals[9];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) lg[e] = 0.f;
+    for (int e = 0; e < 9; ++e) vals[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            const f32x4 r = v[i] * inv * reinterpret_cast<const f32x4*>(w)[c];
-            yp[c] = r;
+    for (int j = 0; j < RR_MAXJ; ++j) {
+        vals[8] += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+        v[j] = v[j] * g[j];                               // x * w_norm; the scalar 1/rms commutes with the dot products
+    }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (e < E) {
-                    const uint2 g = reinterpret_cast<const uint2*>(Wg + (size_t)e * cols)[c];
-                    lg[e] = fmaf(r[0], bf16_lo_to_f32(g.x), lg[e]);
-                    lg[e] = fmaf(r[1], bf16_hi_to_f32(g.x), lg[e]);
-                    lg[e] = fmaf(r[2], bf16_lo_to_f32(g.y), lg[e]);
-                    lg[e] = fmaf(r[3], bf16_hi_to_f32(g.y), lg[e]);
-                }
+    for (int e = 0; e < 8; ++e) {
+        if (e < E) {
+#pragma unroll
+            for (int j = 0; j < RR_MAXJ; ++j) {
+                const int c = threadIdx.x + j * 256;
+                const uint2 q = reinterpret_cast<const uint2*>(Wg + (size_t)e * cols)[c < nv ? c : 0];
+                float a = vals[e];
+                a = fmaf(v[j][0], bf16_lo_to_f32(q.x), a);
+                a = fmaf(v[j][1], bf16_hi_to_f32(q.x), a);
+                a = fmaf(v[j][2], bf16_lo_to_f32(q.y), a);
+                a = fmaf(v[j][3], bf16_hi_to_f32(q.y), a);
+                vals[e] = a;                              // chunks past the row hold v = 0
             }
         }
     }
+    block256_sum<9>(vals, red);
+    const float inv = rsqrtf(vals[8] / (float)cols + eps);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) lg[e] = wave_sum(lg[e]);
-    float mx = -INFINITY;
+    for (int j = 0; j < RR_MAXJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nv) {
+            const f32x4 r = v[j] * inv;
+            if (y) reinterpret_cast<f32x4*>(y + (size_t)row * cols)[c] = r;
+            if (y_hi) {
+                uint32_t hi[4], lo[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
-    float pr[8], sum = 0.f;
+                for (int i = 0; i < 4; ++i) split_bf16(r[i], hi[i], lo[i]);
+                reinterpret_cast<uint2*>(y_hi + (size_t)row * cols)[c] = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                reinterpret_cast<uint2*>(y_lo + (size_t)row * cols)[c] = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        float lg[8];
+        float mx = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
-    int e0 = 0, e1 = 0;
-    float b0 = -1.f, b1 = -1.f;
+        for (int e = 0; e < 8; ++e) { lg[e] = vals[e] * inv; if (e < E) mx = fmaxf(mx, lg[e]); }
+        float pr[8], sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { pr[e] /= sum; if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; } }
+        for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
+        int e0 = 0, e1 = 0;
+        float b0 = -1.f, b1 = -1.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
-    if (lane == 0) {
+        for (int e = 0; e < 8; ++e) { pr[e] /= sum; if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; } }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
         const float t = b0 + b1;
         ids[row * 2] = e0; ids[row * 2 + 1] = e1;
         wts[row * 2] = b0 / t; wts[row * 2 + 1] = b1 / t;
@@ -304,17 +324,24 @@ __global__ void k_moe_sort(const int* __restrict__ ids, int S, int E, int* __res
     }
 }
 
-// x[s,:] += w0*y[2s,:] + w1*y[2s+1,:]   (MixtralExperts index_add_, modeling_mixtral.py:85-93)
+// x[s,:] += w0 * sum_ks y[ks][2s,:] + w1 * sum_ks y[ks][2s+1,:]   (MixtralExperts index_add_,
+// modeling_mixtral.py:85-93; ks = the K-split slabs of the down projection, added in a fixed order)
 __global__ void k_moe_combine(float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ wts,
-                              int S, int H) {
+                              int S, int H, int nslab, long slab_stride) {
     const long total = (long)S * (H / 4);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long s = i / (H / 4);
         const int c = (int)(i % (H / 4));
         const float w0 = wts[s * 2], w1 = wts[s * 2 + 1];
         float4 a = reinterpret_cast<float4*>(x + s * H)[c];
-        const float4 y0 = reinterpret_cast<const float4*>(y + (2 * s) * H)[c];
-        const float4 y1 = reinterpret_cast<const float4*>(y + (2 * s + 1) * H)[c];
+        float4 y0 = reinterpret_cast<const float4*>(y + (2 * s) * H)[c];
+        float4 y1 = reinterpret_cast<const float4*>(y + (2 * s + 1) * H)[c];
+        for (int k = 1; k < nslab; ++k) {
+            const float4 p0 = reinterpret_cast<const float4*>(y + k * slab_stride + (2 * s) * H)[c];
+            const float4 p1 = reinterpret_cast<const float4*>(y + k * slab_stride + (2 * s + 1) * H)[c];
+            y0.x += p0.x; y0.y += p0.y; y0.z += p0.z; y0.w += p0.w;
+            y1.x += p1.x; y1.y += p1.y; y1.z += p1.z; y1.w += p1.w;
+        }
         a.x += w0 * y0.x + w1 * y1.x; a.y += w0 * y0.y + w1 * y1.y;
         a.z += w0 * y0.z + w1 * y1.z; a.w += w0 * y0.w + w1 * y1.w;
         reinterpret_cast<float4*>(x + s * H)[c] = a;
@@ -395,11 +422,12 @@ int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, co
                        S, H);
     return 0;
 }
-int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps,
-                      const uint16_t* Wg, int E, int* ids, float* wts) {
-    if (cols % 4 != 0 || cols > LN_MAXV * 256 || E < 2 || E > 8) return -1;
+int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
+                      int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts) {
+    if (cols % 4 != 0 || cols > RR_MAXJ * 1024 || E < 2 || E > 8 || (y_hi && !y_lo) || (!y && !y_hi)) return -1;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(k_rmsnorm_route, dim3((rows + 3) / 4), dim3(256), 0, st, x, y, w, rows, cols, eps, Wg, E, ids, wts);
+    hipLaunchKernelGGL(k_rmsnorm_route, dim3(rows), dim3(256), 0, st, x, y, y_hi, y_lo, w, rows, cols, eps, Wg, E, ids,
+                       wts);
     return 0;
 }
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot) {
@@ -407,9 +435,11 @@ int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, i
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(64 * E), 0, st, ids, S, E, group_off, sorted_tok, sorted_slot);
     return 0;
 }
-int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H) {
-    if (H % 4 != 0) return -1;
+int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H, int nslab,
+                    long slab_stride) {
+    if (H % 4 != 0 || nslab < 1 || (slab_stride % 4) != 0) return -1;
     if (S == 0) return 0;
-    hipLaunchKernelGGL(k_moe_combine, dim3(grid_for((long)S * (H / 4), 256)), dim3(256), 0, st, x, y, wts, S, H);
+    hipLaunchKernelGGL(k_moe_combine, dim3(grid_for((long)S * (H / 4), 256)), dim3(256), 0, st, x, y, wts, S, H, nslab,
+                       slab_stride);
     return 0;
 }

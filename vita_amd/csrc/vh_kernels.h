@@ -10,11 +10,14 @@ struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
     int gemv_rows = 4;        // rows per block of the decode QKV / O GEMVs: 4 (12.9 / 8.3 us), 8 (13.1 / 9.4), 16 (15.8 / 11.7)
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
-    int prefill_moe_gemm = 1; // MoE prefill GEMMs: 1 = general kernel (fastest), 0 = pre-split skinny glds kernel (vh_gemm_ps)
+    int prefill_moe_gemm = 0; // MoE prefill GEMMs: 0 = weight-streaming pre-split kernel (vh_gemm_ps, default), 1 = general kernel
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
     int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
     int gemm_prefetch = 2;    // general GEMM: 1 = one K-tile in flight, 2 = two for plain GEMMs (default), 3 = two everywhere
-    int ps_ablate = 0;        // timing experiments on vh_gemm_ps (wrong results when non-zero)
+    int ps_cfg = -1;          // vh_gemm_ps variant: -1 = by rows per group, 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights
+    int ps_grid = 0;          // vh_gemm_ps persistent grid (0 = one block per CU)
+    int ps_nt = -1;           // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
+    int moe_ksplit = 2;       // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel)
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
 };
 VhTuning* vh_tuning();
@@ -57,7 +60,7 @@ struct VhGemmArgs {
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
 
-// ---- pre-split skinny GEMM (vh_gemm_ps.hip) ------------------------------------------
+// ---- weight-streaming GEMM on pre-split activations (vh_gemm_ps.hip) -------------------
 // C[orow(m), n] = epilogue( sum_k (A_hi + A_lo)[arow(m), k] * W[n, k] ), A as bf16 hi/lo planes.  K % 64 == 0.
 struct VhGemmPsArgs {
     const uint16_t* A_hi; const uint16_t* A_lo; long lda;   // planes [rows][lda] bf16
@@ -69,8 +72,7 @@ struct VhGemmPsArgs {
     const int* c_rowidx;
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
-    int ablate;                                              // debug: 1 skip A loads, 2 skip W loads, 4 skip MFMA
-    int wide;                                                // plain mode: 256-column tiles (512 threads) instead of 128
+    int ksplit; long c_split_stride;                         // K split: partial sums go to C + ks * c_split_stride (plain fp32 output only)
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
 int vhk_split_planes(hipStream_t st, const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows,
@@ -108,8 +110,9 @@ int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, floa
                 const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx);
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
                      const float* img_feats, const float* aud_feats, float* out, int S, int H);
-int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps,
-                      const uint16_t* Wg, int E, int* ids, float* wts);
+int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
+                      int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts);
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot);
-int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H);
+int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H, int nslab,
+                    long slab_stride);
 int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n);
