@@ -105,16 +105,51 @@ def main():
     host["logo_small"] = np.asarray(img.resize((64, 18)))  # the input travels as a small thumbnail only for docs
     np.savez_compressed(os.path.join(GOLD, "host_logic.npz"), **host)
 
-    # ---- audio front end: the reference's q1.wav and its fbank by the HF-numpy pipeline -----------
-    from transformers.audio_utils import spectrogram, window_function
-    from vita_amd.audio_frontend import kaldi_mel_banks, load_wav
+    # ---- audio front end (A4) ---------------------------------------------------------------------------
+    # fbank              : asset/q1.wav through oracle/kaldi_fbank.py — an independent scalar restatement of
+    #                      torchaudio.compliance.kaldi.fbank (the HF path's dependency, init_model.py:46-56)
+    # whale_numpy_*      : the SAME clip through the reference's OWN vLLM-flavour extractor, loaded from
+    #                      web_demo/vllm_tools/model_weight_file/processor_whale.py (its numpy fallback: torchaudio
+    #                      is not installed here), dither 0: raw log-mel and the CMVN-normalised input_features
+    import importlib.util
+    import json
+    from oracle import kaldi_fbank as okf
+    from vita_amd.audio_frontend import load_wav
     w, sr = load_wav(os.path.join(rh.REF, "asset", "q1.wav"))
-    mf = np.pad(kaldi_mel_banks().T, ((0, 1), (0, 0)))
-    fb = spectrogram((w * (2 ** 15)).astype(np.float32), window_function(400, "povey", periodic=False),
-                     frame_length=400, hop_length=160, fft_length=512, power=2.0, center=False, preemphasis=0.97,
-                     mel_filters=mf, log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
-    np.savez_compressed(os.path.join(GOLD, "q1_audio.npz"), pcm16=np.round(w * 32768).astype(np.int16), sr=sr,
-                        fbank=np.ascontiguousarray(fb, dtype=np.float32))
+    pcm16 = np.round(w * 32768).astype(np.int16)
+    fb = okf.fbank(pcm16.astype(np.float64), float(sr))
+    mdir = os.path.join(rh.REF, "web_demo", "vllm_tools", "model_weight_file")
+    spec = importlib.util.spec_from_file_location("ref_processor_whale", os.path.join(mdir, "processor_whale.py"))
+    pw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pw)
+    with open(os.path.join(mdir, "feature_extractor", "preprocessor_config.json")) as f:
+        pc = json.load(f)
+    fe = pw.WhaleFeatureExtractor(**{**pc, "dither": 0.0})
+    wf = (pcm16.astype(np.float32) / 32768.0)
+    raw = fe._extract_fbank_features(wf[None])
+    feats = fe(wf, sampling_rate=int(sr), return_tensors="np")["input_features"][0]
+    np.savez_compressed(os.path.join(GOLD, "q1_audio.npz"), pcm16=pcm16, sr=sr,
+                        fbank=np.ascontiguousarray(fb, dtype=np.float32),
+                        whale_numpy_fbank=np.ascontiguousarray(raw, dtype=np.float32),
+                        whale_numpy_input_features=np.ascontiguousarray(feats, dtype=np.float32))
+    # ---- vLLM-flavour placeholder expansion (f#1): the reference's OWN repeat_and_pad_image_tokens and
+    # get_audio_feature_size, cut out of web_demo/vllm_tools/vllm_file/mixtral.py (the module itself needs vllm),
+    # with the tile counts of the reference's dynamic_preprocess --------------------------------------------
+    fx = rh.extract_functions(os.path.join(rh.REF, "web_demo", "vllm_tools", "vllm_file", "mixtral.py"),
+                              ["repeat_and_pad_image_tokens", "get_audio_feature_size"])
+    IMG, AUD = 51000, 51001
+    ex_ids = [1, 5, 6, IMG, 7, AUD, 8, IMG, 9, AUD, 10]
+    ex_sizes = [(448, 448), (1000, 500)]
+    ex_frames = [352, 998]
+    ex_tiles = [len(dynamic_preprocess(Image.new("RGB", wh), min_num=1, max_num=12, image_size=448, use_thumbnail=True)[0])
+                for wh in ex_sizes]
+    _, ids1 = fx["repeat_and_pad_image_tokens"](None, None, list(ex_ids), image_token_id=IMG,
+                                                repeat_count=[256 * n for n in ex_tiles])
+    aud_sizes = [fx["get_audio_feature_size"](torch.zeros(n, 80)) for n in ex_frames]
+    _, ids2 = fx["repeat_and_pad_image_tokens"](None, None, ids1, image_token_id=AUD, repeat_count=list(aud_sizes))
+    np.savez_compressed(os.path.join(GOLD, "vllm_expand.npz"), ids=np.asarray(ex_ids), sizes=np.asarray(ex_sizes),
+                        frames=np.asarray(ex_frames), tiles=np.asarray(ex_tiles), audio_sizes=np.asarray(aud_sizes),
+                        new_token_ids=np.asarray(ids2))
     print("golden written:", sorted(os.listdir(GOLD)))
     print("gen ids:", gen_ids)
 

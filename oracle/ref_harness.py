@@ -203,3 +203,27 @@ def reference_inputs_embeds(cfg, sd, input_ids, images, audios, lengths):
             host, torch.as_tensor(input_ids)[None], None, None, None, None, torch.from_numpy(images),
             {"audios": torch.from_numpy(audios)[None], "lengths": torch.as_tensor([lengths])})
     return out[4][0].numpy()
+
+
+def extract_functions(path, names):
+    """Run selected `def`s of a reference file whose module cannot be imported here (its other imports are absent:
+    vllm) — the FunctionDef nodes are cut out of the file's AST, nested ones included, and executed unchanged."""
+    import ast
+    import typing
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {k: getattr(typing, k) for k in ("Optional", "List", "Tuple", "Union", "TypeVar")}
+    ns["_T"] = typing.TypeVar("_T", str, int)
+    ns["PreTrainedTokenizerBase"] = object
+    import torch
+    ns["torch"] = torch
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names and node.name not in found:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), ns)
+            found[node.name] = ns[node.name]
+    missing = set(names) - set(found)
+    if missing:
+        raise KeyError(f"{path}: no function(s) {sorted(missing)}")
+    return found

@@ -70,14 +70,113 @@ def test_stopping_criteria_and_names():
     assert get_model_name_from_path("/a/run/checkpoint-100") == "run_checkpoint-100"
 
 
-def test_fbank_matches_golden_and_token_count():
+def test_fbank_matches_independent_oracle_and_token_count():
+    """A4 (HF path): the product's vectorised Kaldi fbank against the fixture written by oracle/kaldi_fbank.py — an
+    independent scalar restatement of torchaudio.compliance.kaldi.fbank (the dependency init_model.py:46-56 calls)."""
     from vita_amd.audio_frontend import kaldi_fbank
     from vita_amd.config import audio_token_count
     g = np.load(os.path.join(GOLD, "q1_audio.npz"))
     fb = kaldi_fbank(g["pcm16"].astype(np.float64), int(g["sr"]))
     assert fb.shape == (352, 80)                       # SURVEY F6(b): q1.wav = 3.54 s -> 352 frames
-    assert np.abs(fb - g["fbank"]).max() < 1e-4
+    assert np.abs(fb - g["fbank"]).max() < 1e-5
     assert audio_token_count(352) == 44 and audio_token_count(998) == 124 and audio_token_count(400) == 50
+
+
+def test_oracle_fbank_live_equals_fixture():
+    """the committed fixture is what oracle/kaldi_fbank.py computes (first 40 frames re-run here)."""
+    from oracle import kaldi_fbank as okf
+    g = np.load(os.path.join(GOLD, "q1_audio.npz"))
+    n = 400 + 160 * 39
+    fb = okf.fbank(g["pcm16"][:n].astype(np.float64), float(g["sr"]))
+    assert fb.shape == (40, 80) and np.array_equal(fb, g["fbank"][:40])
+
+
+def test_kaldi_mel_banks_hand_checked():
+    """torchaudio get_mel_banks by hand: mel(f) = 1127 ln(1 + f/700), 80 triangles between mel(20) and mel(8000),
+    FFT bin width 16000/512 = 31.25 Hz.  A few weights worked out from the closed form, the partition-of-unity of
+    neighbouring triangles, and the zero weight of bins outside [20 Hz, Nyquist)."""
+    from vita_amd.audio_frontend import kaldi_mel_banks
+    from oracle import kaldi_fbank as okf
+    B = kaldi_mel_banks()
+    assert B.shape == (80, 256)
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    lo, hi = mel(20.0), mel(8000.0)
+    d = (hi - lo) / 81.0
+    # bin 0: left = mel(20), centre = left + d; FFT bin 1 (31.25 Hz) sits on its rising edge
+    assert abs(B[0, 1] - (mel(31.25) - lo) / d) < 1e-12 and B[0, 0] == 0.0          # 0 Hz is below 20 Hz
+    # FFT bin 100 (3125 Hz): between centres j and j+1 -> the two weights are (1 - t) and t
+    j = int((mel(3125.0) - lo) / d) - 1
+    t = (mel(3125.0) - (lo + (j + 1) * d)) / d
+    assert abs(B[j, 100] - (1 - t)) < 1e-12 and abs(B[j + 1, 100] - t) < 1e-12 and abs(B[:, 100].sum() - 1.0) < 1e-12
+    assert np.count_nonzero(B[:, 100]) == 2
+    # last triangle ends exactly at Nyquist; the highest FFT bin (7968.75 Hz) is on its falling edge
+    assert abs(B[79, 255] - (hi - mel(7968.75)) / d) < 1e-12
+    assert np.abs(B - np.asarray(okf.get_mel_banks(80, 512, 16000.0))).max() < 1e-12   # the oracle's scalar loops
+
+
+def test_whale_extractor_numpy_variant_vs_reference_and_documented_deviation():
+    """f#1: WhaleFeatureExtractor(mel_variant="hf_numpy") reproduces the reference's OWN extractor
+    (web_demo/vllm_tools/model_weight_file/processor_whale.py run here by oracle/make_golden.py: numpy fallback,
+    dither 0), and the default Kaldi filter bank deviates from that fallback by the documented amounts
+    (filters up to 0.117, q1.wav log-mel up to 2.95: the fallback uses an FFT bin width of sr/510)."""
+    from vita_amd.audio_frontend import WhaleFeatureExtractor, kaldi_fbank, kaldi_mel_banks
+    g = np.load(os.path.join(GOLD, "q1_audio.npz"))
+    wav = g["pcm16"].astype(np.float32) / 32768.0
+    raw = kaldi_fbank(g["pcm16"].astype(np.float64), int(g["sr"]), mel_variant="hf_numpy")
+    assert np.abs(raw - g["whale_numpy_fbank"]).max() < 1e-5
+    out = WhaleFeatureExtractor(mel_variant="hf_numpy")(wav, sampling_rate=int(g["sr"]))
+    assert out["input_features"].shape == (1, 352, 80) and out["attention_mask"].sum() == 352
+    assert np.abs(out["input_features"][0] - g["whale_numpy_input_features"]).max() < 1e-5
+    fdiff = np.abs(kaldi_mel_banks() - kaldi_mel_banks(variant="hf_numpy")).max()
+    assert 0.11 < fdiff < 0.12
+    dev = np.abs(g["fbank"] - g["whale_numpy_fbank"])
+    assert 2.9 < dev.max() < 3.0 and 0.08 < dev.mean() < 0.095
+    with pytest.raises(ValueError):
+        kaldi_mel_banks(variant="slaney")
+
+
+def test_clip_image_processor_equals_hf():
+    """A3: the host image processor against the installed HF CLIPImageProcessor configured as the reference's
+    preprocessor_config.json (448 shortest edge, bicubic, centre crop, ImageNet mean/std): bit-identical on random
+    non-square images."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    from vita_amd.host.image_processing import IMAGENET_MEAN, IMAGENET_STD, make_image_processor
+    ref = CLIPImageProcessor(size={"shortest_edge": 448}, crop_size={"height": 448, "width": 448}, do_resize=True,
+                             do_center_crop=True, do_normalize=True, do_rescale=True, do_convert_rgb=True,
+                             image_mean=list(IMAGENET_MEAN), image_std=list(IMAGENET_STD), resample=3)
+    ip = make_image_processor(448)
+    rng = np.random.default_rng(5)
+    for (w, h) in [(448, 448), (640, 360), (301, 977), (1280, 720), (97, 53)]:
+        img = Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        a = ip.preprocess(img, return_tensors="pt")["pixel_values"].numpy()
+        b = ref.preprocess(img, return_tensors="np")["pixel_values"]
+        assert a.shape == b.shape == (1, 3, 448, 448)
+        assert np.array_equal(a, np.asarray(b, dtype=a.dtype)), (w, h, np.abs(a - b).max())
+
+
+def test_vllm_placeholder_expansion_vs_reference_function():
+    """f#1: serving.expand_placeholders + the splice widths against `new_token_ids` of the reference's OWN
+    repeat_and_pad_image_tokens / get_audio_feature_size (mixtral.py:100-190,283-287, executed by
+    oracle/make_golden.py), and the same case evaluated by hand."""
+    from PIL import Image
+    from vita_amd.host.constants import AUDIO_TOKEN_INDEX, IMAGE_TOKEN_INDEX
+    from vita_amd.serving import audio_feature_size, expand_placeholders, expanded_token_ids
+    g = np.load(os.path.join(GOLD, "vllm_expand.npz"))
+    IMG, AUD = 51000, 51001
+    ids = g["ids"].tolist()
+    images = [Image.new("RGB", tuple(int(v) for v in wh)) for wh in g["sizes"]]
+    frames = g["frames"].tolist()
+    sent, tiles = expand_placeholders(ids, images, [np.zeros((n, 80), np.float32) for n in frames],
+                                      image_token_index=IMG, audio_token_index=AUD, image_size=448)
+    assert len(tiles) == int(g["tiles"].sum()) == 4 and [audio_feature_size(n) for n in frames] == g["audio_sizes"].tolist()
+    assert sent == [1, 5, 6, IMAGE_TOKEN_INDEX, 7, AUDIO_TOKEN_INDEX, 8] + [IMAGE_TOKEN_INDEX] * 3 + [9, AUDIO_TOKEN_INDEX, 10]
+    full = expanded_token_ids(sent, frames, image_token_index=IMG, audio_token_index=AUD)
+    assert full == g["new_token_ids"].tolist()
+    by_hand = [1, 5, 6] + [IMG] * 256 + [7] + [AUD] * 44 + [8] + [IMG] * 768 + [9] + [AUD] * 124 + [10]
+    assert full == by_hand
+    with pytest.raises(ValueError):
+        expand_placeholders(ids, images[:1], [None, None], image_token_index=IMG, audio_token_index=AUD, image_size=448)
 
 
 def test_image_processor_normalisation():

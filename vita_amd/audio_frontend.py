@@ -22,11 +22,23 @@ def _mel(f):
     return 1127.0 * np.log(1.0 + f / 700.0)
 
 
-def kaldi_mel_banks(num_bins=80, n_fft=512, sample_rate=16000, low=20.0, high=0.0):
+def kaldi_mel_banks(num_bins=80, n_fft=512, sample_rate=16000, low=20.0, high=0.0, variant="kaldi"):
+    """Triangular filters on the Kaldi mel scale, triangularised in mel space.
+    variant "kaldi": torchaudio.compliance.kaldi.get_mel_banks (FFT bin width = sample_rate / n_fft) — what the
+      reference's HF path computes (whale/init_model.py:46-56 -> kaldi.fbank).
+    variant "hf_numpy": the filter bank of the reference's vLLM-flavour extractor when torchaudio is absent
+      (processor_whale.py:127-140: transformers.audio_utils.mel_filter_bank(num_frequency_bins=256, ...,
+      triangularize_in_mel_space=True)), whose FFT bin width is sample_rate / (2 * 255): the filters differ from
+      Kaldi's by up to 0.117 and the log-mel features of asset/q1.wav by up to 2.95 (tests/test_host_logic.py)."""
     nyq = 0.5 * sample_rate
     if high <= 0.0:
         high += nyq
-    fft_bin_width = sample_rate / n_fft
+    if variant == "hf_numpy":
+        fft_bin_width = sample_rate / ((n_fft // 2 - 1) * 2)
+    elif variant == "kaldi":
+        fft_bin_width = sample_rate / n_fft
+    else:
+        raise ValueError(f"unknown mel filter bank variant {variant!r}")
     mel_lo, mel_hi = _mel(low), _mel(high)
     delta = (mel_hi - mel_lo) / (num_bins + 1)
     b = np.arange(num_bins, dtype=np.float64)[:, None]
@@ -41,7 +53,7 @@ def povey_window(n):
 
 
 def kaldi_fbank(waveform, sample_rate=16000, num_mel_bins=80, frame_length_ms=25.0, frame_shift_ms=10.0,
-                dither=0.0, preemphasis=0.97, rng=None):
+                dither=0.0, preemphasis=0.97, rng=None, mel_variant="kaldi"):
     """waveform: 1-D float array already scaled to the int16 range (the reference multiplies by
     1<<15, init_model.py:46).  Returns float32 [num_frames, num_mel_bins]."""
     x = np.asarray(waveform, dtype=np.float64).reshape(-1)
@@ -62,7 +74,7 @@ def kaldi_fbank(waveform, sample_rate=16000, num_mel_bins=80, frame_length_ms=25
     fr = fr * povey_window(win)[None, :]
     spec = np.fft.rfft(fr, n=n_fft, axis=1)
     power = (spec.real ** 2 + spec.imag ** 2)[:, : n_fft // 2]
-    mel = power @ kaldi_mel_banks(num_mel_bins, n_fft, sample_rate).T
+    mel = power @ kaldi_mel_banks(num_mel_bins, n_fft, sample_rate, variant=mel_variant).T
     return np.log(np.maximum(mel, EPS)).astype(np.float32)
 
 
@@ -110,13 +122,17 @@ class WhaleFeatureExtractor:
     CMVN with the PRELOADED means / inverse stds (utterance_cmvn with cmvn_means/cmvn_istds, :211-233), so the
     audio tower receives normalised features.  Call: extractor(waveform [1, n] or [n] in [-1, 1),
     sampling_rate=16000, return_tensors="pt") -> {"input_features": [1, T, 80], "attention_mask": [1, T]}.
-    dither is pinned to 0 (the shipped preprocessor_config.json says 1.0 = random noise per call)."""
+    dither is pinned to 0 (the shipped preprocessor_config.json says 1.0 = random noise per call).
+    mel_variant: "kaldi" (default) = torchaudio's filter bank, i.e. what the reference extractor computes when
+    torchaudio is installed (processor_whale.py:179-191) and what the audio tower was trained on;
+    "hf_numpy" = bit-compatible with its numpy fallback (processor_whale.py:127-140,192-206), see kaldi_mel_banks."""
 
     def __init__(self, sampling_rate=16000, num_mel_bins=80, frame_length=25, frame_shift=10, cmvn_means=None,
-                 cmvn_istds=None, **_):
+                 cmvn_istds=None, mel_variant="kaldi", **_):
         from .checkpoint import vendored_cmvn
         self.sampling_rate, self.num_mel_bins = sampling_rate, num_mel_bins
         self.frame_length, self.frame_shift = frame_length, frame_shift
+        self.mel_variant = mel_variant
         if cmvn_means is None or cmvn_istds is None:
             cmvn_means, cmvn_istds = vendored_cmvn(num_mel_bins)
         self.cmvn_means = np.asarray(cmvn_means, np.float32)
@@ -141,7 +157,7 @@ class WhaleFeatureExtractor:
             g = math.gcd(int(sampling_rate), int(self.sampling_rate))
             x = resample_poly(x, self.sampling_rate // g, sampling_rate // g)
         feats = kaldi_fbank(x * (1 << 15), self.sampling_rate, self.num_mel_bins, self.frame_length, self.frame_shift,
-                            dither=0.0)
+                            dither=0.0, mel_variant=self.mel_variant)
         feats = ((feats - self.cmvn_means[None]) * self.cmvn_istds[None]).astype(np.float32)
         mask = np.ones((1, feats.shape[0]), np.int32)
         out = {"input_features": feats[None], "attention_mask": mask}

@@ -63,6 +63,50 @@ def audio_feature_size(n_frames: int) -> int:
     return (down - 1) // 2 + 1
 
 
+def expand_placeholders(ids, images, audios, *, image_token_index, audio_token_index, image_size, min_dynamic_patch=1,
+                        max_dynamic_patch=12, use_thumbnail=True, limit_mm=None):
+    """The plugin's input processor (web_demo/vllm_tools/vllm_file/mixtral.py:194-295) in the HF-flavour vocabulary:
+    every image placeholder becomes one IMAGE sentinel per TILE of dynamic_preprocess (+ thumbnail), every audio
+    placeholder one AUDIO sentinel; the splice later widens a sentinel to 256 tokens per tile / audio_feature_size
+    tokens per clip, which is the reference's repeat_and_pad_image_tokens (:100-190) with repeat counts
+    256 * tiles and ((T-1)//2-1)//2 -> (.-1)//2+1 (:283-287).  Returns (sentinel ids, tiles)."""
+    limit_mm = limit_mm or {}
+    n_img, n_aud = ids.count(image_token_index), ids.count(audio_token_index)
+    if n_img != len(images) or n_aud != len(audios):
+        raise ValueError(f"prompt has {n_img} image / {n_aud} audio placeholders but multi_modal_data holds "
+                         f"{len(images)} / {len(audios)}")                    # mixtral.py:136-140,1110-1124
+    if len(images) > limit_mm.get("image", 256) or len(audios) > limit_mm.get("audio", 50):
+        raise ValueError("limit_mm_per_prompt exceeded")
+    tiles, out, ii = [], [], 0
+    for t in ids:
+        if t == image_token_index:
+            ts, _ = dynamic_preprocess(images[ii], min_num=min_dynamic_patch, max_num=max_dynamic_patch,
+                                       image_size=image_size, use_thumbnail=use_thumbnail)
+            tiles += ts
+            out += [IMAGE_TOKEN_INDEX] * len(ts)
+            ii += 1
+        elif t == audio_token_index:
+            out.append(AUDIO_TOKEN_INDEX)
+        else:
+            out.append(int(t))
+    return out, tiles
+
+
+def expanded_token_ids(sentinel_ids, audio_frames, *, image_token_index, audio_token_index, tokens_per_tile=256):
+    """The id sequence the reference's input processor hands to vLLM (`new_token_ids`, mixtral.py:175-190,289-295),
+    rebuilt from the sentinel form: what the spliced embedding sequence corresponds to, position by position."""
+    out, ai = [], 0
+    for t in sentinel_ids:
+        if t == IMAGE_TOKEN_INDEX:
+            out += [image_token_index] * tokens_per_tile
+        elif t == AUDIO_TOKEN_INDEX:
+            out += [audio_token_index] * audio_feature_size(audio_frames[ai])
+            ai += 1
+        else:
+            out.append(int(t))
+    return out
+
+
 class LLM:
     def __init__(self, model, dtype=None, tensor_parallel_size=1, trust_remote_code=True, gpu_memory_utilization=None,
                  disable_custom_all_reduce=True, limit_mm_per_prompt=None, max_new_tokens=1024, device="cuda", **_):
@@ -94,27 +138,11 @@ class LLM:
 
     # ---- one request ----------------------------------------------------------------------------
     def _expand(self, ids, images, audios):
-        """placeholders -> sentinels of the HF-flavour splice: one IMAGE sentinel per TILE, one AUDIO per clip."""
-        n_img, n_aud = ids.count(self.image_token_index), ids.count(self.audio_token_index)
-        if n_img != len(images) or n_aud != len(audios):
-            raise ValueError(f"prompt has {n_img} image / {n_aud} audio placeholders but multi_modal_data holds "
-                             f"{len(images)} / {len(audios)}")                # mixtral.py:244-247,1110-1124
-        if len(images) > self.limit_mm.get("image", 256) or len(audios) > self.limit_mm.get("audio", 50):
-            raise ValueError("limit_mm_per_prompt exceeded")
-        size = self.image_processor.crop_size["height"]
-        tiles, out, ii = [], [], 0
-        for t in ids:
-            if t == self.image_token_index:
-                ts, _ = dynamic_preprocess(images[ii], min_num=self.min_dynamic_patch, max_num=self.max_dynamic_patch,
-                                           image_size=size, use_thumbnail=self.use_thumbnail)
-                tiles += ts
-                out += [IMAGE_TOKEN_INDEX] * len(ts)
-                ii += 1
-            elif t == self.audio_token_index:
-                out.append(AUDIO_TOKEN_INDEX)
-            else:
-                out.append(int(t))
-        return out, tiles
+        return expand_placeholders(ids, images, audios, image_token_index=self.image_token_index,
+                                   audio_token_index=self.audio_token_index,
+                                   image_size=self.image_processor.crop_size["height"],
+                                   min_dynamic_patch=self.min_dynamic_patch, max_dynamic_patch=self.max_dynamic_patch,
+                                   use_thumbnail=self.use_thumbnail, limit_mm=self.limit_mm)
 
     @torch.no_grad()
     def _one(self, inp, sp: SamplingParams, streamer=None):
