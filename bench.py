@@ -191,8 +191,6 @@ def main():
 
     from vita_amd.checkpoint import synth_mixtral_device, synth_state_dict
     from vita_amd.config import VitaConfig, audio_token_count
-    from vita_amd.audio_frontend import kaldi_fbank
-    from vita_amd.host.constants import AUDIO_TOKEN_INDEX, IMAGE_TOKEN_INDEX
     from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
 
     if args.tune:
@@ -225,16 +223,12 @@ def main():
     t_build = time.time() - t0
 
     # ---- synthetic request: 1 image tile + 10 s audio + text (configs[2]) -----------------------------
-    g = torch.Generator(device="cpu").manual_seed(2)
-    image = ((torch.rand((args.frames, 3, 448, 448), generator=g) - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
-             / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)).to(dev)
-    wav = 0.1 * np.random.default_rng(3).standard_normal(160000)
-    feats = kaldi_fbank(wav * (1 << 15), 16000)                      # [998, 80]
+    from vita_amd.host.synthetic import make_request
+    req = make_request(cfg, frames=args.frames, text_tokens=args.text_tokens)   # the request tests/test_realgeom_gpu.py checks
+    image = torch.from_numpy(req["pixel_values"]).to(dev)
+    feats = req["fbank"]                                                      # [998, 80]
     n_aud_tok = audio_token_count(feats.shape[0])
-    rng = np.random.default_rng(1)
-    sys_ids = rng.integers(3, 51000, size=139).tolist()              # stand-in for the ~140-token system prompt
-    txt_ids = rng.integers(3, 51000, size=args.text_tokens).tolist()
-    ids = [t.bos_token_id] + sys_ids + [IMAGE_TOKEN_INDEX] * args.frames + txt_ids + [AUDIO_TOKEN_INDEX]
+    ids = req["input_ids"]
     input_ids = torch.tensor([ids], dtype=torch.long, device=dev)
     audios = {"audios": torch.from_numpy(feats)[None].to(dev), "lengths": torch.tensor([feats.shape[0]], device=dev)}
 

@@ -107,6 +107,11 @@ int vh_layernorm(const float* x, long ldx, float* y, long ldy, const float* w, c
 int vh_rmsnorm(const float* x, float* y, const float* w, int rows, int cols, float eps, void* stream);
 int vh_add(float* x, const float* y, long n, void* stream);
 int vh_cast_bf16_f32(const uint16_t* in, float* out, long n, void* stream);
+/* Synthetic bf16 weights from a counter-based generator whose values are exact in bf16 (integers in [-126, 126] x 2^-11,
+ * sigma 0.018): element (r, c) of the [rows, cols] view is sample idx0 + r * ld_src + c of stream `seed`, so shards of a
+ * logical tensor hold the full tensor's values.  The host twin is oracle/hashfill.c — identical weights on both sides
+ * at any size (no checkpoint exists offline: SURVEY 8(d)). */
+int vh_fill_hash_bf16(uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0, uint64_t seed, void* stream);
 
 /* InternViT front/back (modeling_intern_vit.py:68-122; internvit_encoder.py:35-79). */
 int vh_vit_patchify(const float* pix, float* out, int n, int img, int patch, int kpad, void* stream);
@@ -166,6 +171,9 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* unique_id_128_bytes /* hos
  * out_tokens[0] (greedy) and the engine ready to decode.  If logits_out != NULL the fp32
  * logits of the last position are copied there ([vocab]).  hidden_dbg (nullable): fp32
  * [n_layers][S][hidden] receives the residual stream after every layer.                   */
+/* Debug / parity hook: the top-2 expert ids of every layer of the following prefills are copied to ids_out
+ * (device int[n_layers][S][2]; null switches it off) — SURVEY 8(c) golden list "router top-2 ids per layer". */
+int vh_mixtral_route_debug(vh_mixtral_t* m, int* ids_out);
 int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, float* logits_out, float* hidden_dbg,
                        void* stream);
 /* Run n_steps greedy decode steps back to back with no host interaction. */

@@ -1,6 +1,6 @@
 """Full BASELINE geometry (VITA-Mixtral-8x7B: 32 layers, 4096 hidden, 8 experts top-2, vocab 51760 —
-93.7 GB of bf16 weights generated on the GPU).  The fp32 oracle cannot run at this size (187 GB),
-so parity is checked through size-independent properties of the path:
+93.7 GB of bf16 weights generated on the GPU).  The oracle comparison at this size is tests/test_realgeom_gpu.py
+(layer-streamed fp32 oracle on the bench's own request); this file adds the size-independent properties of the path:
 
   * the two implementations of the SAME function must agree: a decode step (GEMV kernels, split-KV
     attention, on-device routing) == the last row of a prefill (MFMA GEMMs, flash attention, sorted

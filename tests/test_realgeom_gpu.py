@@ -1,0 +1,114 @@
+"""Parity on the HEADLINE configuration (BASELINE configs[2], the request bench.py times) at the RELEASED geometry:
+24-layer InternViT + projector, 24-layer Whale + adapter, 32-layer Mixtral-8x7B with the full vocabulary, prefill
+S = 552 and 16 greedy steps — device vs the layer-streamed fp32 oracle (oracle/stream.py) on identical weights
+(counter-based generator, same integers on both sides).  SURVEY 8(c) golden list: encoder outputs, spliced
+inputs_embeds, hidden states after layers 0 / 15 / 31, router top-2 ids of every layer, last-row logits within 1e-3,
+greedy ids bit-exact (vita/model/language_model/vita_mixtral.py:158-173; video_audio_demo.py:257-270).
+
+VITA_REALGEOM_LAYERS=n shortens the backbone for a quick run (default: all 32 layers)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoders as oe, hashw, stream
+from tests.util import assert_close, report, to_np
+from vita_amd.checkpoint import synth_mixtral_device, synth_state_dict
+from vita_amd.config import VitaConfig
+from vita_amd.host.synthetic import make_request
+
+pytestmark = pytest.mark.gpu
+T_NEW = 16
+SEED = 0
+
+
+@pytest.fixture(scope="module")
+def run(dev):
+    from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
+    cfg = VitaConfig()
+    cfg.text.num_hidden_layers = int(os.environ.get("VITA_REALGEOM_LAYERS", cfg.text.num_hidden_layers))
+    t0 = time.time()
+    packed = synth_mixtral_device(cfg, dev, seed=SEED)
+    sd_enc = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
+    model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=T_NEW + 8, max_prefill=1024,
+                                   keep_scores=True)
+    model.get_vision_tower().load_model()
+    req = make_request(cfg)
+    pix = torch.from_numpy(req["pixel_values"]).to(dev)
+    feats = torch.from_numpy(req["fbank"]).to(dev)
+    ids = torch.tensor([req["input_ids"]], dtype=torch.long, device=dev)
+    audios = {"audios": feats[None], "lengths": torch.tensor([feats.shape[0]], device=dev)}
+    vit = model.get_vision_tower()(pix)
+    img = model.model.mm_projector(vit)
+    aud = model.get_audio_encoder()(audios["audios"], audios["lengths"])
+    _, _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix, audios)
+    eng = model.engine
+    _, hid = eng.prefill(emb[0], want_hidden=True, want_route=True)
+    route = eng.route_ids
+    eng.decode(T_NEW - 1)
+    torch.cuda.synchronize()
+    out = dict(cfg=cfg, sd_enc=sd_enc, req=req, vit=to_np(vit), img=to_np(img), aud=to_np(aud["inputs_embeds"]),
+               aud_mask=to_np(aud["attention_mask"]), emb=to_np(emb[0]), toks=eng.generated(),
+               logits=to_np(eng.logits_all[:T_NEW]), route=route.cpu().numpy(),
+               hidden={l: to_np(hid[l]) for l in {0, min(15, cfg.text.num_hidden_layers - 1), cfg.text.num_hidden_layers - 1}})
+    print(f"[realgeom] device side done in {time.time() - t0:.1f}s: S={emb.shape[1]}, tokens {out['toks']}")
+    model.engine.close()
+    del model, packed, hid
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.fixture(scope="module")
+def oracle_embeds(run):
+    """the oracle's own encoders and splice -> inputs_embeds of the prompt."""
+    cfg, sd, req = run["cfg"], run["sd_enc"], run["req"]
+    t0 = time.time()
+    vit = oe.internvit_tower(sd, cfg.vision, req["pixel_values"])
+    img = oe.projector(sd, vit)
+    aud, amask = oe.whale_encoder(sd, cfg.audio, req["fbank"])[:2]
+    table = hashw.fill((cfg.text.vocab_size, cfg.text.hidden_size), hashw.tensor_seed("model.embed_tokens.weight", SEED))
+    emb = oe.splice(np.asarray(req["input_ids"]), table, img, aud[None] if aud.ndim == 2 else aud)
+    print(f"[realgeom] oracle encoders + splice in {time.time() - t0:.1f}s")
+    return dict(vit=vit, img=img, aud=aud, emb=np.asarray(emb, np.float32))
+
+
+def test_encoders_full_depth(run, oracle_embeds):
+    """A8-A10 at full depth (24 + 24 layers) on the bench's image and 10 s clip."""
+    o = oracle_embeds
+    assert run["vit"].shape == (1, 256, 4096) and run["aud"].shape == (1, 124, 4096) and run["aud_mask"].all()
+    assert_close("InternViT (24 layers) + pixel shuffle", run["vit"], o["vit"], atol=2e-3, rtol=1e-3)
+    assert_close("projector", run["img"], o["img"], atol=2e-3, rtol=1e-3)
+    assert_close("Whale (24 layers) + adapter", run["aud"][0], o["aud"].reshape(124, 4096), atol=2e-3, rtol=1e-3)
+    assert_close("spliced inputs_embeds", run["emb"], o["emb"], atol=2e-3, rtol=1e-3)
+
+
+def test_backbone_32_layers_prefill_and_greedy(run, oracle_embeds):
+    """A11-A14: one teacher-forced oracle forward over prompt + generated tokens vs the device's prefill + 15 decode steps."""
+    cfg = run["cfg"]
+    t, L = cfg.text, cfg.text.num_hidden_layers
+    S = run["emb"].shape[0]
+    toks = run["toks"]
+    assert S == 552 and len(toks) == T_NEW
+    cap = sorted(run["hidden"])
+    full = np.concatenate([oracle_embeds["emb"], stream.embed_rows(t, toks[:-1], SEED)], 0)
+    t0 = time.time()
+    ref = stream.forward(t, SEED, full, n_layers=L, capture=cap, logits_from=S - 1, verbose=True)
+    print(f"[realgeom] oracle backbone ({L} layers, {full.shape[0]} rows) in {time.time() - t0:.1f}s")
+    # router decisions of every layer over the prompt rows
+    r_dev, r_ref = np.sort(run["route"], -1), np.sort(ref["route"][:, :S], -1)
+    mism = np.argwhere((r_dev != r_ref).any(-1))
+    print(f"router top-2 sets: {r_dev.shape[0] * S} decisions, {len(mism)} differ", mism[:5].tolist())
+    assert len(mism) == 0
+    for l in cap:
+        # both sides accumulate in fp32 in different orders: the tolerance follows the residual stream's scale
+        # (|x| grows to ~40 by layer 31), 3e-4 of the tensor's largest magnitude + 1e-3 relative
+        h_ref = ref["hidden"][l][:S]
+        assert_close(f"hidden after layer {l}", run["hidden"][l], h_ref, atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
+    ref_ids = ref["logits"].argmax(-1).tolist()
+    print("device ids", toks)
+    print("oracle ids", ref_ids)
+    print(report("logits of the 16 steps", run["logits"], ref["logits"]))
+    assert toks == ref_ids                                               # greedy ids bit-exact
+    assert np.abs(run["logits"] - ref["logits"]).max() < 1e-3            # north-star: logits within 1e-3 (fp32)

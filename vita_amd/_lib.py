@@ -86,6 +86,7 @@ SIGNATURES = {
     "vh_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "vh_add": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "vh_cast_bf16_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "vh_fill_hash_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_long, c_long, C.c_uint64, c_void_p]),
     "vh_vit_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vh_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vh_vit_pixel_shuffle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "vh_mixtral_set_allreduce": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
     "vh_rccl_unique_id": (c_int, [c_void_p]),
     "vh_mixtral_init_rccl": (c_int, [c_void_p, c_void_p]),
+    "vh_mixtral_route_debug": (c_int, [c_void_p, c_void_p]),
     "vh_mixtral_prefill": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vh_mixtral_decode": (c_int, [c_void_p, c_int, c_void_p]),
     "vh_mixtral_tokens": (c_void_p, [c_void_p]),

@@ -196,9 +196,38 @@ def pack_mixtral(sd, cfg: VitaConfig, device, rank=0, world=1):
     return out
 
 
+def tensor_seed(name, base=0):
+    """64-bit stream id of a reference-named tensor (FNV-1a over the name, mixed with the run's seed) for the
+    counter-based weight generator vh_fill_hash_bf16; oracle/hashw.py computes the same id on the host."""
+    h = 0xCBF29CE484222325
+    for ch in name.encode():
+        h = ((h ^ ch) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return (h ^ (int(base) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
+
+def hash_fill(dst, name, seed=0, ld_src=None, idx0=0):
+    """dst: bf16 device tensor view [rows, cols] (rows may be strided) <- the values of reference tensor `name`."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    if dst.dtype != torch.bfloat16 or dst.ndim != 2 or dst.stride(1) != 1:
+        raise ValueError("hash_fill wants a 2-D bfloat16 view contiguous along its last dimension")
+    rows, cols = dst.shape
+    _lib.check(_lib.load().vh_fill_hash_bf16(C.c_void_p(dst.data_ptr()), rows, cols, dst.stride(0),
+                                             cols if ld_src is None else int(ld_src), int(idx0),
+                                             C.c_uint64(tensor_seed(name, seed)),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vh_fill_hash_bf16")
+    return dst
+
+
 def synth_mixtral_device(cfg: VitaConfig, device, seed=0, rank=0, world=1):
-    """Random-init backbone generated directly on the GPU in packed layout (bench path: the full
-    model is 93.7 GB bf16, too large to stage through host numpy).  SURVEY §8(d) init."""
+    """Random-init backbone generated directly on the GPU in packed layout (the full model is 93.7 GB bf16, too
+    large to stage through host numpy).  SURVEY §8(d) init (sigma ~0.02, norms 1) from the counter-based generator
+    vh_fill_hash_bf16, keyed by the REFERENCE'S parameter names: a tensor-parallel rank's shard holds exactly the
+    values of its slice of the full tensor, and the CPU oracle regenerates any tensor on the host
+    (oracle/hashw.py) — the released geometry can be parity-checked without a checkpoint."""
     import torch
     t = cfg.text
     qs, kvs, ff = tp_slices(t, rank, world)
@@ -206,23 +235,26 @@ def synth_mixtral_device(cfg: VitaConfig, device, seed=0, rank=0, world=1):
     nkv = (kvs.stop - kvs.start) // t.head_dim
     I = ff.stop - ff.start
     H, E, hd = t.hidden_size, t.num_local_experts, t.head_dim
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)  # same seed on every rank: replicated tensors are identical
-
-    def W(*shape):
-        w = torch.empty(shape, device=device, dtype=torch.bfloat16)
-        # chunked so the fp32 staging buffer stays small
-        flat = w.view(-1)
-        step = 1 << 28
-        for i in range(0, flat.numel(), step):
-            n = min(step, flat.numel() - i)
-            flat[i:i + n] = (torch.randn(n, device=device, generator=gen, dtype=torch.float32) * 0.02).to(torch.bfloat16)
-        return w
-
+    bf = torch.bfloat16
     ones = lambda n: torch.ones(n, device=device, dtype=torch.float32)
-    out = {"embed": W(t.vocab_size, H), "final_norm": ones(H), "lm_head": W(t.vocab_size, H), "layers": []}
-    for _ in range(t.num_hidden_layers):
+    new = lambda *shape: torch.empty(shape, device=device, dtype=bf)
+    out = {"embed": hash_fill(new(t.vocab_size, H), "model.embed_tokens.weight", seed), "final_norm": ones(H),
+           "lm_head": hash_fill(new(t.vocab_size, H), "lm_head.weight", seed), "layers": []}
+    for l in range(t.num_hidden_layers):
+        p = LLM.format(l)
+        wqkv = new((nq + 2 * nkv) * hd, H)
+        hash_fill(wqkv[:nq * hd], p + "self_attn.q_proj.weight", seed, idx0=qs.start * H)
+        hash_fill(wqkv[nq * hd:(nq + nkv) * hd], p + "self_attn.k_proj.weight", seed, idx0=kvs.start * H)
+        hash_fill(wqkv[(nq + nkv) * hd:], p + "self_attn.v_proj.weight", seed, idx0=kvs.start * H)
+        wo = hash_fill(new(H, nq * hd), p + "self_attn.o_proj.weight", seed, ld_src=t.num_attention_heads * hd,
+                       idx0=qs.start)
+        w1, w3, w2 = new(E, I, H), new(E, I, H), new(E, H, I)
+        for e in range(E):
+            q = p + f"block_sparse_moe.experts.{e}."
+            hash_fill(w1[e], q + "w1.weight", seed, idx0=ff.start * H)
+            hash_fill(w3[e], q + "w3.weight", seed, idx0=ff.start * H)
+            hash_fill(w2[e], q + "w2.weight", seed, ld_src=t.intermediate_size, idx0=ff.start)
         out["layers"].append({
-            "attn_norm": ones(H), "wqkv": W((nq + 2 * nkv) * hd, H), "wo": W(H, nq * hd), "ffn_norm": ones(H),
-            "wrouter": W(E, H), "w1": W(E, I, H), "w3": W(E, I, H), "w2": W(E, H, I)})
+            "attn_norm": ones(H), "wqkv": wqkv, "wo": wo, "ffn_norm": ones(H),
+            "wrouter": hash_fill(new(E, H), p + "block_sparse_moe.gate.weight", seed), "w1": w1, "w3": w3, "w2": w2})
     return out

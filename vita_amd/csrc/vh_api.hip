@@ -119,6 +119,10 @@ int vh_add(float* x, const float* y, long n, void* stream) { return check_launch
 int vh_cast_bf16_f32(const uint16_t* in, float* out, long n, void* stream) {
     return check_launch("vh_cast_bf16_f32", vhk_cast_bf16_f32(S(stream), in, out, n));
 }
+int vh_fill_hash_bf16(uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0, uint64_t seed, void* stream) {
+    if (!dst) return fail(VH_E_ARG, "vh_fill_hash_bf16: null pointer");
+    return check_launch("vh_fill_hash_bf16", vhk_fill_hash_bf16(S(stream), dst, rows, cols, ld_dst, ld_src, idx0, seed));
+}
 int vh_vit_patchify(const float* pix, float* out, int n, int img, int patch, int kpad, void* stream) {
     return check_launch("vh_vit_patchify", vhk_vit_patchify(S(stream), pix, out, n, img, patch, kpad));
 }
@@ -204,6 +208,7 @@ struct vh_mixtral {
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
     int *pids, *pgoff, *pstok, *psslot;
+    int* route_dbg = nullptr;   // optional: per-layer top-2 expert ids of the next prefill, [layer][token][2]
     // tensor parallel
     vh_allreduce_fn ar_fn; void* ar_user; void* rccl_comm;
     // optional live timing of the dominant decode kernel (gate/up GEMV), sampled every prof_stride layers
@@ -342,6 +347,12 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* uid) {
     if (rc != 0) return fail(VH_E_COMM, "ncclCommInitRank failed (%d)", rc);
     m->rccl_comm = comm;
     m->ar_fn = rccl_allreduce_cb; m->ar_user = m;
+    return VH_OK;
+}
+
+int vh_mixtral_route_debug(vh_mixtral_t* m, int* ids_out) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    m->route_dbg = ids_out;   // device int[n_layers][S][2] filled by the following prefill calls; null = off
     return VH_OK;
 }
 
@@ -496,6 +507,9 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
         } else {
             VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H, nslab, slab), "combine");
         }
+        if (m->route_dbg)
+            hipMemcpyAsync(m->route_dbg + (size_t)l * 2 * Sn, m->pids, (size_t)2 * Sn * sizeof(int),
+                           hipMemcpyDeviceToDevice, st);
         if (hidden_dbg)
             hipMemcpyAsync(hidden_dbg + (size_t)l * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
                            hipMemcpyDeviceToDevice, st);

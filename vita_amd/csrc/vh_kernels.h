@@ -116,3 +116,5 @@ int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, i
 int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H, int nslab,
                     long slab_stride);
 int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n);
+int vhk_fill_hash_bf16(hipStream_t st, uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0,
+                       uint64_t seed);

@@ -109,8 +109,9 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_set_allreduce(self.h, self._ar_cb, None), "vh_mixtral_set_allreduce")
 
     # ---- forward -----------------------------------------------------------------------------
-    def prefill(self, embeds, pos0=0, want_hidden=False):
-        """embeds fp32 [S, hidden] on device.  Returns (logits_of_last_pos view, hidden_dbg or None)."""
+    def prefill(self, embeds, pos0=0, want_hidden=False, want_route=False):
+        """embeds fp32 [S, hidden] on device.  Returns (logits_of_last_pos view, hidden_dbg or None); with
+        want_route the per-layer top-2 expert ids [layers, S, 2] are left in self.route_ids."""
         if embeds.dtype != torch.float32 or not embeds.is_cuda:
             raise TypeError("embeds must be a float32 GPU tensor")
         embeds = embeds.contiguous()
@@ -118,9 +119,17 @@ class MixtralEngine:
         hid = None
         if want_hidden:
             hid = torch.empty((self.c.n_layers, S, self.c.hidden), dtype=torch.float32, device=self.device)
-        check(self.lib.vh_mixtral_prefill(self.h, embeds.data_ptr(), S, pos0, None,
-                                          hid.data_ptr() if hid is not None else None, self._stream()),
-              "vh_mixtral_prefill")
+        self.route_ids = None
+        if want_route:
+            self.route_ids = torch.empty((self.c.n_layers, S, 2), dtype=torch.int32, device=self.device)
+            check(self.lib.vh_mixtral_route_debug(self.h, self.route_ids.data_ptr()), "vh_mixtral_route_debug")
+        try:
+            check(self.lib.vh_mixtral_prefill(self.h, embeds.data_ptr(), S, pos0, None,
+                                              hid.data_ptr() if hid is not None else None, self._stream()),
+                  "vh_mixtral_prefill")
+        finally:
+            if want_route:
+                check(self.lib.vh_mixtral_route_debug(self.h, None), "vh_mixtral_route_debug")
         self.n_gen = 1
         return self.logits_all[0], hid
 
