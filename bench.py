@@ -38,41 +38,24 @@ def pmc_traffic(kernel):
 
 
 def native_rccl_or_fallback(eng, rank, dist, dev, backend, timeout_s=180):
-    """Bring up the engine's own RCCL communicator (ncclAllReduce enqueued straight from the C layer loop).
-    The attempt is bounded and the ranks AGREE on the outcome: if any rank failed or timed out, every rank uses
-    torch.distributed's all-reduce through the callback hook instead (slower host side, same results) — a
-    bench line beats a hang.  Returns True when the native path is active on all ranks."""
-    import ctypes
-    import threading
-    from vita_amd import _lib
-    uid = ctypes.create_string_buffer(128)
-    ok = [0]
-    try:
-        if rank == 0:
-            _lib.check(_lib.load().vh_rccl_unique_id(uid), "vh_rccl_unique_id")
-        obj = [bytes(uid.raw)]
-        dist.broadcast_object_list(obj, src=0)
+    """(kept under its round-1 name) the engine's own RCCL communicator with rank consensus: vita_amd.parallel."""
+    from vita_amd.parallel import native_rccl
+    return native_rccl(eng, rank, dist, dev, backend, timeout_s)
 
-        def run():
-            try:
-                torch.cuda.set_device(dev)      # HIP's current device is per thread; ncclCommInitRank binds to it
-                eng.use_rccl(obj[0])
-                ok[0] = 1
-            except Exception as e:
-                print(f"[bench] rank {rank}: native RCCL init failed: {e}", file=sys.stderr)
 
-        th = threading.Thread(target=run, daemon=True)
-        th.start()
-        th.join(timeout_s)
-        if th.is_alive():
-            print(f"[bench] rank {rank}: native RCCL init still not done after {timeout_s}s", file=sys.stderr)
-            ok[0] = 0
-    except Exception as e:
-        print(f"[bench] rank {rank}: native RCCL setup failed: {e}", file=sys.stderr)
-        ok[0] = 0
-    flag = torch.tensor([ok[0]], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(flag.item())
+def self_launch(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher: re-run this command under torch.distributed.run with one
+    rank per GPU (the driver's multi-GPU form is the explicit torchrun line; both end in the same main())."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(cfg, n_layers=2, ctx=64, n_tok=6):
@@ -152,7 +135,10 @@ def main():
     ap.add_argument("--phase-iters", type=int, default=7, help="timed encoder+prefill passes (median and min reported)")
     ap.add_argument("--layers", type=int, default=0, help="debug only: fewer layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--collective", default="auto", choices=["auto", "ipc", "rccl", "torch"],
+                    help="auto = the library's IPC all-reduce, else native RCCL, else torch.distributed (ranks agree)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="debug: only bring the ranks up (process group + one all-reduce) and print a JSON line; no GPU needed with --backend gloo")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo + --one-device is the 1-GPU functional check of the N>1 path")
     ap.add_argument("--try-rccl", action="store_true",
@@ -172,21 +158,40 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))       # no launcher around us: spawn one rank per GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group(backend=args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo")
+            v = torch.tensor([float(rank + 1)])
+            if dist.get_backend() == "nccl":
+                torch.cuda.set_device(local_rank)
+                v = v.cuda()
+            dist.all_reduce(v)
+            total = float(v.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            total = 1.0
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "allreduce_sum": total,
+                              "expected": world * (world + 1) / 2}), flush=True)
+        return
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend="gloo")
-            if not args.try_rccl:
+            if not args.try_rccl and args.collective == "rccl":
                 args.collective = "torch"  # RCCL refuses two ranks on one device; gloo stages through the host
 
     from vita_amd.checkpoint import synth_mixtral_device, synth_state_dict
@@ -214,11 +219,8 @@ def main():
     eng = model.engine
     collective = "none"
     if world > 1:
-        collective = args.collective
-        if collective == "rccl":
-            collective = "rccl" if native_rccl_or_fallback(eng, rank, dist, dev, args.backend) else "torch"
-        if collective == "torch":
-            eng.use_torch_allreduce()
+        from vita_amd.parallel import setup_tensor_parallel
+        collective = setup_tensor_parallel(eng, rank, world, dev, backend=args.backend, collective=args.collective)
     torch.cuda.synchronize()
     t_build = time.time() - t0
 

@@ -173,6 +173,9 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* unique_id_128_bytes /* hos
  * [n_layers][S][hidden] receives the residual stream after every layer.                   */
 /* Debug / parity hook: the top-2 expert ids of every layer of the following prefills are copied to ids_out
  * (device int[n_layers][S][2]; null switches it off) — SURVEY 8(c) golden list "router top-2 ids per layer". */
+/* Give up on a vh_mixtral_init_rccl that is still running in another thread (bring-up time-out): when it returns it
+ * destroys its communicator instead of installing it. */
+int vh_mixtral_cancel_rccl(vh_mixtral_t* m);
 int vh_mixtral_route_debug(vh_mixtral_t* m, int* ids_out);
 int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, float* logits_out, float* hidden_dbg,
                        void* stream);

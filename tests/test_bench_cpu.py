@@ -32,6 +32,9 @@ class _FakeEngine:
         if self.fail:
             raise RuntimeError("simulated ncclCommInitRank failure")
 
+    def cancel_rccl(self):
+        self.cancelled = True
+
 
 def _bringup_worker(rank, world, port, fail_rank, ret):
     import torch
@@ -43,7 +46,7 @@ def _bringup_worker(rank, world, port, fail_rank, ret):
     try:
         eng = _FakeEngine(fail=(rank == fail_rank))
         ok = bench.native_rccl_or_fallback(eng, rank, dist, torch.device("cpu"), "gloo", timeout_s=20)
-        ret[rank] = (bool(ok), eng.called)
+        ret[rank] = (bool(ok), eng.called, getattr(eng, "cancelled", False))
     finally:
         dist.destroy_process_group()
 
@@ -67,5 +70,23 @@ def test_rccl_bringup_consensus_world2():
     ranks to the torch fallback; nobody may be left believing the native communicator is active alone."""
     r = _run_bringup(fail_rank=1)
     assert r[0][0] is False and r[1][0] is False, r
+    assert r[0][2] and r[1][2], r              # ... and every rank cancelled its attempt (a late init must not install)
     r2 = _run_bringup(fail_rank=-1)
     assert r2[0][0] == r2[1][0], r2            # agree either way (True only where librccl could mint an id)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it spawns its own ranks (torch.distributed.run, 127.0.0.1)
+    and rank 0 prints ONE JSON line — the driver's multi-GPU command shape.  --launch-check stops after the process
+    group + one all-reduce, so this runs on CPU (gloo)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--backend", "gloo"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["launch_check"] and j["n_gpus"] == 2 and j["allreduce_sum"] == j["expected"] == 3.0

@@ -100,6 +100,7 @@ SIGNATURES = {
     "vh_mixtral_set_allreduce": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
     "vh_rccl_unique_id": (c_int, [c_void_p]),
     "vh_mixtral_init_rccl": (c_int, [c_void_p, c_void_p]),
+    "vh_mixtral_cancel_rccl": (c_int, [c_void_p]),
     "vh_mixtral_route_debug": (c_int, [c_void_p, c_void_p]),
     "vh_mixtral_prefill": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vh_mixtral_decode": (c_int, [c_void_p, c_int, c_void_p]),

@@ -208,6 +208,8 @@ struct vh_mixtral {
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
     int *pids, *pgoff, *pstok, *psslot;
+    int rccl_gen = 0;           // bumped by vh_mixtral_cancel_rccl: a pending vh_mixtral_init_rccl then discards its communicator
+    int poisoned = 0;           // a decode step failed half-way: only prefill / reset may follow
     int* route_dbg = nullptr;   // optional: per-layer top-2 expert ids of the next prefill, [layer][token][2]
     // tensor parallel
     vh_allreduce_fn ar_fn; void* ar_user; void* rccl_comm;
@@ -343,10 +345,23 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* uid) {
     Id128 id;
     memcpy(id.b, uid, 128);
     void* comm = nullptr;
+    const int gen = __atomic_load_n(&m->rccl_gen, __ATOMIC_ACQUIRE);
     const int rc = g_rccl.CommInitRank(&comm, m->c.tp_world, id, m->c.tp_rank);
     if (rc != 0) return fail(VH_E_COMM, "ncclCommInitRank failed (%d)", rc);
+    // a caller that gave up on this attempt (vh_mixtral_cancel_rccl: bring-up time-out, the ranks agreed on another
+    // collective) must not find the communicator installed later, in the middle of a run
+    if (__atomic_load_n(&m->rccl_gen, __ATOMIC_ACQUIRE) != gen) {
+        if (g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+        return fail(VH_E_COMM, "RCCL bring-up was cancelled");
+    }
     m->rccl_comm = comm;
     m->ar_fn = rccl_allreduce_cb; m->ar_user = m;
+    return VH_OK;
+}
+
+int vh_mixtral_cancel_rccl(vh_mixtral_t* m) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    __atomic_add_fetch(&m->rccl_gen, 1, __ATOMIC_ACQ_REL);
     return VH_OK;
 }
 
@@ -392,13 +407,20 @@ int vh_mixtral_reset(vh_mixtral_t* m, void* stream) {
     if (!m) return fail(VH_E_ARG, "null engine");
     if (hipMemsetAsync(m->counters, 0, 4 * sizeof(int), S(stream)) != hipSuccess)
         return fail(VH_E_HIP, "reset memset failed");
-    m->host_pos = 0; m->attn_epoch = 0;
+    m->host_pos = 0; m->attn_epoch = 0; m->poisoned = 0;
     return VH_OK;
 }
 
-#define VH_TRY(expr, what)                                               \
-    do {                                                                 \
-        if ((expr) != 0) return fail(VH_E_SHAPE, "%s: launch rejected", what); \
+// a launcher returns non-zero when it REJECTS its arguments before launching (VH_E_SHAPE); a launch the runtime
+// refused shows up in hipGetLastError (VH_E_HIP)
+static int launch_failed(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VH_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return fail(VH_E_SHAPE, "%s: launch rejected (shape / arguments)", what);
+}
+#define VH_TRY(expr, what)                             \
+    do {                                               \
+        if ((expr) != 0) return launch_failed(what);   \
     } while (0)
 
 int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, float* logits_out, float* hidden_dbg,
@@ -414,6 +436,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
         return fail(VH_E_HIP, "prefill: embed copy failed");
     if (hipMemsetAsync(m->counters + 1, 0, 3 * sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
     m->attn_epoch = 0;
+    m->poisoned = 0;
 
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
@@ -528,52 +551,69 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     return VH_OK;
 }
 
-int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
-    if (!m) return fail(VH_E_ARG, "null engine");
-    hipStream_t st = S(stream);
+// One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
+// mirrors (host_pos, attn_epoch) are advanced by the CALLER only after the step was enqueued without error.
+static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
+    *epoch_inc = 0;
+    for (int l = 0; l < m->c.n_layers; ++l) {
+        const vh_mixtral_layer& w = m->L[l];
+        float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
+                           m->qkv), "dec qkv");
+        int fused = 1;
+        if (vh_tuning()->fuse_attn_oproj) {
+            fused = vhk_dec_attn_oproj(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o,
+                                       m->part_ml, m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits,
+                                       m->host_pos + 1, scale, m->counters + 2, (m->attn_epoch + *epoch_inc + 1) * nkv,
+                                       m->counters + 3, w.wo, H, nq * hd, m->delta_attn);
+            if (fused < 0) return launch_failed("dec attn+oproj");
+            if (fused == 0) *epoch_inc += 1;
+        }
+        if (fused != 0) {  // long contexts (grid not co-resident) or fusion disabled: two kernels
+            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                                m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
+                                scale), "dec attn");
+            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
+        }
+        if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+        if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
+        VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
+                              m->route, m->hbuf, 0), "dec gateup");
+        if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+        VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe), "dec down");
+        if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+    }
+    VH_TRY(vhk_dec_lmhead(st, m->xa, m->delta_moe, m->final_norm, eps, m->lm_head, m->V, H, m->logits, m->blk_val,
+                          m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "dec lm_head");
+    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->V, m->xa, m->counters,
+                          m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
+    const hipError_t e = hipGetLastError();   // checked per step: the mirrors below must not run ahead of a failed launch
+    if (e != hipSuccess) return fail(VH_E_HIP, "decode: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
+int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    hipStream_t st = S(stream);
+    if (m->poisoned) return fail(VH_E_ARG, "decode: a previous step failed; prefill or reset first");
     for (int step = 0; step < n_steps; ++step) {
         if (m->host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx);
-        for (int l = 0; l < m->c.n_layers; ++l) {
-            const vh_mixtral_layer& w = m->L[l];
-            float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
-            float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
-            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
-                               m->qkv), "dec qkv");
-            int fused = 1;
-            if (vh_tuning()->fuse_attn_oproj) {
-                fused = vhk_dec_attn_oproj(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o,
-                                           m->part_ml, m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits,
-                                           m->host_pos + 1, scale, m->counters + 2, (m->attn_epoch + 1) * nkv,
-                                           m->counters + 3, w.wo, H, nq * hd, m->delta_attn);
-                if (fused < 0) return fail(VH_E_SHAPE, "dec attn+oproj: launch rejected");
-                if (fused == 0) m->attn_epoch += 1;
-            }
-            if (fused != 0) {  // long contexts (grid not co-resident) or fusion disabled: two kernels
-                VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
-                                    m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
-                                    scale), "dec attn");
-                VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
-            }
-            if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
-            const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
-            if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
-            VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
-                                  m->route, m->hbuf, 0), "dec gateup");
-            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe), "dec down");
-            if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        int epoch_inc = 0;
+        const int rc = decode_one_step(m, st, &epoch_inc);
+        if (rc != VH_OK) {
+            // the step was not (fully) enqueued: host_pos / attn_epoch keep their values, i.e. they describe the
+            // last COMPLETE step; the device state of the partial step is discarded by the next prefill / reset
+            m->poisoned = 1;
+            return rc;
         }
-        VH_TRY(vhk_dec_lmhead(st, m->xa, m->delta_moe, m->final_norm, eps, m->lm_head, m->V, H, m->logits, m->blk_val,
-                              m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "dec lm_head");
-        VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->V, m->xa, m->counters,
-                              m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
         m->host_pos += 1;
+        m->attn_epoch += epoch_inc;
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(VH_E_HIP, "decode: %s", hipGetErrorString(e));
     return VH_OK;
 }
 

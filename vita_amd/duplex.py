@@ -65,33 +65,41 @@ def worker_loop(llm_id, make_llm, sampling_params, inputs_queue, outputs_queue, 
         results, pending, first_positive, t_first = [], "", True, None
         previous, n_tokens = "", 0
         st = {"speaking": False}     # the stop flag only counts once this engine has taken the floor (:354)
-        for out in llm.generate_stream(inputs, sampling_params, request_id=uuid.uuid4().hex,
-                                       should_stop=lambda: st["speaking"] and stop_event.is_set()):
-            text = out.outputs[0].text
-            n_tokens = len(out.outputs[0].token_ids)
-            new = text[len(previous):]
-            previous = text
-            if new == "":
-                continue
-            if t_first is None:
-                t_first = time.perf_counter()
-            if judge_negative(new) or (first_positive and judge_negative(text)):
-                break                                   # noise: answer nothing
-            pending += new
-            if first_positive:                          # first real words: take the floor
-                stop_event.clear()
-                other_stop_event.set()
-                clear_queue(outputs_queue)
-                first_positive = False
-                st["speaking"] = True
-                interrupt_signal.value = llm_id
-            if stop_event.is_set():
-                break                                   # the other engine took the floor
-            results.append(new)
-            pending = pending.replace("<1> ", "").replace("<1>", "")
-            if new in SENTENCE_END or new[-1:] in SENTENCE_END:
-                outputs_queue.put({"id": llm_id, "response": pending})
-                pending = ""
+        error = None
+        stream = llm.generate_stream(inputs, sampling_params, request_id=uuid.uuid4().hex,
+                                     should_stop=lambda: st["speaking"] and stop_event.is_set())
+        try:
+            for out in stream:
+                text = out.outputs[0].text
+                n_tokens = len(out.outputs[0].token_ids)
+                new = text[len(previous):]
+                previous = text
+                if new == "":
+                    continue
+                if t_first is None:
+                    t_first = time.perf_counter()
+                if judge_negative(new) or (first_positive and judge_negative(text)):
+                    break                                   # noise: answer nothing
+                pending += new
+                if first_positive:                          # first real words: take the floor
+                    stop_event.clear()
+                    other_stop_event.set()
+                    clear_queue(outputs_queue)
+                    first_positive = False
+                    st["speaking"] = True
+                    interrupt_signal.value = llm_id
+                if stop_event.is_set():
+                    break                                   # the other engine took the floor
+                results.append(new)
+                pending = pending.replace("<1> ", "").replace("<1>", "")
+                if new in SENTENCE_END or new[-1:] in SENTENCE_END:
+                    outputs_queue.put({"id": llm_id, "response": pending})
+                    pending = ""
+        except Exception as e:      # one bad request must not kill the engine process: the baton would never return
+            error = f"{type(e).__name__}: {e}"
+            print(f"[duplex worker {llm_id}] request failed: {error}", flush=True)
+        finally:
+            stream.close()            # abandons the generation (noise verdict / interrupt / error) without decoding on
         if pending and not stop_event.is_set() and not first_positive:
             outputs_queue.put({"id": llm_id, "response": pending})
         current["response"] = "".join(results)
@@ -105,7 +113,7 @@ def worker_loop(llm_id, make_llm, sampling_params, inputs_queue, outputs_queue, 
                              "take_to_first_chunk_s": None if t_first is None else t_first - t_take,
                              "first_chunk_to_end_s": None if t_first is None else t_end - t_first, "n_tokens": n_tokens,
                              "interrupted": bool(stop_event.is_set()), "negative": first_positive,
-                             "n_chunks": len(results)})
+                             "n_chunks": len(results), "error": error})
 
 
 def _engine_process(llm_id, llm_factory, factory_args, sampling_params, shared):

@@ -94,6 +94,10 @@ class MixtralEngine:
         buf = C.create_string_buffer(unique_id, 128)
         check(self.lib.vh_mixtral_init_rccl(self.h, buf), "vh_mixtral_init_rccl")
 
+    def cancel_rccl(self):
+        """give up on a use_rccl() still running in another thread: it then discards its communicator."""
+        check(self.lib.vh_mixtral_cancel_rccl(self.h), "vh_mixtral_cancel_rccl")
+
     def use_torch_allreduce(self, group=None):
         """Fallback collective: torch.distributed.all_reduce (RCCL under backend 'nccl', gloo on CPU
         tests) called back from the C layer loop."""
@@ -151,9 +155,15 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_profile_read(self.h, C.byref(tot), C.byref(n)), "vh_mixtral_profile_read")
         return tot.value, n.value
 
+    def check_device_flag(self, counters=None):
+        """raise if a kernel reported a device-side error (counters[3]: hand-off / all-reduce spin time-out)."""
+        c = self.counters.tolist() if counters is None else counters
+        if c[3] != 0:
+            raise _lib.VitaHipError("device-side time-out (fused decode hand-off or all-reduce): error flag set, "
+                                    "the tokens of this request are not trustworthy")
+        return c
+
     def generated(self):
         """(synchronising) list of token ids generated so far."""
-        c = self.counters.tolist()
-        if c[3] != 0:
-            raise _lib.VitaHipError("device-side hand-off timeout in the fused decode kernel (error flag set)")
+        c = self.check_device_flag()
         return self.tokens[:min(c[1], self.max_new)].tolist()

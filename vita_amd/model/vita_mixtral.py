@@ -202,17 +202,30 @@ class VITAMixtralForCausalLM(_HipModule):
         crit = list(stopping_criteria or [])
         keep_scores = output_scores and eng.logit_rows > 1
         generated, done, n_checked = [], False, 0
+        # prompt + every token generated so far, written in place (the stopping criteria see a VIEW of it: no
+        # concatenation per token; KeywordsStoppingCriteria decodes only the last max_keyword_len ids)
+        seq_buf = None
+        if crit:
+            seq_buf = torch.empty((1, prompt.shape[1] + max_new), dtype=prompt.dtype, device=self._device)
+            seq_buf[:, :prompt.shape[1]] = prompt
         while not done:
             # tokens [n_checked, eng.n_gen) are on the device; look at them one at a time, in order,
             # so stopping is decided exactly as a token-by-token loop would
             torch.cuda.current_stream().synchronize()
+            eng.check_device_flag()        # a device-side spin time-out must not yield silently wrong tokens
             new = eng.tokens[n_checked:eng.n_gen].tolist()
             n_before = len(generated)
+            if crit and new:
+                p0 = prompt.shape[1] + n_checked
+                seq_buf[0, p0:p0 + len(new)] = torch.tensor(new, dtype=prompt.dtype, device=self._device)
             for tok in new:
                 generated.append(tok)
                 n_checked += 1
-                seq = torch.cat([prompt, torch.tensor([generated], dtype=prompt.dtype, device=self._device)], dim=1)
-                if tok in eos_set or len(generated) >= max_new or any(c(seq, None) for c in crit):
+                stop = tok in eos_set or len(generated) >= max_new
+                if not stop and crit:
+                    seq = seq_buf[:, :prompt.shape[1] + len(generated)]
+                    stop = any(c(seq, None) for c in crit)
+                if stop:
                     done = True
                     break
             # streaming hook (duplex serving): receives the tokens accepted in this window, returns False to

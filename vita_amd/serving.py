@@ -121,9 +121,16 @@ class LLM:
         if world > 1:
             kw.update(rank=int(os.environ.get("RANK", "0")), world=world)
             device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        if world > 1:
+            torch.cuda.set_device(torch.device(device))       # kernels launch on the CURRENT device's stream
         self.tokenizer, self.model, self.image_processor, _ = load_pretrained_model(
             model, None, os.path.basename(str(model).rstrip("/")), "mixtral-8x7b", device=device,
             max_new_tokens=max_new_tokens, **kw)
+        self.collective = "none"
+        if world > 1:
+            from .parallel import setup_tensor_parallel
+            self.collective = setup_tensor_parallel(self.model.engine, kw["rank"], world, device,
+                                                    backend=os.environ.get("VITA_AMD_DIST_BACKEND", "nccl"))
         with open(os.path.join(model, "config.json")) as f:
             j = json.load(f)
         self.image_token_index = int(j.get("image_token_index", 51000))
@@ -160,6 +167,7 @@ class LLM:
         if sp.temperature is not None and sp.temperature > 0.011:
             raise NotImplementedError("vita_amd serves greedy decoding (temperature <= 0.01, the reference demo's setting)")
         dev = self.model.device
+        max_tokens = min(int(sp.max_tokens), int(self.model.max_new_tokens))   # the engine's output buffer is the hard cap
         sent, tiles = self._expand(ids, images, audios)
         size = self.image_processor.crop_size["height"]
         if tiles:
@@ -185,7 +193,7 @@ class LLM:
         try:
             out = self.model.generate(torch.tensor([sent], dtype=torch.long, device=dev), images=pix,
                                       audios={"audios": feats.to(dev), "lengths": lens.to(dev)}, do_sample=False,
-                                      num_beams=1, return_dict_in_generate=True, max_new_tokens=int(sp.max_tokens),
+                                      num_beams=1, return_dict_in_generate=True, max_new_tokens=max_tokens,
                                       eos_token_id=list({self.model.generation_config.eos_token_id,
                                                          *(sp.stop_token_ids or [])}), streamer=streamer)
         finally:
@@ -206,12 +214,14 @@ class LLM:
         import threading
         sp = sampling_params or SamplingParams()
         q = queue.Queue()
-        state = {"toks": []}
+        state = {"toks": [], "abandoned": False}
 
         def streamer(new):
             state["toks"] += list(new)
             q.put(list(state["toks"]))
-            return not (should_stop is not None and should_stop())
+            # abandoned: the consumer left the iterator (noise verdict, interrupt): stop at the next window instead of
+            # decoding to EOS / max_tokens while the worker waits in th.join() (the reference aborts the request)
+            return not (state["abandoned"] or (should_stop is not None and should_stop()))
 
         result = {}
 
@@ -235,6 +245,7 @@ class LLM:
                                     outputs=[CompletionOutput(0, self.tokenizer.decode(
                                         item, skip_special_tokens=sp.skip_special_tokens), item, "")])
         finally:
+            state["abandoned"] = True
             th.join()
             self.model.lookahead = old_la
         if "err" in result:
