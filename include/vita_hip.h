@@ -171,6 +171,24 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* unique_id_128_bytes /* hos
  * out_tokens[0] (greedy) and the engine ready to decode.  If logits_out != NULL the fp32
  * logits of the last position are copied there ([vocab]).  hidden_dbg (nullable): fp32
  * [n_layers][S][hidden] receives the residual stream after every layer.                   */
+/* ---- the library's own all-reduce over IPC-mapped peer buffers (vh_comm.hip): one process per GPU ------------------
+ * vh_comm_create allocates this rank's receive buffer (the ONLY allocation the library makes: it must be fine-grained
+ * device memory) and writes its 64-byte IPC handle to handle_out; the caller gathers the world's handles (any bootstrap:
+ * torch.distributed, MPI, a file) and passes them, rank-major, to vh_comm_connect.  vh_comm_allreduce sums `count` fp32
+ * values in place across the ranks (every rank must call it, in the same order, with the same count); results are
+ * bit-identical on all ranks.  vh_comm_status: 0, or the phase whose bounded spin timed out. */
+typedef struct vh_comm vh_comm_t;
+vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_out);
+int vh_comm_connect(vh_comm_t* c, const void* handles);
+size_t vh_comm_capacity(const vh_comm_t* c);
+int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream);
+int vh_comm_status(vh_comm_t* c);
+void vh_comm_destroy(vh_comm_t* c);
+const char* vh_comm_last_error(void);
+/* Route the engine's per-layer all-reduces through `c` (messages above its capacity keep using the RCCL / callback
+ * collective installed before); null detaches it.  The engine does not own `c`. */
+int vh_mixtral_use_comm(vh_mixtral_t* m, vh_comm_t* c);
+
 /* Debug / parity hook: the top-2 expert ids of every layer of the following prefills are copied to ids_out
  * (device int[n_layers][S][2]; null switches it off) — SURVEY 8(c) golden list "router top-2 ids per layer". */
 /* Give up on a vh_mixtral_init_rccl that is still running in another thread (bring-up time-out): when it returns it

@@ -100,6 +100,14 @@ SIGNATURES = {
     "vh_mixtral_set_allreduce": (c_int, [c_void_p, ALLREDUCE_FN, c_void_p]),
     "vh_rccl_unique_id": (c_int, [c_void_p]),
     "vh_mixtral_init_rccl": (c_int, [c_void_p, c_void_p]),
+    "vh_comm_create": (c_void_p, [c_int, c_int, c_size_t, c_void_p]),
+    "vh_comm_connect": (c_int, [c_void_p, c_void_p]),
+    "vh_comm_capacity": (c_size_t, [c_void_p]),
+    "vh_comm_allreduce": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "vh_comm_status": (c_int, [c_void_p]),
+    "vh_comm_destroy": (None, [c_void_p]),
+    "vh_comm_last_error": (C.c_char_p, []),
+    "vh_mixtral_use_comm": (c_int, [c_void_p, c_void_p]),
     "vh_mixtral_cancel_rccl": (c_int, [c_void_p]),
     "vh_mixtral_route_debug": (c_int, [c_void_p, c_void_p]),
     "vh_mixtral_prefill": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

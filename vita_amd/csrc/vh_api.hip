@@ -257,8 +257,10 @@ struct vh_mixtral {
         lm_grid = (V + 7) / 8;
         if (lm_grid > 1024) lm_grid = 1024;
     }
+    vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
     int allreduce(float* buf, long count, hipStream_t st) {
         if (c.tp_world <= 1 && !vh_tuning()->force_allreduce) return 0;
+        if (comm && (size_t)count <= vh_comm_capacity(comm)) return vh_comm_allreduce(comm, buf, count, st) == VH_OK ? 0 : -1;
         if (!ar_fn) return -1;
         return ar_fn(ar_user, buf, count, st);
     }
@@ -356,6 +358,12 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* uid) {
     }
     m->rccl_comm = comm;
     m->ar_fn = rccl_allreduce_cb; m->ar_user = m;
+    return VH_OK;
+}
+
+int vh_mixtral_use_comm(vh_mixtral_t* m, vh_comm_t* c) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    m->comm = c;
     return VH_OK;
 }
 

@@ -1,0 +1,213 @@
+// vh_comm.hip — the library's own all-reduce(sum) over IPC-mapped peer buffers (the exchange after
+// o_proj and after the MoE down projection — web_demo/vllm_tools/vllm_file/mixtral.py:405-414 FusedMoE reduce_results,
+// :470-476 RowParallel o_proj).
+//
+// Why not only RCCL.  A decode step carries 64 all-reduces of ONE 16 KB vector; a ring / tree collective pays several
+// hops of flag latency per call.  On an MI355X node every GPU has a direct xGMI link to each of its 7 peers, so the
+// latency-optimal exchange is direct: every rank PUSHES its vector into a slot of every peer's receive buffer and then
+// sums the world slots it finds in its OWN memory, in rank order (so all ranks hold bit-identical sums — the replicated
+// router / norm computations downstream must not diverge).
+//
+// Transport: 8-byte granules {value : fp32 bits, tag : epoch} written with ONE system-scope store each, polled with
+// system-scope loads until the tag matches (the data is the flag: no fence, no separate flag word — guide §6 G16 R2 /
+// NCCL "LL").  Receive buffers are allocated fine-grained (uncached) by the library so that a peer's stores become
+// visible to a spinning kernel; they are double-buffered by epoch parity: rank A can only overwrite the slot of epoch
+// e at epoch e+2, which it reaches only after receiving B's epoch e+1 data, i.e. after B finished reading epoch e.
+//   one-shot  (count <= VH_COMM_ONESHOT_MAX): 7 remote stores + 8 local polls per element, one exchange.
+//   two-shot  (larger, the prefill messages): reduce-scatter — rank r pushes slice s of its vector to slice owner s,
+//             the owner sums the world contributions in rank order — then all-gather — the owner pushes the reduced
+//             slice to every rank.  1.75 N granules per rank instead of 7 N, spread over all 7 links at once
+//             (a ring moves 2 (W-1)/W N over ONE link per direction).
+// Every spin is bounded; a time-out sets the error word read by vh_comm_status().  Bring-up (vita_amd/parallel.py)
+// self-tests the path against torch.distributed before it is used and falls back to RCCL otherwise.
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vita_hip.h"
+#include "vh_common.h"
+
+#define VH_COMM_MAX_WORLD 8
+#define VH_COMM_ONESHOT_MAX 32768          // elements: 256 KB of granules per peer slot
+#define VH_COMM_SPIN_LIMIT (1u << 26)      // polls (with s_sleep): seconds, never a device hang
+
+struct vh_comm {
+    int rank, world;
+    size_t cap;                              // fp32 elements per all-reduce
+    size_t region;                           // granules per parity region
+    uint64_t* local;                         // [2 parity][region] granules, fine-grained
+    uint64_t* peer[VH_COMM_MAX_WORLD];       // every rank's buffer as mapped here (peer[rank] == local)
+    bool opened[VH_COMM_MAX_WORLD];
+    int* err;                                // device error word
+    uint32_t epoch;
+    bool connected;
+};
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void put(uint64_t* p, uint32_t tag, float v) {
+    __hip_atomic_store(reinterpret_cast<u64*>(p), ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// poll one granule until its tag is `tag`; returns the value (0 and *err = code on time-out)
+__device__ __forceinline__ float get(const uint64_t* p, uint32_t tag, int* err, int code) {
+    unsigned spins = 0;
+    for (;;) {
+        const u64 x = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((uint32_t)(x >> 32) == tag) return __uint_as_float((uint32_t)x);
+        if (++spins > VH_COMM_SPIN_LIMIT) {
+            __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0.f;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+struct Peers { uint64_t* p[VH_COMM_MAX_WORLD]; };
+
+// region layout (granules): one-shot: slot r at [r * cap, ...)
+__global__ __launch_bounds__(256) void k_ar_oneshot(float* __restrict__ buf, long count, Peers peers, uint64_t* local,
+                                                    size_t cap, int rank, int world, uint32_t tag, int* err) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float v = buf[i];
+        for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)rank * cap + i, tag, v);
+        float s = 0.f;
+        for (int r = 0; r < world; ++r) s += get(local + (size_t)r * cap + i, tag, err, 1);   // rank order: same sum everywhere
+        buf[i] = s;
+    }
+}
+
+// two-shot: region A (contributions) = [src rank][slice elements] at offset 0, region B (reduced slices) = [element] at
+// offset world * slice.  slice = ceil(count / world) elements, slice s owned by rank s.
+__global__ __launch_bounds__(256) void k_ar_twoshot(float* __restrict__ buf, long count, Peers peers, uint64_t* local,
+                                                    long slice, int rank, int world, uint32_t tag, int* err) {
+    const long nthr = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    // 1. push my contribution to every slice's owner
+    for (long i = t0; i < count; i += nthr) {
+        const int s = (int)(i / slice);
+        put(peers.p[s] + (size_t)rank * slice + (i - (long)s * slice), tag, buf[i]);
+    }
+    // 2. reduce the slice I own (rank order) and push the result to every rank
+    const long lo = (long)rank * slice, n_own = min(slice, count - lo);
+    uint64_t* const bofs = nullptr; (void)bofs;
+    for (long j = t0; j < n_own; j += nthr) {
+        float s = 0.f;
+        for (int r = 0; r < world; ++r) s += get(local + (size_t)r * slice + j, tag, err, 2);
+        for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)world * slice + lo + j, tag, s);
+    }
+    // 3. collect every reduced slice
+    for (long i = t0; i < count; i += nthr) buf[i] = get(local + (size_t)world * slice + i, tag, err, 3);
+}
+
+thread_local char g_cerr[256] = "";
+int cfail(int code, const char* msg, hipError_t e = hipSuccess) {
+    if (e != hipSuccess) snprintf(g_cerr, sizeof(g_cerr), "%s: %s", msg, hipGetErrorString(e));
+    else snprintf(g_cerr, sizeof(g_cerr), "%s", msg);
+    return code;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vh_comm_last_error(void) { return g_cerr; }
+
+vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_out) {
+    if (rank < 0 || world < 2 || world > VH_COMM_MAX_WORLD || rank >= world || cap_elems == 0 || !handle_out) {
+        cfail(VH_E_ARG, "vh_comm_create: bad arguments (2 <= world <= 8)");
+        return nullptr;
+    }
+    vh_comm* c = new vh_comm{};
+    c->rank = rank; c->world = world; c->cap = cap_elems;
+    // one-shot needs world * cap granules; two-shot world * slice (contributions) + count (reduced) <= 2 * cap + world
+    const size_t oneshot = (size_t)world * (cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX);
+    const size_t twoshot = 2 * cap_elems + 2 * (size_t)world;
+    c->region = oneshot > twoshot ? oneshot : twoshot;
+    const size_t bytes = 2 * c->region * sizeof(uint64_t);
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->local), bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {   // (same-device tests do not need the coherent flavour)
+        (void)hipGetLastError();
+        e = hipMalloc(reinterpret_cast<void**>(&c->local), bytes);
+    }
+    if (e != hipSuccess) { cfail(VH_E_HIP, "vh_comm_create: buffer allocation", e); delete c; return nullptr; }
+    if ((e = hipMemset(c->local, 0, bytes)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void**>(&c->err), sizeof(int))) != hipSuccess ||
+        (e = hipMemset(c->err, 0, sizeof(int))) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        cfail(VH_E_HIP, "vh_comm_create: initialisation", e);
+        hipFree(c->local); delete c; return nullptr;
+    }
+    hipIpcMemHandle_t h;
+    if ((e = hipIpcGetMemHandle(&h, c->local)) != hipSuccess) {
+        cfail(VH_E_HIP, "vh_comm_create: hipIpcGetMemHandle", e);
+        hipFree(c->local); hipFree(c->err); delete c; return nullptr;
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    memcpy(handle_out, &h, sizeof(h));
+    c->peer[rank] = c->local;
+    c->epoch = 0;
+    return c;
+}
+
+int vh_comm_connect(vh_comm_t* c, const void* handles) {
+    if (!c || !handles) return cfail(VH_E_ARG, "vh_comm_connect: null argument");
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char*>(handles) + (size_t)r * 64, 64);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return cfail(VH_E_COMM, "vh_comm_connect: hipIpcOpenMemHandle", e);
+        c->peer[r] = static_cast<uint64_t*>(p);
+        c->opened[r] = true;
+    }
+    c->connected = true;
+    return VH_OK;
+}
+
+size_t vh_comm_capacity(const vh_comm_t* c) { return c ? c->cap : 0; }
+
+int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
+    if (!c || !buf) return cfail(VH_E_ARG, "vh_comm_allreduce: null argument");
+    if (!c->connected) return cfail(VH_E_COMM, "vh_comm_allreduce: not connected");
+    if (count < 0 || (size_t)count > c->cap) return cfail(VH_E_SHAPE, "vh_comm_allreduce: message above the capacity");
+    if (count == 0) return VH_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    c->epoch += 1;
+    if (c->epoch == 0) c->epoch = 1;                       // tag 0 = never written
+    uint64_t* local = c->local + (size_t)(c->epoch & 1) * c->region;
+    Peers peers{};
+    for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r] + (size_t)(c->epoch & 1) * c->region;
+    if (count <= VH_COMM_ONESHOT_MAX) {
+        const size_t cap1 = c->cap < VH_COMM_ONESHOT_MAX ? c->cap : VH_COMM_ONESHOT_MAX;
+        const int grid = (int)((count + 255) / 256);
+        hipLaunchKernelGGL(k_ar_oneshot, dim3(grid), dim3(256), 0, st, buf, count, peers, local, cap1, c->rank, c->world,
+                           c->epoch, c->err);
+    } else {
+        const long slice = (count + c->world - 1) / c->world;
+        long g = (count + 255) / 256;
+        if (g > 128) g = 128;                              // fully resident next to the compute stream's kernels
+        hipLaunchKernelGGL(k_ar_twoshot, dim3((int)g), dim3(256), 0, st, buf, count, peers, local, slice, c->rank, c->world,
+                           c->epoch, c->err);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cfail(VH_E_HIP, "vh_comm_allreduce: launch", e);
+    return VH_OK;
+}
+
+int vh_comm_status(vh_comm_t* c) {
+    if (!c) return -1;
+    int v = 0;
+    if (hipMemcpy(&v, c->err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;   // 0 = no spin ever timed out; 1 / 2 / 3 = phase that did
+}
+
+void vh_comm_destroy(vh_comm_t* c) {
+    if (!c) return;
+    for (int r = 0; r < c->world; ++r)
+        if (c->opened[r]) hipIpcCloseMemHandle(c->peer[r]);
+    hipFree(c->local);
+    hipFree(c->err);
+    delete c;
+}
+
+}  // extern "C"

@@ -62,6 +62,7 @@ class MixtralEngine:
         if not self.h:
             check(-1, "vh_mixtral_create")
         self._ar_cb = None
+        self._comm = None
         self._tok_ptr = self.lib.vh_mixtral_tokens(self.h)
         self._cnt_ptr = self.lib.vh_mixtral_counters(self.h)
         self._logit_ptr = self.lib.vh_mixtral_logits(self.h)
@@ -79,6 +80,9 @@ class MixtralEngine:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def close(self):
+        if getattr(self, "_comm", None) is not None and getattr(self, "h", None):
+            self.lib.vh_mixtral_use_comm(self.h, None)
+            self._comm = None
         if getattr(self, "h", None):
             self.lib.vh_mixtral_destroy(self.h)
             self.h = None
@@ -93,6 +97,11 @@ class MixtralEngine:
     def use_rccl(self, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         check(self.lib.vh_mixtral_init_rccl(self.h, buf), "vh_mixtral_init_rccl")
+
+    def attach_comm(self, comm):
+        """route the per-layer all-reduces through the library's IPC all-reduce (vita_amd.parallel.IpcComm); None detaches."""
+        check(self.lib.vh_mixtral_use_comm(self.h, comm.ptr if comm is not None else None), "vh_mixtral_use_comm")
+        self._comm = comm
 
     def cancel_rccl(self):
         """give up on a use_rccl() still running in another thread: it then discards its communicator."""
@@ -158,6 +167,9 @@ class MixtralEngine:
     def check_device_flag(self, counters=None):
         """raise if a kernel reported a device-side error (counters[3]: hand-off / all-reduce spin time-out)."""
         c = self.counters.tolist() if counters is None else counters
+        comm = getattr(self, "_comm", None)
+        if comm is not None and comm.status() != 0:
+            raise _lib.VitaHipError(f"all-reduce spin time-out (phase {comm.status()}): a peer rank is not responding")
         if c[3] != 0:
             raise _lib.VitaHipError("device-side time-out (fused decode hand-off or all-reduce): error flag set, "
                                     "the tokens of this request are not trustworthy")

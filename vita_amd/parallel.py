@@ -59,44 +59,92 @@ def native_rccl(eng, rank, dist, device, backend, timeout_s=180):
     return agreed
 
 
+class IpcComm:
+    """The library's own all-reduce over IPC-mapped peer buffers (include/vita_hip.h vh_comm_*): create on every rank,
+    exchange the 64-byte handles through any bootstrap channel, connect, then allreduce(tensor) in lock step."""
+
+    def __init__(self, rank, world, cap_elems):
+        from . import _lib
+        self.lib = _lib.load()
+        self._handle = ctypes.create_string_buffer(64)
+        self.rank, self.world = int(rank), int(world)
+        self.ptr = self.lib.vh_comm_create(self.rank, self.world, int(cap_elems), self._handle)
+        if not self.ptr:
+            raise _lib.VitaHipError("vh_comm_create failed: " + (self.lib.vh_comm_last_error() or b"").decode())
+
+    @property
+    def handle(self):
+        return bytes(self._handle.raw)
+
+    def connect(self, handles):
+        from . import _lib
+        buf = ctypes.create_string_buffer(b"".join(handles), 64 * len(handles))
+        if self.lib.vh_comm_connect(self.ptr, buf) != 0:
+            raise _lib.VitaHipError("vh_comm_connect failed: " + (self.lib.vh_comm_last_error() or b"").decode())
+
+    @property
+    def capacity(self):
+        return int(self.lib.vh_comm_capacity(self.ptr))
+
+    def allreduce(self, t):
+        """in-place sum of a contiguous float32 device tensor across the ranks, on torch's current stream."""
+        from . import _lib
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("IpcComm.allreduce wants a contiguous float32 device tensor")
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.lib.vh_comm_allreduce(self.ptr, t.data_ptr(), t.numel(), st) != 0:
+            raise _lib.VitaHipError("vh_comm_allreduce failed: " + (self.lib.vh_comm_last_error() or b"").decode())
+        return t
+
+    def status(self):
+        return int(self.lib.vh_comm_status(self.ptr))
+
+    def destroy(self):
+        if self.ptr:
+            self.lib.vh_comm_destroy(self.ptr)
+            self.ptr = None
+
+
 def ipc_allreduce(eng, rank, world, dist, device, backend):
-    """The library's own all-reduce over IPC-mapped peer buffers; self-tested against torch.distributed before use."""
-    ok = 0
+    """Bring up IpcComm for the engine and self-test it against torch.distributed before use.  Returns True when every
+    rank's self-test passed (the engine then routes its all-reduces through it)."""
+    comm, ok = None, 0
     try:
-        eng.comm_create(rank, world)
+        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden)
         handles = [None] * world
-        dist.all_gather_object(handles, eng.comm_handle())
-        eng.comm_connect(handles)
+        dist.all_gather_object(handles, comm.handle)
+        comm.connect(handles)
         ok = 1
     except Exception as e:
         print(f"[vita_amd.parallel] rank {rank}: IPC all-reduce bring-up failed: {e}", file=sys.stderr)
     if not _agree(dist, ok, device, backend):
-        eng.comm_destroy()
+        if comm is not None:
+            comm.destroy()
         return False
-    # self-test: three sizes (decode message, odd size, a prefill-sized message) against torch.distributed
     good = 1
     try:
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        for n in (eng.c.hidden, 1000, min(eng.comm_capacity(), 300 * eng.c.hidden)):
-            x = torch.randn(n, generator=g).to(device)
+        for n in (eng.c.hidden, 1000, min(comm.capacity, 300 * eng.c.hidden)):   # decode message, odd size, prefill-sized
+            x = torch.randn(n, generator=g)
             ref = x.clone()
-            dist.all_reduce(ref) if backend == "nccl" else None
-            if backend != "nccl":
-                c = x.cpu()
-                dist.all_reduce(c)
-                ref = c.to(device)
-            eng.comm_allreduce(x)
+            if backend == "nccl":
+                ref = ref.to(device)
+                dist.all_reduce(ref)
+            else:
+                dist.all_reduce(ref)
+                ref = ref.to(device)
+            y = comm.allreduce(x.to(device))
             torch.cuda.synchronize()
-            if eng.comm_status() != 0 or not torch.allclose(x, ref, rtol=1e-5, atol=1e-5):
+            if comm.status() != 0 or not torch.allclose(y, ref, rtol=1e-5, atol=1e-5):
                 good = 0
                 break
     except Exception as e:
         print(f"[vita_amd.parallel] rank {rank}: IPC all-reduce self-test failed: {e}", file=sys.stderr)
         good = 0
     if not _agree(dist, good, device, backend):
-        eng.comm_destroy()
+        comm.destroy()
         return False
-    eng.use_comm()
+    eng.attach_comm(comm)
     return True
 
 
@@ -114,7 +162,7 @@ def setup_tensor_parallel(engine, rank, world, device, backend="nccl", collectiv
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if collective in ("auto", "ipc") and hasattr(engine, "comm_create"):
+    if collective in ("auto", "ipc") and hasattr(engine, "attach_comm"):
         if ipc_allreduce(engine, rank, world, dist, device, backend):
             return "ipc"
         if collective == "ipc":
