@@ -59,8 +59,9 @@ def test_ipc_allreduce_two_processes_one_gpu():
         assert r0[key][1] == r1[key][1], key                                             # bit-identical across ranks
 
 
-def _tp_worker(rank, world, port, ret):
+def _tp_worker(rank, world, port, overlap, ret):
     import torch.distributed as dist
+    from vita_amd import _lib
     from vita_amd.checkpoint import pack_mixtral, synth_state_dict
     from vita_amd.config import VitaConfig
     from vita_amd.engine import MixtralEngine
@@ -74,6 +75,7 @@ def _tp_worker(rank, world, port, ret):
         sd = synth_state_dict(cfg, seed=3, parts=("text",))
         packed = pack_mixtral(sd, cfg, dev, rank=rank, world=world)
         eng = MixtralEngine(cfg, packed, dev, max_ctx=128, max_prefill=64, max_new=16, rank=rank, world=world, logit_rows=16)
+        _lib.tune("tp_overlap", overlap)
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
         rng = np.random.default_rng(5)
         ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
@@ -88,15 +90,18 @@ def _tp_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev):
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap):
     """two engine processes (TP = 2, one GPU) with the IPC all-reduce installed by setup_tensor_parallel: greedy ids
-    equal the unsharded fp32 oracle's, logits within 1e-3, both ranks identical."""
+    equal the unsharded fp32 oracle's, logits within 1e-3, both ranks identical.  overlap = 1: the prefill's
+    o_proj / MoE-down GEMMs run as column halves with the all-reduce of one half on the comm stream under the GEMM of
+    the other (the default); 0: one all-reduce per sub-block on the compute stream."""
     import torch.multiprocessing as mp
     from oracle import mixtral as om
     from vita_amd.checkpoint import synth_state_dict
     from vita_amd.config import VitaConfig
     ret = mp.Manager().dict()
-    mp.spawn(_tp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_tp_worker, args=(2, _free_port(), overlap, ret), nprocs=2, join=True)
     cfg = VitaConfig.tiny()
     sd = synth_state_dict(cfg, seed=3, parts=("text",))
     rng = np.random.default_rng(5)

@@ -52,6 +52,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "ps_grid")) { g_tuning.ps_grid = value; return VH_OK; }
     if (!strcmp(key, "ps_nt")) { g_tuning.ps_nt = value; return VH_OK; }
     if (!strcmp(key, "moe_ksplit")) { g_tuning.moe_ksplit = value; return VH_OK; }
+    if (!strcmp(key, "tp_overlap")) { g_tuning.tp_overlap = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
@@ -258,6 +259,18 @@ struct vh_mixtral {
         if (lm_grid > 1024) lm_grid = 1024;
     }
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
+    hipStream_t cs = nullptr;    // communication stream of the overlapped tensor-parallel prefill
+    hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // half computed / half reduced
+    // the collective can run on another stream than the compute stream (native RCCL, IPC) — the Python callback cannot
+    bool stream_capable() const { return comm != nullptr || rccl_comm != nullptr; }
+    int ensure_comm_stream() {
+        if (cs) return 0;
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return -1;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&ev_c[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_r[i], hipEventDisableTiming) != hipSuccess) return -1;
+        return 0;
+    }
     int allreduce(float* buf, long count, hipStream_t st) {
         if (c.tp_world <= 1 && !vh_tuning()->force_allreduce) return 0;
         if (comm && (size_t)count <= vh_comm_capacity(comm)) return vh_comm_allreduce(comm, buf, count, st) == VH_OK ? 0 : -1;
@@ -325,6 +338,8 @@ vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_laye
 void vh_mixtral_destroy(vh_mixtral_t* m) {
     if (!m) return;
     for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) hipEventDestroy(m->ev_r[i]); }
+    if (m->cs) hipStreamDestroy(m->cs);
     if (m->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->rccl_comm);
     delete m;
 }
@@ -445,6 +460,15 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     if (hipMemsetAsync(m->counters + 1, 0, 3 * sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
     m->attn_epoch = 0;
     m->poisoned = 0;
+    // overlapped tensor-parallel prefill: needs a collective that takes a stream, and halves that stay 16-byte rows
+    const int H2 = H / 2;
+    const bool overlap = tp && vh_tuning()->tp_overlap != 0 && m->stream_capable() && (H2 % 4) == 0 && Sn >= 16;
+    if (overlap) {
+        if (m->ensure_comm_stream() != 0) return fail(VH_E_HIP, "prefill: comm stream creation failed");
+        // the comm stream starts behind everything already queued on the compute stream
+        hipEventRecord(m->ev_c[0], st);
+        hipStreamWaitEvent(m->cs, m->ev_c[0], 0);
+    }
 
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
@@ -473,15 +497,33 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
             VhGemmArgs g{};
             g.A = m->pattn; g.lda = (long)nq * hd; g.a_rows = Sn; g.nseg = 1; g.seglen = nq * hd;
             g.W = w.wo; g.ldw = (long)nq * hd; g.M = Sn; g.N = H; g.K = nq * hd;
-            if (tp) { g.C = m->ptmp; g.ldc = H; }
-            else { g.C = m->px; g.ldc = H; g.resid = m->px; g.ldr = H; }
-            VH_TRY(vhk_gemm(st, g), "o gemm");
-            if (tp) {
-                if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
-                VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+            if (tp && overlap) {
+                // column halves: the all-reduce of half 0 (comm stream) runs under the GEMM of half 1 (SURVEY 8(e);
+                // o_proj is RowParallel in the reference: vllm_file/mixtral.py:470-476)
+                for (int h = 0; h < 2; ++h) {
+                    float* part = m->ptmp + (size_t)h * Sn * H2;
+                    g.W = w.wo + (size_t)h * H2 * g.ldw; g.N = H2; g.C = part; g.ldc = H2;
+                    VH_TRY(vhk_gemm(st, g), "o gemm");
+                    hipEventRecord(m->ev_c[h], st);
+                    hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
+                    if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                    hipEventRecord(m->ev_r[h], m->cs);
+                }
+                hipStreamWaitEvent(st, m->ev_r[0], 0);
+                hipStreamWaitEvent(st, m->ev_r[1], 0);
+                VH_TRY(vhk_add_halves(st, m->px, m->ptmp, m->ptmp + (size_t)Sn * H2, Sn, H), "add");
+            } else {
+                if (tp) { g.C = m->ptmp; g.ldc = H; }
+                else { g.C = m->px; g.ldc = H; g.resid = m->px; g.ldr = H; }
+                VH_TRY(vhk_gemm(st, g), "o gemm");
+                if (tp) {
+                    if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                    VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+                }
             }
         }
         const bool stream_moe = vh_tuning()->prefill_moe_gemm == 0;
+        bool moe_done = false;
         int nslab = 1;
         const long slab = (long)2 * m->c.max_prefill * H;
         if (stream_moe) {
@@ -507,7 +549,31 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
             d.group_off = m->pgoff; d.ngroups = E;
             d.C = m->py; d.ldc = H; d.c_rowidx = m->psslot; d.M = 2 * Sn; d.N = H; d.K = I;
             d.ksplit = nslab; d.c_split_stride = slab;
-            VH_TRY(vhk_gemm_ps(st, d), "down gemm");
+            if (tp && overlap) {
+                // "all-reduce over xGMI overlapped with the expert GEMMs" (FusedMoE reduce_results, vllm_file/
+                // mixtral.py:405-414): the down projection runs as two COLUMN halves (disjoint weight rows); half
+                // 0 is combined and all-reduced on the comm stream while half 1 streams its weights
+                const long hslab = (long)2 * m->c.max_prefill * H2;            // one K-split slab of a half
+                for (int h = 0; h < 2; ++h) {
+                    float* yh = m->py + (size_t)h * 2 * hslab;
+                    float* part = m->ptmp + (size_t)h * Sn * H2;
+                    d.W = w.w2 + (size_t)h * H2 * I; d.N = H2; d.C = yh; d.ldc = H2; d.c_split_stride = hslab;
+                    VH_TRY(vhk_gemm_ps(st, d), "down gemm");
+                    if (hipMemsetAsync(part, 0, (size_t)Sn * H2 * sizeof(float), st) != hipSuccess)
+                        return fail(VH_E_HIP, "memset failed");
+                    VH_TRY(vhk_moe_combine(st, part, yh, m->pwts, Sn, H2, nslab, hslab), "combine");
+                    hipEventRecord(m->ev_c[h], st);
+                    hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
+                    if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                    hipEventRecord(m->ev_r[h], m->cs);
+                }
+                hipStreamWaitEvent(st, m->ev_r[0], 0);
+                hipStreamWaitEvent(st, m->ev_r[1], 0);
+                VH_TRY(vhk_add_halves(st, m->px, m->ptmp, m->ptmp + (size_t)Sn * H2, Sn, H), "add");
+                moe_done = true;
+            } else {
+                VH_TRY(vhk_gemm_ps(st, d), "down gemm");
+            }
         } else {
             VH_TRY(vhk_rmsnorm_route(st, m->px, m->pxn, nullptr, nullptr, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter, E,
                                      m->pids, m->pwts), "rmsnorm + route");
@@ -529,7 +595,8 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
                 VH_TRY(vhk_gemm(st, g), "down gemm");
             }
         }
-        if (tp) {
+        if (moe_done) {
+        } else if (tp) {
             if (hipMemsetAsync(m->ptmp, 0, (size_t)Sn * H * sizeof(float), st) != hipSuccess)
                 return fail(VH_E_HIP, "memset failed");
             VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H, nslab, slab), "combine");

@@ -160,6 +160,21 @@ __global__ void k_add(float* __restrict__ x, const float* __restrict__ y, long n
     }
 }
 
+// x[r, :] += [a[r, :] | b[r, :]]  (a, b: the two column halves [rows][cols/2] of the overlapped TP prefill)
+__global__ void k_add_halves(float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b, int rows,
+                             int cols4) {
+    const long total = (long)rows * cols4;
+    const int h4 = cols4 / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        const float4 v = c < h4 ? reinterpret_cast<const float4*>(a)[r * h4 + c] : reinterpret_cast<const float4*>(b)[r * h4 + c - h4];
+        float4 o = reinterpret_cast<float4*>(x)[i];
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        reinterpret_cast<float4*>(x)[i] = o;
+    }
+}
+
 __global__ void k_cast_bf16_f32(const uint16_t* __restrict__ in, float* __restrict__ out, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = bf16_to_f32(in[i]);
@@ -400,6 +415,12 @@ int vhk_rmsnorm(hipStream_t st, const float* x, float* y, const float* w, int ro
 int vhk_add(hipStream_t st, float* x, const float* y, long n) {
     if (n % 4 != 0) return -1;
     hipLaunchKernelGGL(k_add, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, x, y, n / 4);
+    return 0;
+}
+int vhk_add_halves(hipStream_t st, float* x, const float* a, const float* b, int rows, int cols) {
+    if (cols % 8 != 0) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_add_halves, dim3(grid_for((long)rows * (cols / 4), 256)), dim3(256), 0, st, x, a, b, rows, cols / 4);
     return 0;
 }
 int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n) {

@@ -17,6 +17,7 @@ struct VhTuning {
     int ps_cfg = -1;          // vh_gemm_ps variant: -1 = by rows per group, 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights
     int ps_grid = 0;          // vh_gemm_ps persistent grid (0 = one block per CU)
     int ps_nt = -1;           // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
+    int tp_overlap = 1;       // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
     int moe_ksplit = 2;       // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel)
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
 };
@@ -100,6 +101,7 @@ int vhk_layernorm(hipStream_t st, const float* x, long ldx, float* y, long ldy, 
                   int rows, int cols, float eps, int act, float post_scale);
 int vhk_rmsnorm(hipStream_t st, const float* x, float* y, const float* w, int rows, int cols, float eps);
 int vhk_add(hipStream_t st, float* x, const float* y, long n);
+int vhk_add_halves(hipStream_t st, float* x, const float* a, const float* b, int rows, int cols);
 int vhk_vit_patchify(hipStream_t st, const float* pix, float* out, int n, int img, int patch, int kpad);
 int vhk_vit_assemble(hipStream_t st, const float* patches, const uint16_t* cls, const uint16_t* pos, float* x, int n,
                      int ntok, int hid);
