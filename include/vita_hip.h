@@ -138,6 +138,9 @@ typedef struct {
     int tp_rank, tp_world;/* n_q_heads / n_kv_heads / inter above are THIS RANK's slices */
     int nsplit;           /* decode split-KV factor, 0 = auto */
     int logit_rows;       /* >1: keep the fp32 logits of the first logit_rows generated tokens */
+    int vocab_lo, vocab_n;/* vocab-sharded LM head (ParallelLMHead, vllm_file/mixtral.py:939-951): `lm_head` holds rows
+                             [vocab_lo, vocab_lo + vocab_n) of the table; the ranks exchange (max, index) candidates
+                             through the all-reduce hook.  vocab_n == 0: the whole table on every rank. */
 } vh_mixtral_cfg;
 
 typedef struct {

@@ -83,7 +83,9 @@ def _tp_worker(rank, world, port, overlap, ret):
         eng.prefill(emb)
         eng.decode(9)
         torch.cuda.synchronize()
-        ret[rank] = (name, eng.generated(), eng.logits_all[:10].cpu().numpy())
+        lg = eng.logits_all[:10].cpu()
+        dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
+        ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n))
         dist.barrier()
         eng.close()
     finally:
@@ -108,6 +110,8 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap):
     ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
     ref_ids, ref_lg = om.MixtralOracle(sd, cfg.text).greedy(sd["model.embed_tokens.weight"][ids], 10)
     assert ret[0][0] == ret[1][0] == "ipc"
+    V = cfg.text.vocab_size
+    assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
     assert ret[0][1] == ret[1][1] == ref_ids
     assert np.array_equal(ret[0][2], ret[1][2])
     assert np.abs(ret[0][2] - ref_lg).max() < 1e-3

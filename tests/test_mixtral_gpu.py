@@ -96,11 +96,14 @@ def test_gateup_kernel_variants(dev, variant):
         _lib.tune("gateup_variant", 0)
 
 
-def test_tp2_two_ranks_on_one_gpu(dev):
+@pytest.mark.parametrize("shard_vocab", [True, False])
+def test_tp2_two_ranks_on_one_gpu(dev, shard_vocab):
     """Tensor parallel without a second GPU: both ranks' engines live on this GPU and
     run in lock-step from two host threads; the all-reduce hook sums the two partial buffers.
     Checks the sharded packing, the per-rank kernels at sliced shapes (1 kv head, I/2) and the
-    placement of the two collectives per layer against the unsharded oracle."""
+    placement of the two collectives per layer against the unsharded oracle.  shard_vocab: the LM head holds half
+    of the vocabulary per rank and the (max, index) candidates take one more all-reduce per forward
+    (ParallelLMHead + logits gather of the reference's vLLM flavour, vllm_file/mixtral.py:939-951)."""
     import ctypes as C
     import threading
     from vita_amd import _lib
@@ -112,7 +115,7 @@ def test_tp2_two_ranks_on_one_gpu(dev):
     emb = sd["model.embed_tokens.weight"][rng.integers(3, cfg.text.vocab_size, size=S)]
     ref_ids, ref_lg = om.MixtralOracle(sd, cfg.text).greedy(emb, n_new)
 
-    engs = [MixtralEngine(cfg, pack_mixtral(sd, cfg, dev, rank=r, world=world), dev, max_ctx=S + n_new + 8,
+    engs = [MixtralEngine(cfg, pack_mixtral(sd, cfg, dev, rank=r, world=world, shard_vocab=shard_vocab), dev, max_ctx=S + n_new + 8,
                           max_prefill=S, max_new=n_new + 4, rank=r, world=world, logit_rows=n_new + 4)
             for r in range(world)]
     bar = threading.Barrier(world)
@@ -159,11 +162,17 @@ def test_tp2_two_ranks_on_one_gpu(dev):
     torch.cuda.synchronize()
     assert not errs, errs
     L = cfg.text.num_hidden_layers
-    assert n_calls == [2 * L * n_new] * world            # 2 collectives per layer per forward
+    assert n_calls == [(2 * L + (1 if shard_vocab else 0)) * n_new] * world   # 2 collectives per layer (+ candidates) per forward
     for r in range(world):
         assert engs[r].generated() == ref_ids, f"rank {r} tokens differ from the unsharded oracle"
-        for i in range(n_new):
-            assert_close(f"rank {r} logits step {i}", to_np(engs[r].logits_all[i]), ref_lg[i], atol=LOGIT_TOL)
+    for i in range(n_new):
+        if shard_vocab:      # each rank kept its slice of the row (zeros elsewhere): the sum is the full row
+            assert_close(f"logits step {i}", to_np(engs[0].logits_all[i] + engs[1].logits_all[i]), ref_lg[i], atol=LOGIT_TOL)
+            half = (cfg.text.vocab_size + 1) // 2
+            assert float(engs[0].logits_all[i][half:].abs().max()) == 0.0 and float(engs[1].logits_all[i][:half].abs().max()) == 0.0
+        else:
+            for r in range(world):
+                assert_close(f"rank {r} logits step {i}", to_np(engs[r].logits_all[i]), ref_lg[i], atol=LOGIT_TOL)
     [e.close() for e in engs]
 
 

@@ -60,6 +60,7 @@ class MixtralCfg(C.Structure):
         ("head_dim", c_int), ("inter", c_int), ("n_experts", c_int), ("top_k", c_int), ("vocab", c_int),
         ("rms_eps", c_float), ("max_ctx", c_int), ("max_prefill", c_int), ("max_new", c_int),
         ("tp_rank", c_int), ("tp_world", c_int), ("nsplit", c_int), ("logit_rows", c_int),
+        ("vocab_lo", c_int), ("vocab_n", c_int),
     ]
 
 

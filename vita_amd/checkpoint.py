@@ -165,16 +165,30 @@ def tp_slices(cfg_text, rank, world):
     return q, kv, ff
 
 
-def pack_mixtral(sd, cfg: VitaConfig, device, rank=0, world=1):
+def vocab_shard(vocab, rank, world):
+    """rows of the LM head on this rank: ceil(V / world) consecutive rows, the last rank takes the remainder
+    (ParallelLMHead of the reference's vLLM flavour, vllm_file/mixtral.py:939-951; no padding rows: the candidate
+    exchange carries global indices)."""
+    if world <= 1:
+        return 0, vocab
+    per = -(-vocab // world)
+    lo = min(rank * per, vocab)
+    return lo, max(0, min(per, vocab - lo))
+
+
+def pack_mixtral(sd, cfg: VitaConfig, device, rank=0, world=1, shard_vocab=True):
     """state dict (reference names) -> dict of device tensors in engine layout for this TP rank."""
     import torch
     t = cfg.text
     qs, kvs, ff = tp_slices(t, rank, world)
     bf, f32 = torch.bfloat16, torch.float32
     g = lambda k: sd[k]
+    lo, n = vocab_shard(t.vocab_size, rank, world if shard_vocab else 1)
     out = {"embed": _t(g("model.embed_tokens.weight"), device, bf),
            "final_norm": _t(g("model.norm.weight"), device, f32),
-           "lm_head": _t(g("lm_head.weight"), device, bf), "layers": []}
+           "lm_head": _t(g("lm_head.weight")[lo:lo + n], device, bf), "layers": []}
+    if world > 1 and shard_vocab:
+        out["vocab_lo"], out["vocab_n"] = lo, n
     for l in range(t.num_hidden_layers):
         p = LLM.format(l)
         cat = np.concatenate if isinstance(g(p + "self_attn.q_proj.weight"), np.ndarray) else torch.cat
@@ -222,7 +236,7 @@ def hash_fill(dst, name, seed=0, ld_src=None, idx0=0):
     return dst
 
 
-def synth_mixtral_device(cfg: VitaConfig, device, seed=0, rank=0, world=1):
+def synth_mixtral_device(cfg: VitaConfig, device, seed=0, rank=0, world=1, shard_vocab=True):
     """Random-init backbone generated directly on the GPU in packed layout (the full model is 93.7 GB bf16, too
     large to stage through host numpy).  SURVEY §8(d) init (sigma ~0.02, norms 1) from the counter-based generator
     vh_fill_hash_bf16, keyed by the REFERENCE'S parameter names: a tensor-parallel rank's shard holds exactly the
@@ -238,8 +252,11 @@ def synth_mixtral_device(cfg: VitaConfig, device, seed=0, rank=0, world=1):
     bf = torch.bfloat16
     ones = lambda n: torch.ones(n, device=device, dtype=torch.float32)
     new = lambda *shape: torch.empty(shape, device=device, dtype=bf)
+    lo, nv = vocab_shard(t.vocab_size, rank, world if shard_vocab else 1)
     out = {"embed": hash_fill(new(t.vocab_size, H), "model.embed_tokens.weight", seed), "final_norm": ones(H),
-           "lm_head": hash_fill(new(t.vocab_size, H), "lm_head.weight", seed), "layers": []}
+           "lm_head": hash_fill(new(nv, H), "lm_head.weight", seed, idx0=lo * H), "layers": []}
+    if world > 1 and shard_vocab:
+        out["vocab_lo"], out["vocab_n"] = lo, nv
     for l in range(t.num_hidden_layers):
         p = LLM.format(l)
         wqkv = new((nq + 2 * nkv) * hd, H)

@@ -199,6 +199,8 @@ struct vh_mixtral {
     const uint16_t* embed; const float* final_norm; const uint16_t* lm_head;
     const float* rope_cos; const float* rope_sin;
     int nq, nkv, hd, H, I, E, V, nqkv, max_splits, lm_grid;
+    int v0 = 0, Vn = 0;         // this rank's rows of the LM head ([v0, v0 + Vn); the whole table when unsharded)
+    float* cand = nullptr;      // [tp_world][2] (value, index) candidates of the vocab-sharded head
     int host_pos = 0;  // host mirror of counters[0] (sizes the split-KV grid without a device read)
     int attn_epoch = 0;  // fused attention+O-proj launches since the last reset (counters[2] grows by nkv per launch)
     // state
@@ -235,6 +237,7 @@ struct vh_mixtral {
         logits = cv.take<float>((size_t)hist_rows() * V);
         blk_val = cv.take<float>(lm_grid);
         blk_idx = cv.take<int>(lm_grid);
+        cand = cv.take<float>(2 * (c.tp_world > 0 ? c.tp_world : 1));
         route = cv.take<int>(4);
         counters = cv.take<int>(4);  // {pos, n_generated, attn_done (monotonic), device error flag}
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
@@ -255,8 +258,11 @@ struct vh_mixtral {
         nq = c.n_q_heads; nkv = c.n_kv_heads; hd = c.head_dim; H = c.hidden; I = c.inter; E = c.n_experts;
         V = c.vocab; nqkv = (nq + 2 * nkv) * hd;
         max_splits = (c.max_ctx + 63) / 64;
-        lm_grid = (V + 7) / 8;
+        v0 = c.vocab_n > 0 ? c.vocab_lo : 0;
+        Vn = c.vocab_n > 0 ? c.vocab_n : V;
+        lm_grid = (Vn + 7) / 8;
         if (lm_grid > 1024) lm_grid = 1024;
+        if (lm_grid < c.tp_world) lm_grid = c.tp_world;   // blk_val / blk_idx also hold the gathered candidates
     }
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
     hipStream_t cs = nullptr;    // communication stream of the overlapped tensor-parallel prefill
@@ -291,6 +297,9 @@ int cfg_ok(const vh_mixtral_cfg* c) {
     if (c->n_q_heads % c->n_kv_heads || c->n_q_heads / c->n_kv_heads > 4)
         return fail(VH_E_SHAPE, "GQA group must divide and be <= 4");
     if (c->max_ctx < 1 || c->max_prefill < 1 || c->n_layers < 1) return fail(VH_E_SHAPE, "bad sizes");
+    if (c->vocab_n < 0 || c->vocab_lo < 0 || (c->vocab_n > 0 && c->vocab_lo + c->vocab_n > c->vocab))
+        return fail(VH_E_SHAPE, "vocab shard outside the table");
+    if (c->vocab_n > 0 && c->vocab >= (1 << 24)) return fail(VH_E_SHAPE, "vocab-sharded head needs vocab < 2^24");
     return VH_OK;
 }
 int rccl_allreduce_cb(void* user, float* buf, long count, void* stream) {
@@ -441,6 +450,7 @@ static int launch_failed(const char* what) {
     if (e != hipSuccess) return fail(VH_E_HIP, "%s: %s", what, hipGetErrorString(e));
     return fail(VH_E_SHAPE, "%s: launch rejected (shape / arguments)", what);
 }
+static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos);
 #define VH_TRY(expr, what)                             \
     do {                                               \
         if ((expr) != 0) return launch_failed(what);   \
@@ -460,6 +470,9 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     if (hipMemsetAsync(m->counters + 1, 0, 3 * sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
     m->attn_epoch = 0;
     m->poisoned = 0;
+    if (m->c.vocab_n > 0 && m->c.tp_world > 1 &&
+        hipMemsetAsync(m->logits, 0, (size_t)m->hist_rows() * m->V * sizeof(float), st) != hipSuccess)
+        return fail(VH_E_HIP, "memset failed");   // vocab-sharded head: a kept score row holds THIS rank's slice, zeros elsewhere
     // overlapped tensor-parallel prefill: needs a collective that takes a stream, and halves that stay 16-byte rows
     const int H2 = H / 2;
     const bool overlap = tp && vh_tuning()->tp_overlap != 0 && m->stream_capable() && (H2 % 4) == 0 && Sn >= 16;
@@ -614,15 +627,34 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     }
     // logits of the last position only (the reference computes all S rows and uses the last:
     // vita_mixtral.py:171-172 + HF greedy argmax(logits[:, -1]))
-    VH_TRY(vhk_dec_lmhead(st, m->px + (size_t)(Sn - 1) * H, nullptr, m->final_norm, m->c.rms_eps, m->lm_head, m->V, H,
-                          m->logits, m->blk_val, m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "lm_head");
-    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->V, m->xa, m->counters, m->counters + 1,
-                          m->out_tokens, m->c.max_new, /*mode=*/0, /*set_pos=*/pos0 + Sn), "select");
+    {
+        const int rc = head_and_select(m, st, m->px + (size_t)(Sn - 1) * H, nullptr, /*mode=*/0, /*set_pos=*/pos0 + Sn);
+        if (rc != VH_OK) return rc;
+    }
     m->host_pos = pos0 + Sn;
     if (logits_out)
         hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VH_E_HIP, "prefill: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
+// Final norm + LM head + greedy selection.  Vocab-sharded head: every rank scores its rows, the (max, index) candidates
+// travel through the all-reduce hook, every rank takes the same global argmax; when scores are kept (logit_rows > 1)
+// the full row is assembled by an all-reduce of the zero-filled slices.
+static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos) {
+    const bool sharded = m->c.vocab_n > 0 && m->c.tp_world > 1;
+    VH_TRY(vhk_dec_lmhead(st, x_in, delta, m->final_norm, m->c.rms_eps, m->lm_head, m->Vn, m->H, m->logits, m->blk_val,
+                          m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows(), m->v0, m->V), "lm_head");
+    int nblk = m->lm_grid;
+    if (sharded) {
+        VH_TRY(vhk_dec_cand(st, m->blk_val, m->blk_idx, m->lm_grid, m->cand, m->c.tp_rank, m->c.tp_world), "candidates");
+        if (m->allreduce(m->cand, 2L * m->c.tp_world, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        VH_TRY(vhk_dec_cand_unpack(st, m->cand, m->c.tp_world, m->blk_val, m->blk_idx), "candidates");
+        nblk = m->c.tp_world;
+    }
+    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, nblk, m->embed, m->H, m->V, m->xa, m->counters, m->counters + 1,
+                          m->out_tokens, m->c.max_new, mode, set_pos), "select");
     return VH_OK;
 }
 
@@ -663,10 +695,10 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
         VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe), "dec down");
         if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
     }
-    VH_TRY(vhk_dec_lmhead(st, m->xa, m->delta_moe, m->final_norm, eps, m->lm_head, m->V, H, m->logits, m->blk_val,
-                          m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows()), "dec lm_head");
-    VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, m->lm_grid, m->embed, H, m->V, m->xa, m->counters,
-                          m->counters + 1, m->out_tokens, m->c.max_new, /*mode=*/1, /*set_pos=*/0), "dec select");
+    {
+        const int rc = head_and_select(m, st, m->xa, m->delta_moe, /*mode=*/1, /*set_pos=*/0);
+        if (rc != VH_OK) return rc;
+    }
     const hipError_t e = hipGetLastError();   // checked per step: the mirrors below must not run ahead of a failed launch
     if (e != hipSuccess) return fail(VH_E_HIP, "decode: %s", hipGetErrorString(e));
     return VH_OK;

@@ -564,13 +564,15 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
                                                     const uint16_t* __restrict__ W, int V, int K,
                                                     float* __restrict__ logits, float* __restrict__ blk_val,
                                                     int* __restrict__ blk_idx, const int* __restrict__ ngen_ptr,
-                                                    int hist_rows) {
+                                                    int hist_rows, int v0, int Vfull) {
     __shared__ float red[4 * (LM_R + 1)];
     __shared__ float bv_s[LM_R];
     __shared__ int bi_s[LM_R];
     // logits history: row = index of the token this step produces (clamped), so the host can
     // read every step's scores after a multi-step launch (HF generate(output_scores=True)).
-    if (hist_rows > 1) logits += (size_t)min(*ngen_ptr, hist_rows - 1) * V;
+    // W holds rows [v0, v0 + V) of the table (vocab-sharded head under tensor parallelism; v0 = 0, V = Vfull otherwise)
+    if (hist_rows > 1) logits += (size_t)min(*ngen_ptr, hist_rows - 1) * Vfull;
+    logits += v0;
     const int n_iter = (V + LM_R - 1) / LM_R;
     auto rows_of = [&](int it, const uint16_t* (&rows)[LM_R]) {
 #pragma unroll
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
             for (int r = 0; r < LM_R; ++r) if (threadIdx.x == r) v = vals[r];
             v *= inv;
             logits[n0 + threadIdx.x] = v;
-            if (v > best) { best = v; besti = n0 + threadIdx.x; }  // ascending n: first max wins
+            if (v > best) { best = v; besti = v0 + n0 + threadIdx.x; }  // ascending n: first max wins
         }
         it = nxt;
     }
@@ -659,6 +661,40 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ bl
         reinterpret_cast<float4*>(x_next)[c * 2 + 1] =
             make_float4(bf16_lo_to_f32(w.z), bf16_hi_to_f32(w.z), bf16_lo_to_f32(w.w), bf16_hi_to_f32(w.w));
     }
+}
+
+// ---- vocab-sharded LM head: this rank's best (value, index) -> its slot of a zeroed [world][2] vector; the
+// all-reduce(sum) of that vector hands every rank every candidate (adding zeros is exact, indices < 2^24 are exact
+// in fp32), k_dec_select then takes the global argmax with the usual lowest-index tie rule on every rank alike.
+__global__ __launch_bounds__(256) void k_dec_cand(const float* __restrict__ blk_val, const int* __restrict__ blk_idx,
+                                                  int nblk, float* __restrict__ cand, int rank, int world) {
+    __shared__ float v_s[256];
+    __shared__ int i_s[256];
+    float b = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        const float v = blk_val[i]; const int ix = blk_idx[i];
+        if (v > b || (v == b && ix < bi)) { b = v; bi = ix; }
+    }
+    v_s[threadIdx.x] = b; i_s[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = v_s[threadIdx.x + s]; const int ix = i_s[threadIdx.x + s];
+            if (v > v_s[threadIdx.x] || (v == v_s[threadIdx.x] && ix < i_s[threadIdx.x])) {
+                v_s[threadIdx.x] = v; i_s[threadIdx.x] = ix;
+            }
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < 2 * world) {
+        float o = 0.f;
+        if ((int)threadIdx.x == 2 * rank) o = v_s[0];
+        if ((int)threadIdx.x == 2 * rank + 1) o = (float)i_s[0];
+        cand[threadIdx.x] = o;
+    }
+}
+__global__ void k_dec_cand_unpack(const float* __restrict__ cand, int world, float* __restrict__ val, int* __restrict__ idx) {
+    if ((int)threadIdx.x < world) { val[threadIdx.x] = cand[2 * threadIdx.x]; idx[threadIdx.x] = (int)cand[2 * threadIdx.x + 1]; }
 }
 
 inline int vh_num_cus() {
@@ -790,12 +826,21 @@ int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint
 
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
-                   const int* ngen_ptr, int hist_rows) {
+                   const int* ngen_ptr, int hist_rows, int v0, int Vfull) {
     return pick_nj(K, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_lmhead<decltype(nj)::value>), dim3(grid), dim3(256), 0, st, x_in, delta, norm_w, eps,
-                           W, V, K, logits, blk_val, blk_idx, ngen_ptr, hist_rows);
+                           W, V, K, logits, blk_val, blk_idx, ngen_ptr, hist_rows, v0, Vfull);
         return 0;
     });
+}
+int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, float* cand, int rank, int world) {
+    if (world < 1 || world > 128) return -1;
+    hipLaunchKernelGGL(k_dec_cand, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, cand, rank, world);
+    return 0;
+}
+int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx) {
+    hipLaunchKernelGGL(k_dec_cand_unpack, dim3(1), dim3(128), 0, st, cand, world, val, idx);
+    return 0;
 }
 
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,

@@ -40,7 +40,9 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out);
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
-                   const int* ngen_ptr, int hist_rows);
+                   const int* ngen_ptr, int hist_rows, int v0, int Vfull);
+int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, float* cand, int rank, int world);
+int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx);
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
                    int vocab, float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
 

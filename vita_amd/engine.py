@@ -42,6 +42,9 @@ class MixtralEngine:
         c.vocab, c.rms_eps = t.vocab_size, t.rms_norm_eps
         c.max_ctx, c.max_prefill, c.max_new = max_ctx, max_prefill, max_new
         c.tp_rank, c.tp_world, c.nsplit, c.logit_rows = rank, world, nsplit, logit_rows
+        c.vocab_lo, c.vocab_n = int(packed.get("vocab_lo", 0)), int(packed.get("vocab_n", 0))   # vocab-sharded LM head
+        if c.vocab_n and packed["lm_head"].shape[0] != c.vocab_n:
+            raise ValueError("packed lm_head does not match its vocab shard")
         self.c = c
         nbytes = self.lib.vh_mixtral_workspace_bytes(C.byref(c))
         if nbytes == 0:

@@ -242,5 +242,17 @@ class VITAMixtralForCausalLM(_HipModule):
         sequences = torch.cat([prompt, torch.tensor([generated], dtype=prompt.dtype, device=self._device)], dim=1)
         if not return_dict_in_generate:
             return sequences
-        scores = tuple(eng.logits_all[i][None].clone() for i in range(len(generated))) if keep_scores else None
+        scores = None
+        if keep_scores:
+            rows = eng.logits_all[:len(generated)].clone()
+            if eng.c.vocab_n and eng.c.tp_world > 1:
+                # vocab-sharded head: a kept row holds this rank's slice and zeros elsewhere; the sum is the full row
+                import torch.distributed as dist
+                if dist.is_initialized() and dist.get_backend() == "nccl":
+                    dist.all_reduce(rows)
+                elif dist.is_initialized():
+                    r = rows.cpu()
+                    dist.all_reduce(r)
+                    rows = r.to(rows.device)
+            scores = tuple(rows[i][None] for i in range(len(generated)))
         return GenerateOutput(sequences=sequences, scores=scores, past_key_values=None)
