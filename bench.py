@@ -58,52 +58,62 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(cfg, n_layers=2, ctx=64, n_tok=6):
-    """The oracle (numpy port of the HF Mixtral arithmetic the reference calls) timed on this box's
-    host cores: `n_layers` real-geometry decoder layers + LM head, decode steps at a short context,
-    extrapolated to 32 layers.  Bounded to a few seconds of weight generation + ~10-20 s of compute."""
+def cpu_baseline(cfg, n_layers=2, ctx=None, n_tok=6, encoders=True, request=None):
+    """The oracle (numpy port of the arithmetic the reference reaches: HF Mixtral, InternViT, Whale) timed on THIS box's
+    host cores, on a bounded sample of the bench's own workload (SURVEY 8(d) "Reference CPU timing" a-c):
+      decode   `n_layers` real-geometry decoder layers + LM head, greedy steps at the bench's real context (prompt S =
+               552 rows in the KV cache), extrapolated to 32 layers; best of a few BLAS thread counts
+      prefill  the same layers over the S-row prompt (the pass that fills that KV cache), extrapolated likewise
+      encoders the full 24-layer InternViT + projector on one tile and the full Whale encoder + adapter on the 10 s
+               clip (fp64 numpy restatements, oracle/encoders.py)
+    Weights come from the counter-based generator (oracle/hashw.py) — values do not matter for timing."""
     import copy
-    from oracle import mixtral as om
+    from oracle import hashw, mixtral as om, stream
     t = copy.deepcopy(cfg.text)
+    L_full = cfg.text.num_hidden_layers
     t.num_hidden_layers = n_layers
-    rng = np.random.default_rng(0)
-    H, I, E, hd = t.hidden_size, t.intermediate_size, t.num_local_experts, t.head_dim
+    H = t.hidden_size
+    S = int(ctx) if ctx else 552
+    bufs = [stream.LayerBuffers(t) for _ in range(n_layers)]
+    layers = [bufs[l].load(t, l, 0) for l in range(n_layers)]
+    lm = hashw.fill((t.vocab_size, H), hashw.tensor_seed("lm_head.weight", 0))
+    norm = np.ones(H, np.float32)
+    x0 = hashw.fill((S, H), 12345)
+    tok = hashw.fill((1, H), 54321)
+    d, nq, nkv = t.head_dim, t.num_attention_heads, t.num_key_value_heads
 
-    def W(*shape):  # cheap uniform init (values do not matter for timing), distinct memory per tensor
-        return (rng.random(shape, dtype=np.float32) - 0.5) * np.float32(0.07)
-
-    sd = {"model.embed_tokens.weight": W(1024, H), "model.norm.weight": np.ones(H, np.float32),
-          "lm_head.weight": W(t.vocab_size, H)}
-    for l in range(n_layers):
-        p = f"model.layers.{l}."
-        sd[p + "input_layernorm.weight"] = np.ones(H, np.float32)
-        sd[p + "post_attention_layernorm.weight"] = np.ones(H, np.float32)
-        sd[p + "self_attn.q_proj.weight"] = W(t.num_attention_heads * hd, H)
-        sd[p + "self_attn.k_proj.weight"] = W(t.num_key_value_heads * hd, H)
-        sd[p + "self_attn.v_proj.weight"] = W(t.num_key_value_heads * hd, H)
-        sd[p + "self_attn.o_proj.weight"] = W(H, t.num_attention_heads * hd)
-        sd[p + "block_sparse_moe.gate.weight"] = W(E, H)
-        for e in range(E):
-            q = p + f"block_sparse_moe.experts.{e}."
-            sd[q + "w1.weight"], sd[q + "w2.weight"], sd[q + "w3.weight"] = W(I, H), W(H, I), W(I, H)
-    orc = om.MixtralOracle(sd, t)
-    del sd
-    x = W(ctx, H)
-    orc.forward(x)                                   # prefill the oracle's KV cache (untimed)
-    tok = W(1, H)
+    def forward(x, pos0, kc, vc):
+        n = x.shape[0]
+        cos, sin = om.rope_cos_sin(np.arange(pos0, pos0 + n), d, t.rope_theta)
+        for l, Lw in enumerate(layers):
+            xn = om.rmsnorm(x, Lw["ln1"], t.rms_norm_eps)
+            q = om.apply_rope((xn @ Lw["q"].T).reshape(n, nq, d).transpose(1, 0, 2), cos, sin)
+            k = om.apply_rope((xn @ Lw["k"].T).reshape(n, nkv, d).transpose(1, 0, 2), cos, sin)
+            v = (xn @ Lw["v"].T).reshape(n, nkv, d).transpose(1, 0, 2)
+            kc[l] = k if kc[l] is None else np.concatenate([kc[l], k], 1)
+            vc[l] = v if vc[l] is None else np.concatenate([vc[l], v], 1)
+            x = x + om.attention(q, kc[l], vc[l], pos0) @ Lw["o"].T
+            y, _, _ = om.moe(om.rmsnorm(x, Lw["ln2"], t.rms_norm_eps), Lw, t.num_experts_per_tok)
+            x = x + y
+        return x
 
     def timed():
+        kc, vc = [None] * n_layers, [None] * n_layers
+        t0 = time.perf_counter()
+        forward(x0, 0, kc, vc)                                  # prefill of the sample layers (fills the KV cache)
+        t_pre = time.perf_counter() - t0
         t_full, t_head = [], []
-        for _ in range(n_tok):
+        for i in range(n_tok):
+            kk, vv = [a.copy() for a in kc], [a.copy() for a in vc]   # every step at the same context
             t0 = time.perf_counter()
-            orc.forward(tok)
+            xo = forward(tok, S, kk, vv)
             t_full.append(time.perf_counter() - t0)
             t0 = time.perf_counter()
-            _ = (om.rmsnorm(tok, orc.norm, t.rms_norm_eps) @ orc.lm_head.T)
+            _ = om.rmsnorm(xo, norm, t.rms_norm_eps) @ lm.T
             t_head.append(time.perf_counter() - t0)
         full, head = float(np.median(t_full[1:])), float(np.median(t_head[1:]))
-        per_layer = max(full - head, 1e-9) / n_layers
-        return 1.0 / (per_layer * cfg.text.num_hidden_layers + head), per_layer, head
+        per_layer = full / n_layers
+        return 1.0 / (per_layer * L_full + head), per_layer, head, t_pre
 
     # batch-1 GEMVs are memory-bound: the BLAS pool's default (all cores) is not the fastest setting on a
     # many-core host, so a few thread counts are tried and the BEST one is the reported baseline
@@ -111,19 +121,39 @@ def cpu_baseline(cfg, n_layers=2, ctx=64, n_tok=6):
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
         all_thr = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-        for thr in sorted({all_thr, min(all_thr, 32), min(all_thr, 8), 1}, reverse=True):
+        for thr in sorted({all_thr, min(all_thr, 32), min(all_thr, 8)}, reverse=True):
             with threadpool_limits(limits=thr):
                 sweep[thr] = timed()
     except ImportError:
-        sweep[os.cpu_count() or 1] = timed()
+        all_thr = os.cpu_count() or 1
+        sweep[all_thr] = timed()
     threads = max(sweep, key=lambda k: sweep[k][0])
-    tok_s, per_layer, head = sweep[threads]
-    return {"value": round(tok_s, 4), "unit": "tokens/s", "cores": int(threads), "kind": "port",
-            "sample": f"numpy fp32 oracle: {n_layers} of {cfg.text.num_hidden_layers} real-geometry decoder layers + "
-                      f"LM head, {n_tok - 1} timed decode steps at ctx {ctx}, median, best of the BLAS thread counts tried, extrapolated x"
-                      f"{cfg.text.num_hidden_layers}/{n_layers} (the full fp32 model is 187 GB)",
-            "ms_per_layer_token": round(per_layer * 1e3, 3), "ms_lm_head": round(head * 1e3, 3),
-            "tokens_per_s_by_threads": {str(k): round(v[0], 4) for k, v in sweep.items()}}
+    tok_s, per_layer, head, _ = sweep[threads]
+    pre_thr = min(sweep, key=lambda k: sweep[k][3])
+    prefill_ms = (sweep[pre_thr][3] / n_layers * L_full + head) * 1e3
+    out = {"value": round(tok_s, 4), "unit": "tokens/s", "cores": int(threads), "kind": "port",
+           "sample": f"numpy fp32 oracle: {n_layers} of {L_full} real-geometry decoder layers + LM head, {n_tok - 1} timed greedy steps "
+                     f"at context {S} (the bench's prompt), median, best of the BLAS thread counts tried, extrapolated x{L_full}/{n_layers} "
+                     "(the full fp32 model is 187 GB)",
+           "ms_per_layer_token": round(per_layer * 1e3, 3), "ms_lm_head": round(head * 1e3, 3),
+           "tokens_per_s_by_threads": {str(k): round(v[0], 4) for k, v in sweep.items()},
+           "prefill_ms": round(prefill_ms, 1), "prefill_cores": int(pre_thr),
+           "prefill_sample": f"the same {n_layers} layers over the S={S} prompt rows, x{L_full}/{n_layers} + LM head (extrapolated)"}
+    if encoders and request is not None:
+        from oracle import encoders as oe
+        from vita_amd.checkpoint import synth_state_dict
+        sd = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
+        t0 = time.perf_counter()
+        vit = oe.internvit_tower(sd, cfg.vision, request["pixel_values"][:1])
+        oe.projector(sd, vit)
+        t_v = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oe.whale_encoder(sd, cfg.audio, request["fbank"])
+        t_a = time.perf_counter() - t0
+        out.update({"vit_projector_ms": round(t_v * 1e3, 1), "audio_encoder_ms": round(t_a * 1e3, 1), "encoder_cores": int(all_thr),
+                    "encoder_sample": "full-depth numpy fp64 restatements (24-layer InternViT + projector on one 448x448 tile; Whale "
+                                      "encoder + adapter on the 10 s clip), one pass each, BLAS default threads"})
+    return out
 
 
 def main():
@@ -344,7 +374,7 @@ def main():
             out["INVALID_debug_backend"] = f"{args.backend}, one_device={args.one_device}"
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed once, at N=1 (torchrun also pins OMP to 1 thread)
             try:
-                out["cpu_baseline"] = cpu_baseline(VitaConfig())
+                out["cpu_baseline"] = cpu_baseline(VitaConfig(), ctx=int(S), request=req)
             except Exception as e:  # never lose the GPU line to a host-side problem
                 out["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
         print(json.dumps(out), flush=True)

@@ -78,6 +78,7 @@ typedef struct {
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act, wide;
     int ksplit; long c_split_stride;
+    int* nslab_out;       /* ksplit < 0: the kernel picks the split (1 .. -ksplit) from the group sizes and stores it here (device int) */
 } vh_gemm_ps_args;
 int vh_gemm_ps(const vh_gemm_ps_args* args, void* stream);
 int vh_split_planes(const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows, int cols, void* stream);

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--nocheck", action="store_true", help="ablated builds: skip the parity assertion")
+    ap.add_argument("--skew", action="store_true", help="imbalanced routing: expert probabilities of a real layer "
+                                                        "(76 .. 307 of 1136 rows) instead of uniform")
     ap.add_argument("--H", type=int, default=4096)
     ap.add_argument("--I", type=int, default=14336)
     ap.add_argument("--E", type=int, default=8)
@@ -38,7 +40,12 @@ def main():
     layers = [dict(w1=W(E, I, H), w3=W(E, I, H), w2=W(E, H, I)) for _ in range(args.layers)]
     x = torch.randn((S, H), device=dev, generator=g, dtype=torch.float32)
     rng = np.random.default_rng(1)
-    ids = np.stack([rng.permutation(E)[:2] for _ in range(S)]).astype(np.int32)
+    if args.skew:
+        pr = np.asarray([107, 114, 89, 76, 82, 307, 140, 221], np.float64)[:E]
+        pr = pr / pr.sum()
+        ids = np.stack([rng.choice(E, size=2, replace=False, p=pr) for _ in range(S)]).astype(np.int32)
+    else:
+        ids = np.stack([rng.permutation(E)[:2] for _ in range(S)]).astype(np.int32)
     flat = ids.reshape(-1)
     order = np.argsort(flat, kind="stable")
     goff = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=E))]).astype(np.int32)).to(dev)
@@ -48,12 +55,16 @@ def main():
     rows = np.bincount(flat, minlength=E)
     print("rows per expert:", rows.tolist(), flush=True)
 
+    nslab = torch.zeros(1, dtype=torch.int32, device=dev)
+
     def run_ps(L, ksplit):
         hh, hl = ops.gemm_ps(xh, xl, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E,
                              w_group_stride=I * H, m=2 * S, out_split=True)
-        y = torch.empty((ksplit, 2 * S, H), dtype=torch.float32, device=dev)
+        y = torch.zeros((abs(ksplit), 2 * S, H), dtype=torch.float32, device=dev)
         ops.gemm_ps(hh, hl, L["w2"], group_off=goff, ngroups=E, w_group_stride=H * I, c_rowidx=sslot,
-                    out=y if ksplit > 1 else y[0], ksplit=ksplit)
+                    out=y if ksplit != 1 else y[0], ksplit=ksplit, nslab_out=nslab)
+        if ksplit < 0:
+            y = y[:int(nslab.item())]
         return hh, hl, y
 
     def run_general(L):
@@ -64,8 +75,9 @@ def main():
 
     # ---- correctness on a sample (fp64 torch reference) ------------------------------------------------
     L = layers[0]
-    hh, hl, y = run_ps(L, 2)
+    hh, hl, y = run_ps(L, -4)
     torch.cuda.synchronize()
+    print("device-chosen K split of the down projection:", int(nslab.item()), flush=True)
     h = hh.float() + hl.float()
     ysum = y.sum(0)
     err_h = err_y = 0.0
@@ -96,7 +108,7 @@ def main():
 
     def time_pair(ksplit):
         hh, hl, _ = run_ps(layers[0], ksplit)
-        y = torch.empty((ksplit, 2 * S, H), dtype=torch.float32, device=dev)
+        y = torch.empty((abs(ksplit), 2 * S, H), dtype=torch.float32, device=dev)
 
         def gu(L):
             ops.gemm_ps(xh, xl, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E,
@@ -104,7 +116,7 @@ def main():
 
         def dn(L):
             ops.gemm_ps(hh, hl, L["w2"], group_off=goff, ngroups=E, w_group_stride=H * I, c_rowidx=sslot,
-                        out=y if ksplit > 1 else y[0], ksplit=ksplit)
+                        out=y if ksplit != 1 else y[0], ksplit=ksplit, nslab_out=nslab)
 
         return timed(gu, args.iters), timed(dn, args.iters)
 
@@ -117,8 +129,10 @@ def main():
               f"down {dn[0]:8.1f} us (min {dn[1]:8.1f}) = {dn_bytes / dn[0] / 1e6:5.2f} TB/s", flush=True)
         out[tag] = {"gateup_us": gu[0], "gateup_min_us": gu[1], "down_us": dn[0], "down_min_us": dn[1]}
 
+    gu, dn = time_pair(-4)
+    report("stream ksplit=auto (default)", gu, dn)
     gu, dn = time_pair(2)
-    report("stream ksplit=2 (default)", gu, dn)
+    report("stream ksplit=2", gu, dn)
     if args.sweep:
         gu, dn = time_pair(1)
         report("stream ksplit=1", gu, dn)

@@ -9,8 +9,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def test_cpu_baseline_fields():
     import bench
     from vita_amd.config import VitaConfig
-    r = bench.cpu_baseline(VitaConfig.tiny(), n_layers=2, ctx=16, n_tok=3)
+    from vita_amd.host.synthetic import make_request
+    cfg = VitaConfig.tiny()
+    r = bench.cpu_baseline(cfg, n_layers=2, ctx=16, n_tok=3, request=make_request(cfg, seconds=1.0))
     assert r["kind"] == "port" and r["unit"] == "tokens/s" and r["value"] > 0
+    assert r["prefill_ms"] > 0 and r["vit_projector_ms"] > 0 and r["audio_encoder_ms"] > 0
     assert str(r["cores"]) in r["tokens_per_s_by_threads"]
     assert r["value"] == max(r["tokens_per_s_by_threads"].values())
 

@@ -35,7 +35,7 @@ class GemmPsArgs(C.Structure):
         ("C", c_void_p), ("ldc", c_long), ("C_hi", c_void_p), ("C_lo", c_void_p), ("ldc_split", c_long),
         ("c_rowidx", c_void_p), ("bias", c_void_p), ("scale", c_void_p), ("resid", c_void_p), ("ldr", c_long),
         ("M", c_int), ("N", c_int), ("K", c_int), ("act", c_int), ("wide", c_int),
-        ("ksplit", c_int), ("c_split_stride", c_long),
+        ("ksplit", c_int), ("c_split_stride", c_long), ("nslab_out", c_void_p),
     ]
 
 

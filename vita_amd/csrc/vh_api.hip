@@ -81,7 +81,7 @@ int vh_gemm_ps(const vh_gemm_ps_args* a, void* stream) {
     g.C = a->C; g.ldc = a->ldc; g.C_hi = a->C_hi; g.C_lo = a->C_lo; g.ldc_split = a->ldc_split;
     g.c_rowidx = a->c_rowidx; g.bias = a->bias; g.scale = a->scale; g.resid = a->resid; g.ldr = a->ldr;
     g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act;
-    g.ksplit = a->ksplit; g.c_split_stride = a->c_split_stride;
+    g.ksplit = a->ksplit; g.c_split_stride = a->c_split_stride; g.nslab_out = a->nslab_out;
     if ((size_t)a->lda * 2 * (size_t)(a->M > 0 ? a->M : 1) >= (1ull << 32))
         return fail(VH_E_SHAPE, "vh_gemm_ps: activation plane above the 32-bit offset range");
     return check_launch("vh_gemm_ps", vhk_gemm_ps(S(stream), g));
@@ -210,7 +210,7 @@ struct vh_mixtral {
     // prefill scratch
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
-    int *pids, *pgoff, *pstok, *psslot;
+    int *pids, *pgoff, *pstok, *psslot, *pnslab;
     int rccl_gen = 0;           // bumped by vh_mixtral_cancel_rccl: a pending vh_mixtral_init_rccl then discards its communicator
     int poisoned = 0;           // a decode step failed half-way: only prefill / reset may follow
     int* route_dbg = nullptr;   // optional: per-layer top-2 expert ids of the next prefill, [layer][token][2]
@@ -244,7 +244,8 @@ struct vh_mixtral {
         px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
         pqkv = cv.take<float>(Sm * nqkv);
         pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
-        ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(2 * 2 * Sm * H);   // py: up to 2 K-split slabs
+        ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(4 * 2 * Sm * H);   // py: up to 4 K-split slabs
+        pnslab = cv.take<int>(4);
         pxn_hi = cv.take<uint16_t>(Sm * H); pxn_lo = cv.take<uint16_t>(Sm * H);
         ph_hi = cv.take<uint16_t>(2 * Sm * I); ph_lo = cv.take<uint16_t>(2 * Sm * I);
         ptmp = cv.take<float>(Sm * H);
@@ -538,6 +539,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
         const bool stream_moe = vh_tuning()->prefill_moe_gemm == 0;
         bool moe_done = false;
         int nslab = 1;
+        const int* nslab_dev = nullptr;
         const long slab = (long)2 * m->c.max_prefill * H;
         if (stream_moe) {
             // weight-streaming path: the norm kernel emits the bf16 hi/lo planes directly, one tall m-tile per
@@ -552,29 +554,32 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
             g.group_off = m->pgoff; g.ngroups = E;
             g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * Sn; g.N = I; g.K = H; g.ksplit = 1;
             VH_TRY(vhk_gemm_ps(st, g), "gate/up gemm");
-            nslab = vh_tuning()->moe_ksplit;
-            if (nslab < 1) nslab = 1;
-            if (nslab > 2) nslab = 2;
+            nslab = vh_tuning()->moe_ksplit;           // < 0: chosen by the kernel from the expert sizes (up to -n)
+            if (nslab == 0) nslab = 1;
+            if (nslab > 4) nslab = 4;
+            if (nslab < -4) nslab = -4;
             if (nslab > (I >> 6)) nslab = 1;
+            nslab_dev = nslab < 0 ? m->pnslab : nullptr;
             VhGemmPsArgs d{};
             d.A_hi = m->ph_hi; d.A_lo = m->ph_lo; d.lda = I;
             d.W = w.w2; d.ldw = I; d.w_group_stride = (long)H * I;
             d.group_off = m->pgoff; d.ngroups = E;
             d.C = m->py; d.ldc = H; d.c_rowidx = m->psslot; d.M = 2 * Sn; d.N = H; d.K = I;
-            d.ksplit = nslab; d.c_split_stride = slab;
+            d.ksplit = nslab; d.c_split_stride = slab; d.nslab_out = m->pnslab;
+            if (nslab < 0) nslab = 1;                   // (the reducer reads the device value)
             if (tp && overlap) {
                 // "all-reduce over xGMI overlapped with the expert GEMMs" (FusedMoE reduce_results, vllm_file/
                 // mixtral.py:405-414): the down projection runs as two COLUMN halves (disjoint weight rows); half
                 // 0 is combined and all-reduced on the comm stream while half 1 streams its weights
                 const long hslab = (long)2 * m->c.max_prefill * H2;            // one K-split slab of a half
                 for (int h = 0; h < 2; ++h) {
-                    float* yh = m->py + (size_t)h * 2 * hslab;
+                    float* yh = m->py + (size_t)h * 4 * hslab;
                     float* part = m->ptmp + (size_t)h * Sn * H2;
                     d.W = w.w2 + (size_t)h * H2 * I; d.N = H2; d.C = yh; d.ldc = H2; d.c_split_stride = hslab;
                     VH_TRY(vhk_gemm_ps(st, d), "down gemm");
                     if (hipMemsetAsync(part, 0, (size_t)Sn * H2 * sizeof(float), st) != hipSuccess)
                         return fail(VH_E_HIP, "memset failed");
-                    VH_TRY(vhk_moe_combine(st, part, yh, m->pwts, Sn, H2, nslab, hslab), "combine");
+                    VH_TRY(vhk_moe_combine(st, part, yh, m->pwts, Sn, H2, nslab, hslab, nslab_dev), "combine");
                     hipEventRecord(m->ev_c[h], st);
                     hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
                     if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
@@ -612,11 +617,11 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
         } else if (tp) {
             if (hipMemsetAsync(m->ptmp, 0, (size_t)Sn * H * sizeof(float), st) != hipSuccess)
                 return fail(VH_E_HIP, "memset failed");
-            VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H, nslab, slab), "combine");
+            VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H, nslab, slab, nslab_dev), "combine");
             if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
             VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
         } else {
-            VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H, nslab, slab), "combine");
+            VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H, nslab, slab, nslab_dev), "combine");
         }
         if (m->route_dbg)
             hipMemcpyAsync(m->route_dbg + (size_t)l * 2 * Sn, m->pids, (size_t)2 * Sn * sizeof(int),

@@ -342,7 +342,8 @@ __global__ void k_moe_sort(const int* __restrict__ ids, int S, int E, int* __res
 // x[s,:] += w0 * sum_ks y[ks][2s,:] + w1 * sum_ks y[ks][2s+1,:]   (MixtralExperts index_add_,
 // modeling_mixtral.py:85-93; ks = the K-split slabs of the down projection, added in a fixed order)
 __global__ void k_moe_combine(float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ wts,
-                              int S, int H, int nslab, long slab_stride) {
+                              int S, int H, int nslab, long slab_stride, const int* __restrict__ nslab_dev) {
+    if (nslab_dev) nslab = *nslab_dev;                  // the down projection chose its K split on the device
     const long total = (long)S * (H / 4);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long s = i / (H / 4);
@@ -482,11 +483,11 @@ int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, i
     return 0;
 }
 int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H, int nslab,
-                    long slab_stride) {
+                    long slab_stride, const int* nslab_dev) {
     if (H % 4 != 0 || nslab < 1 || (slab_stride % 4) != 0) return -1;
     if (S == 0) return 0;
     hipLaunchKernelGGL(k_moe_combine, dim3(grid_for((long)S * (H / 4), 256)), dim3(256), 0, st, x, y, wts, S, H, nslab,
-                       slab_stride);
+                       slab_stride, nslab_dev);
     return 0;
 }
 int vhk_fill_hash_bf16(hipStream_t st, uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0,

@@ -444,15 +444,41 @@ void k_gemm_ps(const VhGemmPsArgs p) {
 
     const int E = p.group_off ? p.ngroups : 1;
     const int NT = (p.N + NOUT - 1) / NOUT;
-    const int KS = p.ksplit > 1 ? p.ksplit : 1;
     const int nk_total = p.K >> 6;
     auto rows_of = [&](int e) { return p.group_off ? (p.group_off[e + 1] - p.group_off[e]) : p.M; };
     auto mtiles_of = [&](int rows) { return (((rows + 15) >> 4) + RTMAX - 1) / RTMAX; };
 
-    int T = 0;
-    for (int e = 0; e < E; ++e) T += mtiles_of(rows_of(e)) * NT * KS;
-    // XCD x serves the contiguous run [T x / 8, T (x+1) / 8) of the expert-major tile list
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    // ---- tile list and its partition ---------------------------------------------------------------------
+    int ord[8], n_exp = 0;
+    for (int e = 0; e < E && e < 8; ++e) ord[n_exp++] = e;
+    for (int i = 1; i < n_exp; ++i)                                   // insertion sort by rows, descending (<= 8 entries)
+        for (int k = i; k > 0 && rows_of(ord[k]) > rows_of(ord[k - 1]); --k) { const int tmp = ord[k]; ord[k] = ord[k - 1]; ord[k - 1] = tmp; }
+    int MT = 0;                                                       // m-tiles over all experts
+    for (int i = 0; i < n_exp; ++i) MT += mtiles_of(rows_of(ord[i]));
+    const int nb = gridDim.x >> 3;
+    // K split chosen HERE when the caller allows it (p.ksplit < 0: up to -p.ksplit): with ~1 tile per CU the
+    // makespan is set by the rounding of tiles / CUs — 256 tiles at 8 balanced experts, 320 when two experts need
+    // two m-tiles (1.25 rounds at ks = 2, but 1.875 rounds of 2/3-size tiles at ks = 3) — so every block evaluates
+    // rounds(ks) / ks + a per-tile overhead and takes the minimum; the count goes to *nslab_out for the reducer.
+    int KS = p.ksplit > 1 ? p.ksplit : 1;
+    if (p.ksplit < 0) {
+        int best = 1 << 30;
+        for (int ks = 1; ks <= -p.ksplit && ks <= nk_total; ++ks) {
+            const int Tx = (MT * NT * ks + 7) >> 3;                   // tiles of the fullest XCD
+            const int Rr = Tx / nb, rr = Tx - Rr * nb;
+            const int rounds16 = 16 * Rr + (rr == 0 ? 0 : (2 * rr <= nb ? 9 : 16));   // M-split last round ~ 0.55
+            const int est = (rounds16 * 64) / ks + 4 * rounds16;      // + ~6 % of a full tile per round (prologue, epilogue)
+            if (est < best) { best = est; KS = ks; }
+        }
+        if (p.nslab_out && blockIdx.x == 0 && threadIdx.x == 0) *p.nslab_out = KS;
+    }
+    const int T = MT * NT * KS;
+    // XCD x serves the contiguous run [T x / 8, T (x+1) / 8) of the tile list: experts by DECREASING row count (real
+    // routers are far from uniform: 76 .. 307 rows per expert at S = 568 on the synthetic model), tiles expert-major:
+    // an XCD streams 1-3 experts whose activation planes stay in its L2, and block j takes tiles j, j + nb, ... of the
+    // run — the cheapest tiles in its last round.  (Runs of equal COST instead of equal count were tried: with ~1 tile
+    // per CU an uneven count costs a whole extra round: down projection 264 -> 426 us.)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int g0 = (int)(((long)T * xcd) >> 3), g1 = (int)(((long)T * (xcd + 1)) >> 3);
 
     // Block j of the XCD takes tiles g0 + j, g0 + j + nb, ...  A run is seldom a multiple of nb (896 gate|up tiles
@@ -468,16 +494,17 @@ void k_gemm_ps(const VhGemmPsArgs p) {
         else if (r == 0) break;
         else if (split_tail) { if (j >= 2 * r) break; g = g0 + R * nb + (j >> 1); half = j & 1; }
         else { if (j >= r) break; g = g0 + R * nb + j; }
-        // ---- decode tile g: expert e, then (ks, n-tile, m-tile) with the m-tile fastest --------------------
-        int e = 0, li = g, rows = 0, mt = 0;
-        for (; e < E; ++e) {
+        // ---- decode tile g: expert (in sorted order), then (ks, n-tile, m-tile) with the m-tile fastest ----------
+        int e = 0, li = g, rows = 0, mt = 0, oi = 0;
+        for (; oi < n_exp; ++oi) {
+            e = ord[oi];
             rows = rows_of(e);
             mt = mtiles_of(rows);
             const int cnt = mt * NT * KS;
             if (li < cnt) break;
             li -= cnt;
         }
-        if (e == E) break;
+        if (oi == n_exp) break;
         const int mi = li % mt;
         li /= mt;
         const int nt = li % NT, ks = li / NT;
@@ -564,9 +591,12 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     VhGemmPsArgs a = a0;
     if (a.K <= 0 || a.K % 64 != 0 || a.M < 0 || a.N <= 0 || (a.lda % 8) != 0 || (a.ldw % 8) != 0) return -1;
     if (!a.A_hi || !a.A_lo || !a.W || (!a.C && !a.C_hi) || (a.C_hi && !a.C_lo)) return -1;
-    if (a.ksplit < 1) a.ksplit = 1;
-    if (a.ksplit > 1 && (a.W_up || a.bias || a.scale || a.resid || a.act != VH_ACT_NONE || a.C_hi || !a.C)) return -1;
+    if (a.ksplit == 0) a.ksplit = 1;
+    if (a.ksplit < -8) return -1;                    // ksplit < 0: the kernel picks 1 .. -ksplit and reports it in *nslab_out
+    if ((a.ksplit > 1 || a.ksplit < 0) && (a.W_up || a.bias || a.scale || a.resid || a.act != VH_ACT_NONE || a.C_hi || !a.C)) return -1;
+    if (a.ksplit < 0 && !a.nslab_out) return -1;
     if (a.ksplit > (a.K >> 6)) return -1;
+    if (a.group_off && a.ngroups > 8) return -1;     // the scheduler sorts at most 8 groups
     // 32-bit per-lane byte offsets inside one operand
     if ((size_t)a.ldw * (size_t)a.N * 2 >= (1ull << 32)) return -1;
     if (a.M == 0) return 0;
@@ -583,7 +613,7 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     bool nt = vh_tuning()->ps_nt > 0;
     if (vh_tuning()->ps_nt < 0) {
         const int NOUT = a.W_up ? 128 : 256;
-        const long T = (long)groups * ((avg + (cfg == 0 ? 63 : 191)) / (cfg == 0 ? 64 : 192)) * ((a.N + NOUT - 1) / NOUT) * a.ksplit;
+        const long T = (long)groups * ((avg + (cfg == 0 ? 63 : 191)) / (cfg == 0 ? 64 : 192)) * ((a.N + NOUT - 1) / NOUT) * (a.ksplit > 0 ? a.ksplit : 2);
         const long nb = grid / 8, Tx = (T + 7) / 8, r = Tx % nb;
         nt = !(r > 0 && 2 * r <= nb);
     }

@@ -18,7 +18,7 @@ struct VhTuning {
     int ps_grid = 0;          // vh_gemm_ps persistent grid (0 = one block per CU)
     int ps_nt = -1;           // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
     int tp_overlap = 1;       // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
-    int moe_ksplit = 2;       // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel)
+    int moe_ksplit = -4;      // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
 };
 VhTuning* vh_tuning();
@@ -75,7 +75,9 @@ struct VhGemmPsArgs {
     const int* c_rowidx;
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
-    int ksplit; long c_split_stride;                         // K split: partial sums go to C + ks * c_split_stride (plain fp32 output only)
+    int ksplit; long c_split_stride;                         // K split: partial sums go to C + ks * c_split_stride (plain fp32 output only);
+                                                             // ksplit < 0: the kernel picks 1 .. -ksplit from the group sizes
+    int* nslab_out;                                          // device int: the split the kernel used (required when ksplit < 0)
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
 int vhk_split_planes(hipStream_t st, const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows,
@@ -118,7 +120,7 @@ int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, 
                       int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts);
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot);
 int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H, int nslab,
-                    long slab_stride);
+                    long slab_stride, const int* nslab_dev);
 int vhk_cast_bf16_f32(hipStream_t st, const uint16_t* in, float* out, long n);
 int vhk_fill_hash_bf16(hipStream_t st, uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0,
                        uint64_t seed);

@@ -188,7 +188,8 @@ def split_planes(x):
 
 
 def gemm_ps(a_hi, a_lo, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=None, out_split=False,
-            a_rowidx=None, m=None, c_rowidx=None, group_off=None, ngroups=0, w_group_stride=0, wide=False, ksplit=1):
+            a_rowidx=None, m=None, c_rowidx=None, group_off=None, ngroups=0, w_group_stride=0, wide=False, ksplit=1,
+            nslab_out=None):
     """Weight-streaming GEMM on pre-split activations (vh_gemm_ps).  Returns fp32 out, or (hi, lo) planes when
     out_split=True.  ksplit > 1: `out` must be [ksplit, rows, N] (partial sums per K range; the caller adds them)."""
     _dev(a_hi, a_lo, w)
@@ -210,13 +211,14 @@ def gemm_ps(a_hi, a_lo, w, *, w_up=None, bias=None, act=None, scale=None, resid=
     else:
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=w.device)
-        if ksplit > 1:
-            if out.ndim != 3 or out.shape[0] != ksplit:
-                raise ValueError("ksplit > 1 needs out of shape [ksplit, rows, N]")
+        if ksplit > 1 or ksplit < 0:
+            if out.ndim != 3 or out.shape[0] != abs(ksplit):
+                raise ValueError("ksplit > 1 needs out of shape [ksplit, rows, N] (ksplit < 0: [-ksplit, rows, N])")
             g.C, g.ldc, g.c_split_stride = out.data_ptr(), int(out.stride(1)), int(out.stride(0))
         else:
             g.C, g.ldc = out.data_ptr(), int(out.stride(0))
     g.ksplit = int(ksplit)
+    g.nslab_out = nslab_out.data_ptr() if nslab_out is not None else None
     g.c_rowidx = c_rowidx.data_ptr() if c_rowidx is not None else None
     g.bias = bias.data_ptr() if bias is not None else None
     g.scale = scale.data_ptr() if scale is not None else None
