@@ -182,6 +182,8 @@ def main():
                     help="debug: number of 448x448 tiles / video frames in the prompt (default 1 = configs[2]; 4-16 is the "
                          "video shape of configs[4])")
     ap.add_argument("--text-tokens", type=int, default=32, help="debug: length of the user text (default 32 = configs[2])")
+    ap.add_argument("--batch", default="", help="also measure B concurrent sequences over the paged KV cache, e.g. 2,4 "
+                    "(SURVEY 8(f)#1; reported under \"concurrent\", the headline value stays batch 1)")
     ap.add_argument("--tune", default="", help="debug: kernel-variant knobs key=val[,key=val] (vh_tune)")
     args = ap.parse_args()
 
@@ -243,8 +245,13 @@ def main():
     t0 = time.time()
     packed = synth_mixtral_device(cfg, dev, seed=0, rank=rank, world=args.emulate_tp or world)
     sd_enc = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
+    batches = [int(b) for b in args.batch.split(",") if b.strip()]
+    max_prefill = max(1024, args.text_tokens + 768 + 256 * args.frames)
+    seq_kw = {}
+    if batches:   # a pool of 64-token KV pages holding max(B) sequences of prompt + generated tokens
+        seq_kw = dict(max_seqs=max(batches), kv_pool_tokens=max(batches) * (-(-(max_prefill + K + Wm + 72) // 64) * 64))
     model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=K + Wm + 8,
-                                   max_prefill=max(1024, args.text_tokens + 768 + 256 * args.frames), rank=rank, world=world, keep_scores=False)
+                                   max_prefill=max_prefill, rank=rank, world=world, keep_scores=False, **seq_kw)
     model.get_vision_tower().load_model()
     eng = model.engine
     collective = "none"
@@ -313,6 +320,38 @@ def main():
 
     ms_step = dt * 1e3 / K
     tok_s = K / dt
+
+    # ---- concurrent sequences (continuous-batching iterations over the paged KV cache) ----------------------------
+    concurrent = []
+    for B in batches:
+        eng.lib.vh_mixtral_reset(eng.h, None)
+        torch.cuda.synchronize()
+        seqs = []
+        for i in range(B):
+            ids_i = [x if x < 0 else 3 + (x + 17 * i) % (t.vocab_size - 3) for x in ids]      # B different prompts
+            _, _, _, _, emb_i, _ = model.prepare_inputs_labels_for_multimodal(
+                torch.tensor([ids_i], dtype=torch.long, device=dev), None, None, None, None, image, audios)
+            sq = eng.seq_alloc()
+            eng.seq_prefill(sq, emb_i[0])
+            seqs.append(sq)
+        for _ in range(Wm):
+            eng.seq_decode(seqs)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(K):
+            eng.seq_decode(seqs)
+        barrier()
+        dtb = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([dtb], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+        for sq in seqs:
+            c = eng.check_device_flag(eng.seq_counters(sq).tolist())
+            assert c[1] == 1 + Wm + K
+            eng.seq_free(sq)
+        concurrent.append({"batch": B, "aggregate_tokens_per_s": round(B * K / dtb, 2),
+                           "ms_per_iteration": round(dtb * 1e3 / K, 4), "vs_batch1": round(B * K / dtb / tok_s, 3)})
     lay0 = packed["layers"][0]
     I_r = lay0["w1"].shape[1]
     gateup_bytes = 2 * 2 * I_r * t.hidden_size * 2 + t.num_local_experts * t.hidden_size * 2   # per launch, this rank
@@ -360,6 +399,8 @@ def main():
                          "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None},
             "build_s": round(t_build, 1),
         }
+        if concurrent:
+            out["concurrent"] = concurrent
         if args.layers:
             out["INVALID_debug_layers"] = args.layers
         if args.tune:

@@ -28,6 +28,7 @@ extern "C" {
 #define VH_E_ARG (-2)
 #define VH_E_HIP (-3)
 #define VH_E_COMM (-4)
+#define VH_E_FULL (-5)   /* a pool is exhausted (sequence slots, KV pages): retry after freeing */
 
 #define VH_ACT_NONE 0
 #define VH_ACT_GELU 1 /* erf GELU (nn.GELU default) */
@@ -142,6 +143,8 @@ typedef struct {
     int vocab_lo, vocab_n;/* vocab-sharded LM head (ParallelLMHead, vllm_file/mixtral.py:939-951): `lm_head` holds rows
                              [vocab_lo, vocab_lo + vocab_n) of the table; the ranks exchange (max, index) candidates
                              through the all-reduce hook.  vocab_n == 0: the whole table on every rank. */
+    int max_seqs;         /* > 0: slots for concurrent sequences over the paged KV cache (vh_mixtral_seq_*); max_ctx is then
+                             the POOL size in tokens (a multiple of 64) shared by all sequences */
 } vh_mixtral_cfg;
 
 typedef struct {
@@ -208,6 +211,27 @@ const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: genera
 const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[4]: {pos, n_generated, attn hand-off counter, device error flag (0 = ok)} */
 const float* vh_mixtral_logits(const vh_mixtral_t* m);   /* fp32[max(1,logit_rows)][vocab]; row i = scores that produced token i */
 int vh_mixtral_reset(vh_mixtral_t* m, void* stream);     /* n_generated = 0, pos = 0      */
+/* ---- concurrent sequences over a paged KV cache: what the reference's serving plugin receives from vLLM as
+ * `kv_caches` + `attn_metadata` block tables (web_demo/vllm_tools/vllm_file/mixtral.py:491-501,1130-1186; the engine
+ * that schedules them: web_interactive_demo.py:942-996).  The KV pool is cut into 64-token pages; a sequence is a slot
+ * with its own page table (grown on demand), residual state, counters and generated ids.  A sequence's arithmetic is
+ * exactly the single-sequence path's (same kernels, physical rows looked up through the table), so its ids and scores
+ * do not depend on what else is scheduled.  Not to be mixed with vh_mixtral_prefill/decode while sequences are live.
+ *   seq_alloc   -> slot id >= 0, or VH_E_FULL
+ *   seq_prefill    appends S embedded tokens at the sequence's current position and leaves its next greedy token in
+ *                  seq_tokens[0] (n_generated restarts at 0, as vh_mixtral_prefill); VH_E_FULL when pages run out
+ *   seq_decode     one greedy step for each listed sequence, in order, on `stream` (a continuous-batching iteration)
+ *   seq_free       returns the pages;  vh_mixtral_reset frees every sequence */
+int vh_mixtral_seq_alloc(vh_mixtral_t* m);
+int vh_mixtral_seq_free(vh_mixtral_t* m, int seq);
+int vh_mixtral_seq_prefill(vh_mixtral_t* m, int seq, const float* embeds, int S, float* logits_out, void* stream);
+int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* seqs /* host */, int n, void* stream);
+int vh_mixtral_pages_free(const vh_mixtral_t* m);
+int vh_mixtral_seq_pos(const vh_mixtral_t* m, int seq);                  /* tokens in the sequence's KV cache, -1 = not live */
+const int* vh_mixtral_seq_tokens(const vh_mixtral_t* m, int seq);        /* device int[max_new]  */
+const int* vh_mixtral_seq_counters(const vh_mixtral_t* m, int seq);      /* device int[4], as vh_mixtral_counters */
+int vh_mixtral_seq_table(const vh_mixtral_t* m, int seq, int* pages_out /* host */, int cap);   /* -> number of pages */
+
 /* Live HIP-event timing of the dominant decode kernel (gate|up expert GEMV): sample one launch
  * every `stride` layers (0 = off), up to max_samples; read returns summed ms and sample count. */
 int vh_mixtral_profile(vh_mixtral_t* m, int stride, int max_samples);

@@ -60,7 +60,7 @@ class MixtralCfg(C.Structure):
         ("head_dim", c_int), ("inter", c_int), ("n_experts", c_int), ("top_k", c_int), ("vocab", c_int),
         ("rms_eps", c_float), ("max_ctx", c_int), ("max_prefill", c_int), ("max_new", c_int),
         ("tp_rank", c_int), ("tp_world", c_int), ("nsplit", c_int), ("logit_rows", c_int),
-        ("vocab_lo", c_int), ("vocab_n", c_int),
+        ("vocab_lo", c_int), ("vocab_n", c_int), ("max_seqs", c_int),
     ]
 
 
@@ -117,6 +117,15 @@ SIGNATURES = {
     "vh_mixtral_counters": (c_void_p, [c_void_p]),
     "vh_mixtral_logits": (c_void_p, [c_void_p]),
     "vh_mixtral_reset": (c_int, [c_void_p, c_void_p]),
+    "vh_mixtral_seq_alloc": (c_int, [c_void_p]),
+    "vh_mixtral_seq_free": (c_int, [c_void_p, c_int]),
+    "vh_mixtral_seq_prefill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vh_mixtral_seq_decode": (c_int, [c_void_p, C.POINTER(c_int), c_int, c_void_p]),
+    "vh_mixtral_pages_free": (c_int, [c_void_p]),
+    "vh_mixtral_seq_pos": (c_int, [c_void_p, c_int]),
+    "vh_mixtral_seq_tokens": (c_void_p, [c_void_p, c_int]),
+    "vh_mixtral_seq_counters": (c_void_p, [c_void_p, c_int]),
+    "vh_mixtral_seq_table": (c_int, [c_void_p, c_int, C.POINTER(c_int), c_int]),
     "vh_mixtral_profile": (c_int, [c_void_p, c_int, c_int]),
     "vh_mixtral_profile_read": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
 }

@@ -59,7 +59,7 @@ int vh_tune(const char* key, int value) {
 
 int vh_gemm(const vh_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->W || !a->C) return fail(VH_E_ARG, "vh_gemm: null pointer");
-    VhGemmArgs g;
+    VhGemmArgs g{};
     g.A = a->A; g.lda = a->lda; g.a_rows = a->a_rows; g.a_rowidx = a->a_rowidx;
     g.nseg = a->nseg; g.seglen = a->seglen;
     for (int i = 0; i < 16; ++i) g.segrow[i] = a->segrow[i];
@@ -74,7 +74,7 @@ int vh_gemm(const vh_gemm_args* a, void* stream) {
 
 int vh_gemm_ps(const vh_gemm_ps_args* a, void* stream) {
     if (!a || !a->A_hi || !a->A_lo || !a->W) return fail(VH_E_ARG, "vh_gemm_ps: null pointer");
-    VhGemmPsArgs g;
+    VhGemmPsArgs g{};
     g.A_hi = a->A_hi; g.A_lo = a->A_lo; g.lda = a->lda; g.a_rowidx = a->a_rowidx;
     g.W = a->W; g.W_up = a->W_up; g.ldw = a->ldw; g.w_group_stride = a->w_group_stride;
     g.group_off = a->group_off; g.ngroups = a->ngroups;
@@ -93,7 +93,7 @@ int vh_split_planes(const float* x, long ldx, uint16_t* hi, uint16_t* lo, long l
 
 int vh_attention(const vh_attn_args* a, void* stream) {
     if (!a || !a->Q || !a->K || !a->V || !a->O) return fail(VH_E_ARG, "vh_attention: null pointer");
-    VhAttnArgs g;
+    VhAttnArgs g{};
     g.Q = a->Q; g.ldq = a->ldq; g.hsq = a->hsq; g.K = a->K; g.ldk = a->ldk; g.hsk = a->hsk;
     g.V = a->V; g.ldv = a->ldv; g.hsv = a->hsv; g.P = a->P; g.ldp = a->ldp; g.hsp = a->hsp;
     g.bias_u = a->bias_u; g.bias_v = a->bias_v; g.O = a->O; g.ldo = a->ldo;
@@ -211,6 +211,66 @@ struct vh_mixtral {
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
     int *pids, *pgoff, *pstok, *psslot, *pnslab;
+    // ---- concurrent sequences over a paged KV cache (vLLM's block tables).  The KV pool above is cut into
+    // 64-token pages (= one decode-attention tile); a sequence owns a page table, a residual-stream state, its counters
+    // and its generated ids.  The kernels see ONE sequence at a time: bind() points the engine's "current sequence"
+    // members (xa .. out_tokens, table, host mirrors) at a sequence's slots, unbind() restores the default single-sequence
+    // state, so prefill and decode are the same code for both.
+    struct Seq {
+        bool live = false;
+        int host_pos = 0, attn_epoch = 0, poisoned = 0, npages = 0;
+        std::vector<int> pages;        // host mirror of the device table (sized once: uploads read from it)
+    };
+    std::vector<Seq> seqs;
+    std::vector<int> free_pages;
+    float* seq_x = nullptr;            // [max_seqs][4][H]: xa, xb, delta_attn, delta_moe
+    int *seq_counters = nullptr, *seq_tokens = nullptr, *seq_table = nullptr;
+    const int* table = nullptr;        // device page table of the bound sequence; null = contiguous rows (default state)
+    int bound = -1;
+    struct { float *xa, *xb, *da, *dm; int *counters, *out_tokens; int host_pos, attn_epoch, poisoned; } dflt{};
+    int n_pages() const { return c.max_ctx / 64; }
+    int live_seqs() const { int n = 0; for (const Seq& q : seqs) n += q.live; return n; }
+    void bind(int s) {
+        dflt = {xa, xb, delta_attn, delta_moe, counters, out_tokens, host_pos, attn_epoch, poisoned};
+        float* x = seq_x + (size_t)s * 4 * H;
+        xa = x; xb = x + H; delta_attn = x + 2 * H; delta_moe = x + 3 * H;
+        counters = seq_counters + 4 * s;
+        out_tokens = seq_tokens + (size_t)s * (c.max_new > 0 ? c.max_new : 1);
+        table = seq_table + (size_t)s * max_splits;
+        host_pos = seqs[s].host_pos; attn_epoch = seqs[s].attn_epoch; poisoned = seqs[s].poisoned;
+        bound = s;
+    }
+    void unbind() {
+        Seq& q = seqs[bound];
+        q.host_pos = host_pos; q.attn_epoch = attn_epoch; q.poisoned = poisoned;
+        xa = dflt.xa; xb = dflt.xb; delta_attn = dflt.da; delta_moe = dflt.dm;
+        counters = dflt.counters; out_tokens = dflt.out_tokens;
+        host_pos = dflt.host_pos; attn_epoch = dflt.attn_epoch; poisoned = dflt.poisoned;
+        table = nullptr; bound = -1;
+    }
+    // pages covering positions [0, n_tokens) of sequence s; new table entries are uploaded on st.  -1: pool exhausted.
+    int ensure_pages(int s, int n_tokens, hipStream_t st) {
+        Seq& q = seqs[s];
+        const int need = (n_tokens + 63) / 64, had = q.npages;
+        if (need <= had) return 0;
+        if (need > max_splits || (int)free_pages.size() < need - had) return -1;
+        for (int j = had; j < need; ++j) { q.pages[j] = free_pages.back(); free_pages.pop_back(); }
+        q.npages = need;
+        if (hipMemcpyAsync(seq_table + (size_t)s * max_splits + had, q.pages.data() + had, (size_t)(need - had) * sizeof(int),
+                           hipMemcpyHostToDevice, st) != hipSuccess) return -2;
+        return 0;
+    }
+    void release(int s) {
+        Seq& q = seqs[s];
+        for (int j = q.npages - 1; j >= 0; --j) free_pages.push_back(q.pages[j]);
+        q.npages = 0; q.live = false; q.host_pos = 0; q.attn_epoch = 0; q.poisoned = 0;
+    }
+    void init_seqs() {
+        seqs.assign(c.max_seqs > 0 ? c.max_seqs : 0, Seq{});
+        for (Seq& q : seqs) q.pages.assign(max_splits, 0);
+        free_pages.clear();
+        for (int pg = n_pages() - 1; pg >= 0; --pg) free_pages.push_back(pg);   // page 0 is handed out first
+    }
     int rccl_gen = 0;           // bumped by vh_mixtral_cancel_rccl: a pending vh_mixtral_init_rccl then discards its communicator
     int poisoned = 0;           // a decode step failed half-way: only prefill / reset may follow
     int* route_dbg = nullptr;   // optional: per-layer top-2 expert ids of the next prefill, [layer][token][2]
@@ -252,6 +312,13 @@ struct vh_mixtral {
         pwts = cv.take<float>(2 * Sm);
         pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
         pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
+        if (c.max_seqs > 0) {
+            const size_t n = (size_t)c.max_seqs;
+            seq_x = cv.take<float>(n * 4 * H);
+            seq_counters = cv.take<int>(n * 4);
+            seq_tokens = cv.take<int>(n * (c.max_new > 0 ? c.max_new : 1));
+            seq_table = cv.take<int>(n * max_splits);
+        }
         return cv.off;
     }
     int hist_rows() const { return c.logit_rows > 1 ? c.logit_rows : 1; }
@@ -301,6 +368,8 @@ int cfg_ok(const vh_mixtral_cfg* c) {
     if (c->vocab_n < 0 || c->vocab_lo < 0 || (c->vocab_n > 0 && c->vocab_lo + c->vocab_n > c->vocab))
         return fail(VH_E_SHAPE, "vocab shard outside the table");
     if (c->vocab_n > 0 && c->vocab >= (1 << 24)) return fail(VH_E_SHAPE, "vocab-sharded head needs vocab < 2^24");
+    if (c->max_seqs < 0 || c->max_seqs > 4096) return fail(VH_E_SHAPE, "max_seqs outside [0,4096]");
+    if (c->max_seqs > 0 && (c->max_ctx % 64) != 0) return fail(VH_E_SHAPE, "paged KV cache: max_ctx must be a multiple of the 64-token page");
     return VH_OK;
 }
 int rccl_allreduce_cb(void* user, float* buf, long count, void* stream) {
@@ -342,6 +411,7 @@ vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_laye
         delete m;
         return nullptr;
     }
+    m->init_seqs();
     return m;
 }
 
@@ -441,6 +511,8 @@ int vh_mixtral_reset(vh_mixtral_t* m, void* stream) {
     if (hipMemsetAsync(m->counters, 0, 4 * sizeof(int), S(stream)) != hipSuccess)
         return fail(VH_E_HIP, "reset memset failed");
     m->host_pos = 0; m->attn_epoch = 0; m->poisoned = 0;
+    for (int s = 0; s < (int)m->seqs.size(); ++s)
+        if (m->seqs[s].live) m->release(s);      // the pool is one: a reset returns every page
     return VH_OK;
 }
 
@@ -457,12 +529,10 @@ static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, con
         if ((expr) != 0) return launch_failed(what);   \
     } while (0)
 
-int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, float* logits_out, float* hidden_dbg,
-                       void* stream) {
-    if (!m || !embeds) return fail(VH_E_ARG, "vh_mixtral_prefill: null pointer");
+static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, float* logits_out, float* hidden_dbg,
+                        hipStream_t st) {
     if (Sn < 1 || Sn > m->c.max_prefill) return fail(VH_E_SHAPE, "prefill length %d outside [1,%d]", Sn, m->c.max_prefill);
     if (pos0 < 0 || pos0 + Sn >= m->c.max_ctx) return fail(VH_E_SHAPE, "prefill exceeds KV capacity %d", m->c.max_ctx);
-    hipStream_t st = S(stream);
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const bool tp = m->c.tp_world > 1 || vh_tuning()->force_allreduce;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -496,7 +566,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
             VH_TRY(vhk_gemm(st, g), "qkv gemm");
         }
         VH_TRY(vhk_rope_kv(st, m->pqkv, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
-                           m->c.max_ctx), "rope");
+                           m->c.max_ctx, m->table), "rope");
         {
             VhAttnArgs a{};
             a.Q = m->pq; a.ldq = (long)nq * hd; a.hsq = hd;
@@ -505,6 +575,7 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
             a.O = m->pattn; a.ldo = (long)nq * hd;
             a.B = 1; a.Hq = nq; a.Hkv = nkv; a.Sq = Sn; a.Sk = pos0 + Sn; a.d = hd;
             a.causal = 1; a.q_off = pos0; a.klen = pos0 + Sn; a.chunk = 0; a.left = -1; a.scale = scale;
+            a.ktable = m->table;
             VH_TRY(vhk_attn(st, a), "attention");
         }
         {
@@ -644,6 +715,13 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
     return VH_OK;
 }
 
+int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, float* logits_out, float* hidden_dbg,
+                       void* stream) {
+    if (!m || !embeds) return fail(VH_E_ARG, "vh_mixtral_prefill: null pointer");
+    if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_prefill: sequences own pages of the KV pool (free them or reset)");
+    return prefill_impl(m, embeds, Sn, pos0, logits_out, hidden_dbg, S(stream));
+}
+
 // Final norm + LM head + greedy selection.  Vocab-sharded head: every rank scores its rows, the (max, index) candidates
 // travel through the all-reduce hook, every rank takes the same global argmax; when scores are kept (logit_rows > 1)
 // the full row is assembled by an all-reduce of the zero-filled slices.
@@ -681,14 +759,14 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
             fused = vhk_dec_attn_oproj(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o,
                                        m->part_ml, m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits,
                                        m->host_pos + 1, scale, m->counters + 2, (m->attn_epoch + *epoch_inc + 1) * nkv,
-                                       m->counters + 3, w.wo, H, nq * hd, m->delta_attn);
+                                       m->counters + 3, w.wo, H, nq * hd, m->delta_attn, m->table);
             if (fused < 0) return launch_failed("dec attn+oproj");
             if (fused == 0) *epoch_inc += 1;
         }
         if (fused != 0) {  // long contexts (grid not co-resident) or fusion disabled: two kernels
             VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
                                 m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
-                                scale), "dec attn");
+                                scale, m->table), "dec attn");
             VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
         }
         if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
@@ -713,6 +791,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     if (!m) return fail(VH_E_ARG, "null engine");
     hipStream_t st = S(stream);
     if (m->poisoned) return fail(VH_E_ARG, "decode: a previous step failed; prefill or reset first");
+    if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_decode: sequences own pages of the KV pool (use vh_mixtral_seq_decode)");
     for (int step = 0; step < n_steps; ++step) {
         if (m->host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx);
         int epoch_inc = 0;
@@ -725,6 +804,89 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
         }
         m->host_pos += 1;
         m->attn_epoch += epoch_inc;
+    }
+    return VH_OK;
+}
+
+// ---- concurrent sequences (paged KV cache) ---------------------------------------------------------------------------
+static int seq_ok(vh_mixtral* m, int s, const char* what) {
+    if (!m) return fail(VH_E_ARG, "%s: null engine", what);
+    if (s < 0 || s >= (int)m->seqs.size() || !m->seqs[s].live) return fail(VH_E_ARG, "%s: sequence %d is not allocated", what, s);
+    return VH_OK;
+}
+
+int vh_mixtral_seq_alloc(vh_mixtral_t* m) {
+    if (!m) return fail(VH_E_ARG, "null engine");
+    for (int s = 0; s < (int)m->seqs.size(); ++s)
+        if (!m->seqs[s].live) { m->seqs[s].live = true; return s; }
+    return fail(VH_E_FULL, "vh_mixtral_seq_alloc: all %d sequence slots are in use", (int)m->seqs.size());
+}
+
+int vh_mixtral_seq_free(vh_mixtral_t* m, int s) {
+    const int rc = seq_ok(m, s, "vh_mixtral_seq_free");
+    if (rc != VH_OK) return rc;
+    m->release(s);
+    return VH_OK;
+}
+
+int vh_mixtral_pages_free(const vh_mixtral_t* m) { return m ? (int)m->free_pages.size() : 0; }
+int vh_mixtral_seq_pos(const vh_mixtral_t* m, int s) {
+    return (m && s >= 0 && s < (int)m->seqs.size() && m->seqs[s].live) ? m->seqs[s].host_pos : -1;
+}
+const int* vh_mixtral_seq_tokens(const vh_mixtral_t* m, int s) {
+    return (m && s >= 0 && s < (int)m->seqs.size()) ? m->seq_tokens + (size_t)s * (m->c.max_new > 0 ? m->c.max_new : 1) : nullptr;
+}
+const int* vh_mixtral_seq_counters(const vh_mixtral_t* m, int s) {
+    return (m && s >= 0 && s < (int)m->seqs.size()) ? m->seq_counters + 4 * s : nullptr;
+}
+int vh_mixtral_seq_table(const vh_mixtral_t* m, int s, int* pages_out, int cap) {
+    if (!m || s < 0 || s >= (int)m->seqs.size() || !m->seqs[s].live) return -1;
+    const vh_mixtral::Seq& q = m->seqs[s];
+    for (int j = 0; j < q.npages && j < cap; ++j) pages_out[j] = q.pages[j];
+    return q.npages;
+}
+
+int vh_mixtral_seq_prefill(vh_mixtral_t* m, int s, const float* embeds, int Sn, float* logits_out, void* stream) {
+    const int rc0 = seq_ok(m, s, "vh_mixtral_seq_prefill");
+    if (rc0 != VH_OK) return rc0;
+    if (!embeds) return fail(VH_E_ARG, "vh_mixtral_seq_prefill: null pointer");
+    hipStream_t st = S(stream);
+    const int pos0 = m->seqs[s].host_pos;       // appends to the sequence (0 for a new one): chunked prompts, later turns
+    if (Sn < 1 || pos0 + Sn >= m->c.max_ctx) return fail(VH_E_SHAPE, "prefill of %d tokens at %d exceeds the pool", Sn, pos0);
+    const int pr = m->ensure_pages(s, pos0 + Sn, st);
+    if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted: %d pages free, sequence %d needs %d more", (int)m->free_pages.size(),
+                              s, (pos0 + Sn + 63) / 64 - m->seqs[s].npages);
+    if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
+    m->bind(s);
+    const int rc = prefill_impl(m, embeds, Sn, pos0, logits_out, nullptr, st);
+    if (rc != VH_OK) m->poisoned = 1;
+    m->unbind();
+    return rc;
+}
+
+int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) {
+    if (!m || (!ids && n > 0)) return fail(VH_E_ARG, "vh_mixtral_seq_decode: null pointer");
+    hipStream_t st = S(stream);
+    for (int i = 0; i < n; ++i) {               // validate the whole batch before anything is enqueued
+        const int rc = seq_ok(m, ids[i], "vh_mixtral_seq_decode");
+        if (rc != VH_OK) return rc;
+        const vh_mixtral::Seq& q = m->seqs[ids[i]];
+        if (q.poisoned) return fail(VH_E_ARG, "sequence %d: a previous step failed; free it", ids[i]);
+        if (q.host_pos < 1) return fail(VH_E_ARG, "sequence %d has no prompt yet", ids[i]);
+        if (q.host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "sequence %d: context limit %d", ids[i], m->c.max_ctx);
+    }
+    for (int i = 0; i < n; ++i) {
+        const int s = ids[i];
+        const int pr = m->ensure_pages(s, m->seqs[s].host_pos + 1, st);   // the step writes K/V of position host_pos
+        if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", s, i);
+        if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
+        m->bind(s);
+        int epoch_inc = 0;
+        const int rc = decode_one_step(m, st, &epoch_inc);
+        if (rc != VH_OK) m->poisoned = 1;
+        else { m->host_pos += 1; m->attn_epoch += epoch_inc; }
+        m->unbind();
+        if (rc != VH_OK) return rc;
     }
     return VH_OK;
 }

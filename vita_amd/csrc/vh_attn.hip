@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
         for (int i = 0; i < F4; ++i) {
             const int idx = tid + i * 256;
             const int row = idx / (D / 4), c4 = idx % (D / 4);
-            const int key = min(kt0 + row, p.Sk - 1);
+            int key = min(kt0 + row, p.Sk - 1);
+            if (p.ktable) key = p.ktable[key >> 6] * 64 + (key & 63);       // paged KV cache (Mixtral prefill of a sequence)
             kr[i] = reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk)[c4];
             vr[i] = reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv)[c4];
             if (REL) pr[i] = reinterpret_cast<const f32x4*>(Pb + (size_t)key * p.ldp)[c4];

@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
 #define DA_KSTR 132
 // Body of one attention block (h, sp of nsplit).  Returns true in the block that merged the partials
 // of its KV head and wrote attn_out rows [h*G*128, (h+1)*G*128) (block-uniform).
+// `table` (nullable): paged KV cache — logical 64-key block sp of this sequence lives in physical page table[sp] of the
+// pool (one page = one tile of this kernel); null = the contiguous single-sequence layout (page sp).
 __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const int nsplit,
                                                const float* __restrict__ qkv, float* __restrict__ kcache,
-                                               float* __restrict__ vcache, const int pos,
+                                               float* __restrict__ vcache, const int pos, const int* __restrict__ table,
                                                const float* __restrict__ rope_cos,
                                                const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                float* __restrict__ part_ml, int* __restrict__ cnt,
@@ -192,6 +194,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     const int k0 = sp * DA_KT;
     const int k1 = min(pos + 1, k0 + DA_KT);
     const int head = h * G + wid;
+    const int p0 = (table ? table[sp] : sp) * DA_KT;                 // first physical row of this tile's page
 
     // 1. put the K/V tile loads in flight first (8 x 16 B each per thread).  Unconditional loads from
     // clamped rows into NATIVE vector registers: with the loads under a branch and the HIP float4 struct
@@ -202,7 +205,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * 256;
         const int row = idx >> 5, c4 = idx & 31;
-        const int key = min(k0 + row, max_ctx - 1);
+        const int key = min(p0 + row, max_ctx - 1);
         kreg[i] = reinterpret_cast<const f32x4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
         vreg[i] = reinterpret_cast<const f32x4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
     }
@@ -223,8 +226,8 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
         const float va = vp[lane], vb = vp[lane + 64];
         kn_s[lane] = ka; kn_s[lane + 64] = kb;
         vn_s[lane] = va; vn_s[lane + 64] = vb;
-        float* kc = kcache + ((size_t)h * max_ctx + pos) * 128;
-        float* vc = vcache + ((size_t)h * max_ctx + pos) * 128;
+        float* kc = kcache + ((size_t)h * max_ctx + p0 + (pos - k0)) * 128;   // has_new: pos lies in this tile
+        float* vc = vcache + ((size_t)h * max_ctx + p0 + (pos - k0)) * 128;
         kc[lane] = ka; kc[lane + 64] = kb;
         vc[lane] = va; vc[lane + 64] = vb;
     }
@@ -320,13 +323,13 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
 }
 
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                                  float* __restrict__ vcache, const int pos,
+                                                  float* __restrict__ vcache, const int pos, const int* __restrict__ table,
                                                   const float* __restrict__ rope_cos,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
                                                   int max_splits, float scale) {
-    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, rope_cos, rope_sin, part_o,
+    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
                    part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
 }
 
@@ -354,11 +357,12 @@ __global__ __launch_bounds__(256) void k_dec_attn_oproj(const float* __restrict_
                                                         int nkv, int max_ctx, int max_splits, float scale,
                                                         int nsplit, int* __restrict__ done_ctr, int done_target,
                                                         int* __restrict__ err_flag, const uint16_t* __restrict__ Wo,
-                                                        int N, int K, float* __restrict__ out) {
+                                                        int N, int K, float* __restrict__ out,
+                                                        const int* __restrict__ table) {
     const int n_attn = nkv * nsplit;
     if ((int)blockIdx.x < n_attn) {
         const int h = blockIdx.x % nkv, sp = blockIdx.x / nkv;
-        const bool merged = dec_attn_block(h, sp, nsplit, qkv, kcache, vcache, pos, rope_cos, rope_sin, part_o,
+        const bool merged = dec_attn_block(h, sp, nsplit, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
                                            part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
         if (merged) {  // block-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -743,12 +747,13 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
-                 float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale) {
+                 float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
+                 const int* table) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits) return -1;
-    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
+    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
                        rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
     return 0;
 }
@@ -766,7 +771,8 @@ int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int 
 int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                        const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                        float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out) {
+                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out,
+                       const int* table) {
     constexpr int R = 16;
     (void)pos_ptr;
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
@@ -780,11 +786,11 @@ int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* v
     if (K <= 2048)
         hipLaunchKernelGGL((k_dec_attn_oproj<1, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
                            rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
-                           done_ctr, done_target, err_flag, Wo, N, K, out);
+                           done_ctr, done_target, err_flag, Wo, N, K, out, table);
     else
         hipLaunchKernelGGL((k_dec_attn_oproj<2, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
                            rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
-                           done_ctr, done_target, err_flag, Wo, N, K, out);
+                           done_ctr, done_target, err_flag, Wo, N, K, out, table);
     return 0;
 }
 

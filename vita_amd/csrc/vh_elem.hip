@@ -262,7 +262,7 @@ __global__ void k_audio_conv1(const float* __restrict__ feats, const float* __re
 __global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __restrict__ q_out,
                           float* __restrict__ kcache, float* __restrict__ vcache,
                           const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int S, int pos0,
-                          int nq, int nkv, int max_ctx) {
+                          int nq, int nkv, int max_ctx, const int* __restrict__ table) {
     const int nh = nq + 2 * nkv;
     const long total = (long)S * nh * 64;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -270,16 +270,17 @@ __global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __re
         const int hh = (int)((i >> 6) % nh);
         const int s = (int)(i / ((long)nh * 64));
         const int pos = pos0 + s;
+        const int row = table ? table[pos >> 6] * 64 + (pos & 63) : pos;   // paged KV cache: physical row of this position
         const float* src = qkv + (size_t)s * ldqkv + hh * 128;
         const float a = src[d], bq = src[d + 64];
         if (hh < nq + nkv) {
             const float c = rope_cos[(size_t)pos * 64 + d], sn = rope_sin[(size_t)pos * 64 + d];
             const float ra = a * c - bq * sn, rb = bq * c + a * sn;
             float* dst = (hh < nq) ? (q_out + ((size_t)s * nq + hh) * 128)
-                                   : (kcache + ((size_t)(hh - nq) * max_ctx + pos) * 128);
+                                   : (kcache + ((size_t)(hh - nq) * max_ctx + row) * 128);
             dst[d] = ra; dst[d + 64] = rb;
         } else {
-            float* dst = vcache + ((size_t)(hh - nq - nkv) * max_ctx + pos) * 128;
+            float* dst = vcache + ((size_t)(hh - nq - nkv) * max_ctx + row) * 128;
             dst[d] = a; dst[d + 64] = bq;
         }
     }
@@ -456,10 +457,11 @@ int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const
     return 0;
 }
 int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
-                const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx) {
+                const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx,
+                const int* table) {
     if (S == 0) return 0;
     hipLaunchKernelGGL(k_rope_kv, dim3(grid_for((long)S * (nq + 2 * nkv) * 64, 256)), dim3(256), 0, st, qkv, ldqkv,
-                       q_out, kcache, vcache, rope_cos, rope_sin, S, pos0, nq, nkv, max_ctx);
+                       q_out, kcache, vcache, rope_cos, rope_sin, S, pos0, nq, nkv, max_ctx, table);
     return 0;
 }
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,

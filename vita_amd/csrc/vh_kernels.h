@@ -28,12 +28,14 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
                 const uint16_t* W, int N, int K, float* out);
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
-                 float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale);
+                 float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
+                 const int* table);   // table: nullable page table of a paged KV cache (64-token pages)
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out);
 int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                        const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                        float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out);
+                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out,
+                       const int* table);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid);
@@ -97,6 +99,7 @@ struct VhAttnArgs {
     int klen;                             // keys >= klen are masked (pad mask); use Sk for none
     int chunk, left;                      // chunk>0: whale chunk mask (utils.py:88-103); left<0 = all left chunks
     float scale;
+    const int* ktable;                    // nullable: keys / values live in 64-row pages, logical block j>>6 -> page ktable[j>>6]
 };
 int vhk_attn(hipStream_t st, const VhAttnArgs& a);
 
@@ -113,7 +116,8 @@ int vhk_vit_pixel_shuffle(hipStream_t st, const float* x, float* out, int n, int
 int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const float* istd, const uint16_t* w,
                     const float* b, float* out, int T, int F, int C);
 int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
-                const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx);
+                const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx,
+                const int* table);
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
                      const float* img_feats, const float* aud_feats, float* out, int S, int H);
 int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,

@@ -23,7 +23,7 @@ def rope_tables(max_pos, head_dim, theta):
 
 class MixtralEngine:
     def __init__(self, cfg: VitaConfig, packed, device, max_ctx=None, max_prefill=None, max_new=1024, rank=0,
-                 world=1, nsplit=0, logit_rows=0):
+                 world=1, nsplit=0, logit_rows=0, max_seqs=0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VitaHipError("MixtralEngine needs a GPU (no CPU fallback)")
@@ -31,6 +31,8 @@ class MixtralEngine:
         self.cfg, self.device, self.packed = cfg, device, packed
         max_prefill = max_prefill or cfg.tokenizer_model_max_length
         max_ctx = max_ctx or (max_prefill + max_new + 1)
+        if max_seqs > 0:
+            max_ctx = -(-max_ctx // 64) * 64     # paged KV cache: the pool is whole 64-token pages
         self.max_ctx, self.max_prefill, self.max_new = max_ctx, max_prefill, max_new
         lay0 = packed["layers"][0]
         nq = (lay0["wqkv"].shape[0] // t.head_dim) * t.num_attention_heads // (
@@ -43,6 +45,7 @@ class MixtralEngine:
         c.max_ctx, c.max_prefill, c.max_new = max_ctx, max_prefill, max_new
         c.tp_rank, c.tp_world, c.nsplit, c.logit_rows = rank, world, nsplit, logit_rows
         c.vocab_lo, c.vocab_n = int(packed.get("vocab_lo", 0)), int(packed.get("vocab_n", 0))   # vocab-sharded LM head
+        c.max_seqs = int(max_seqs)
         if c.vocab_n and packed["lm_head"].shape[0] != c.vocab_n:
             raise ValueError("packed lm_head does not match its vocab shard")
         self.c = c
@@ -177,6 +180,54 @@ class MixtralEngine:
             raise _lib.VitaHipError("device-side time-out (fused decode hand-off or all-reduce): error flag set, "
                                     "the tokens of this request are not trustworthy")
         return c
+
+    # ---- concurrent sequences over the paged KV cache (vh_mixtral_seq_*) -----------------------------------------
+    def _view_i32(self, ptr, n):
+        base = self.workspace.data_ptr()
+        return self.workspace[ptr - base: ptr - base + 4 * n].view(torch.int32)
+
+    def seq_alloc(self):
+        """-> sequence slot id (raises VitaHipError, code VH_E_FULL, when every slot is taken)."""
+        s = self.lib.vh_mixtral_seq_alloc(self.h)
+        if s < 0:
+            check(s, "vh_mixtral_seq_alloc")
+        return s
+
+    def seq_free(self, s):
+        check(self.lib.vh_mixtral_seq_free(self.h, int(s)), "vh_mixtral_seq_free")
+
+    def seq_prefill(self, s, embeds, want_logits=False):
+        """append embeds [S, hidden] to sequence s; its next greedy token lands in seq_tokens(s)[0]."""
+        if embeds.dtype != torch.float32 or not embeds.is_cuda:
+            raise TypeError("embeds must be a float32 GPU tensor")
+        embeds = embeds.contiguous()
+        out = torch.empty(self.c.vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        check(self.lib.vh_mixtral_seq_prefill(self.h, int(s), embeds.data_ptr(), embeds.shape[0],
+                                              out.data_ptr() if out is not None else None, self._stream()),
+              "vh_mixtral_seq_prefill")
+        return out
+
+    def seq_decode(self, seqs):
+        """one greedy step for every listed sequence (one continuous-batching iteration)."""
+        arr = (C.c_int * len(seqs))(*[int(x) for x in seqs])
+        check(self.lib.vh_mixtral_seq_decode(self.h, arr, len(seqs), self._stream()), "vh_mixtral_seq_decode")
+
+    def seq_tokens(self, s):
+        return self._view_i32(self.lib.vh_mixtral_seq_tokens(self.h, int(s)), max(self.max_new, 1))
+
+    def seq_counters(self, s):
+        return self._view_i32(self.lib.vh_mixtral_seq_counters(self.h, int(s)), 4)
+
+    def seq_pos(self, s):
+        return self.lib.vh_mixtral_seq_pos(self.h, int(s))
+
+    def seq_pages(self, s):
+        buf = (C.c_int * (self.max_ctx // 64 + 1))()
+        n = self.lib.vh_mixtral_seq_table(self.h, int(s), buf, len(buf))
+        return list(buf[:max(n, 0)])
+
+    def pages_free(self):
+        return self.lib.vh_mixtral_pages_free(self.h)
 
     def generated(self):
         """(synchronising) list of token ids generated so far."""

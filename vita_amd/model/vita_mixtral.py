@@ -50,7 +50,7 @@ class _Backbone(_HipModule):
 
 class VITAMixtralForCausalLM(_HipModule):
     def __init__(self, cfg: VitaConfig, state_dict, device="cuda:0", packed_llm=None, max_new_tokens=1024,
-                 max_prefill=None, rank=0, world=1, keep_scores=True):
+                 max_prefill=None, rank=0, world=1, keep_scores=True, max_seqs=0, kv_pool_tokens=None):
         super().__init__()
         from ..checkpoint import pack_mixtral
         self.vcfg_all = cfg
@@ -79,7 +79,8 @@ class VITAMixtralForCausalLM(_HipModule):
         self.max_prefill = max_prefill or cfg.tokenizer_model_max_length
         self.engine = MixtralEngine(cfg, self.packed, self._device, max_prefill=self.max_prefill,
                                     max_new=max_new_tokens, rank=rank, world=world,
-                                    logit_rows=max_new_tokens if keep_scores else 0)
+                                    logit_rows=max_new_tokens if keep_scores else 0,
+                                    max_seqs=max_seqs, max_ctx=kv_pool_tokens)   # max_seqs > 0: paged KV pool (serving)
         self.lookahead = 8          # decode steps enqueued per host synchronisation in generate()
         self.last_timing = {}
 

@@ -16,10 +16,17 @@ dynamic_preprocess (+thumbnail), expand its placeholder to 256 tokens per tile a
 vLLM audio tower has no global_cmvn: mixtral.py:1245-1247), so the encoder is run with `normalized=True`.
 temperature <= 0.01 is greedy (the demo's setting); other sampling is not implemented.
 
-Not here (out of scope for this path): vLLM's paged KV cache / continuous batching scheduler — requests
-are served one at a time, as the offline demo does."""
+Concurrent requests (the interactive demo's AsyncLLMEngine, web_interactive_demo.py:126,315-328,942-951): the engine's
+KV cache is a pool of 64-token pages addressed through per-sequence block tables (vh_mixtral_seq_* in
+include/vita_hip.h); `ContinuousBatcher` is the iteration-level scheduler over it (admit -> prefill, one decode step for
+every running sequence per iteration, free on finish, preempt-by-recompute when the pool runs dry) and
+`AsyncLLMEngine.generate(inputs, sampling_params, request_id)` is the async iterator the demo consumes.  `LLM.generate`
+(the offline demo) keeps serving one request at a time on the same engine."""
+import asyncio
+import collections
 import json
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -109,7 +116,8 @@ def expanded_token_ids(sentinel_ids, audio_frames, *, image_token_index, audio_t
 
 class LLM:
     def __init__(self, model, dtype=None, tensor_parallel_size=1, trust_remote_code=True, gpu_memory_utilization=None,
-                 disable_custom_all_reduce=True, limit_mm_per_prompt=None, max_new_tokens=1024, device="cuda", **_):
+                 disable_custom_all_reduce=True, limit_mm_per_prompt=None, max_new_tokens=1024, device="cuda",
+                 max_num_seqs=0, kv_pool_tokens=None, **_):
         from .model.builder import load_pretrained_model
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if tensor_parallel_size != 1 and tensor_parallel_size != world:
@@ -125,7 +133,7 @@ class LLM:
             torch.cuda.set_device(torch.device(device))       # kernels launch on the CURRENT device's stream
         self.tokenizer, self.model, self.image_processor, _ = load_pretrained_model(
             model, None, os.path.basename(str(model).rstrip("/")), "mixtral-8x7b", device=device,
-            max_new_tokens=max_new_tokens, **kw)
+            max_new_tokens=max_new_tokens, max_seqs=int(max_num_seqs), kv_pool_tokens=kv_pool_tokens, **kw)
         self.collective = "none"
         if world > 1:
             from .parallel import setup_tensor_parallel
@@ -152,7 +160,9 @@ class LLM:
                                    use_thumbnail=self.use_thumbnail, limit_mm=self.limit_mm)
 
     @torch.no_grad()
-    def _one(self, inp, sp: SamplingParams, streamer=None):
+    def _prepare(self, inp, sp: SamplingParams):
+        """host side of one request: ids, placeholder expansion, pixel / fbank tensors (what vLLM's input processor and
+        mapper do: mixtral.py:194-311).  Returns dict(ids, sent, pix, feats, lens, normalized, max_tokens, eos)."""
         if isinstance(inp, str):
             inp = {"prompt": inp}
         ids = inp.get("prompt_token_ids")
@@ -175,6 +185,7 @@ class LLM:
         else:
             pix = torch.zeros((1, 3, size, size), device=dev)                  # the demo's dummy image
         enc = self.model.get_audio_encoder()
+        normalized = False
         if audios:
             if len(audios) > 1:
                 T = max(int(a.shape[0]) for a in audios)
@@ -186,20 +197,43 @@ class LLM:
             lens = torch.tensor([int(a.shape[0]) for a in audios])
             if len({int(a.shape[0]) for a in audios}) > 1:
                 raise NotImplementedError("clips of different lengths in one request are not batched yet")
-            enc.normalized_input = True      # WhaleFeatureExtractor already applied CMVN
+            normalized = True                # WhaleFeatureExtractor already applied CMVN
         else:
             feats, lens = torch.zeros((1, 400, enc.acfg.input_dim)), torch.tensor([400])
+        eos = {self.model.generation_config.eos_token_id, *(sp.stop_token_ids or [])} - {None}
+        return dict(ids=ids, sent=sent, pix=pix, feats=feats.to(dev), lens=lens.to(dev), normalized=normalized,
+                    max_tokens=max_tokens, eos=eos)
+
+    @torch.no_grad()
+    def _embed(self, req):
+        """encoders + splice of a prepared request -> inputs_embeds [S, H] fp32 on the device."""
+        enc = self.model.get_audio_encoder()
+        enc.normalized_input = req["normalized"]
+        try:
+            dev = self.model.device
+            out = self.model.prepare_inputs_labels_for_multimodal(
+                torch.tensor([req["sent"]], dtype=torch.long, device=dev), None, None, None, None, req["pix"],
+                {"audios": req["feats"], "lengths": req["lens"]})
+        finally:
             enc.normalized_input = False
+        return out[4][0].to(torch.float32)
+
+    @torch.no_grad()
+    def _one(self, inp, sp: SamplingParams, streamer=None):
+        req = self._prepare(inp, sp)
+        ids, sent, pix, feats, lens, max_tokens = (req[k] for k in ("ids", "sent", "pix", "feats", "lens", "max_tokens"))
+        dev = self.model.device
+        enc = self.model.get_audio_encoder()
+        enc.normalized_input = req["normalized"]
         try:
             out = self.model.generate(torch.tensor([sent], dtype=torch.long, device=dev), images=pix,
                                       audios={"audios": feats.to(dev), "lengths": lens.to(dev)}, do_sample=False,
                                       num_beams=1, return_dict_in_generate=True, max_new_tokens=max_tokens,
-                                      eos_token_id=list({self.model.generation_config.eos_token_id,
-                                                         *(sp.stop_token_ids or [])}), streamer=streamer)
+                                      eos_token_id=list(req["eos"]), streamer=streamer)
         finally:
             enc.normalized_input = False
         gen = out.sequences[0, len(sent):].tolist()
-        eos = {self.model.generation_config.eos_token_id, *(sp.stop_token_ids or [])}
+        eos = req["eos"]
         reason = "stop" if gen and gen[-1] in eos else "length"
         text = self.tokenizer.decode(gen, skip_special_tokens=sp.skip_special_tokens)
         self._n += 1
@@ -256,3 +290,286 @@ class LLM:
         sp = sampling_params or SamplingParams()
         batch = prompts if isinstance(prompts, list) else [prompts]
         return [self._one(p, sp) for p in batch]
+
+
+# ---- concurrent requests: iteration-level scheduling over the paged KV cache -------------------------------------------
+class ContinuousBatcher:
+    """The scheduler half of vLLM's engine for this path (what drives the plugin's forward with `kv_caches` +
+    `attn_metadata`, vllm_file/mixtral.py:1130-1186), over `MixtralEngine.seq_*`:
+
+      add(request_id, embeds, max_tokens, eos)   queue a request (FIFO)
+      step() -> [(request_id, new_token_ids, finished, finish_reason)]   one iteration:
+          1. admit waiting requests while a sequence slot is free and the pool holds the prompt's pages plus one page of
+             headroom per running sequence (prefill is one C call per admitted request);
+          2. if the running sequences need more new pages than the pool has, preempt the youngest ones (free their pages,
+             re-queue them at the front with prompt + generated tokens as the new prompt: vLLM's recompute preemption);
+          3. `window` greedy decode steps for every running sequence (one C call per step), ONE host synchronisation,
+             then eos / max_tokens per sequence; finished sequences return their pages.
+      abort(request_id)
+
+    A sequence's ids do not depend on what else is scheduled (same kernels, same arithmetic per sequence); tokens decoded
+    past an eos inside a window are discarded, as MixtralEngine's single-request lookahead does."""
+
+    def __init__(self, engine, embed_tokens=None, max_batch=None, window=1):
+        self.eng, self.embed_tokens = engine, embed_tokens
+        self.max_batch = int(max_batch or engine.c.max_seqs)
+        if engine.c.max_seqs < 1:
+            raise ValueError("the engine was created without sequence slots (max_seqs = 0)")
+        self.window = int(window)
+        self.waiting = collections.deque()
+        self.running = []                 # admission order
+        self.stats = {"iterations": 0, "prefills": 0, "preemptions": 0, "decode_steps": 0}
+
+    def add(self, request_id, embeds, max_tokens, eos=()):
+        S = int(embeds.shape[0])
+        if S + 2 > self.eng.max_ctx or S > self.eng.max_prefill:
+            raise ValueError(f"prompt of {S} tokens exceeds the engine (max_prefill {self.eng.max_prefill}, pool "
+                             f"{self.eng.max_ctx} tokens)")
+        self.waiting.append(dict(id=request_id, emb=embeds, max_tokens=min(int(max_tokens), self.eng.max_new),
+                                 eos=set(eos), out=[], seq=None, base=0))
+
+    def abort(self, request_id):
+        for r in list(self.running):
+            if r["id"] == request_id:
+                self.eng.seq_free(r["seq"])
+                self.running.remove(r)
+                return True
+        for r in list(self.waiting):
+            if r["id"] == request_id:
+                self.waiting.remove(r)
+                return True
+        return False
+
+    def has_work(self):
+        return bool(self.waiting or self.running)
+
+    def _pages(self, n_tokens):
+        return -(-int(n_tokens) // 64)
+
+    def _admit(self):
+        events = []
+        while self.waiting and len(self.running) < self.max_batch:
+            r = self.waiting[0]
+            need = self._pages(r["emb"].shape[0] + 1) + len(self.running)       # + one page of headroom per runner
+            if need > self.eng.pages_free():
+                if not self.running:
+                    raise RuntimeError(f"request {r['id']}: prompt needs {need} KV pages, the pool has "
+                                       f"{self.eng.pages_free()}")
+                break
+            self.waiting.popleft()
+            r["seq"] = self.eng.seq_alloc()
+            try:
+                self.eng.seq_prefill(r["seq"], r["emb"])
+            except Exception:
+                self.eng.seq_free(r["seq"])
+                raise
+            r["fresh"] = True                    # its first token (tokens[0]) is not reported yet
+            self.running.append(r)
+            self.stats["prefills"] += 1
+        return events
+
+    def _preempt_for(self, steps):
+        """make sure `steps` decode steps of every running sequence find their pages; youngest sequences yield."""
+        while True:
+            new_pages = sum(self._pages(self.eng.seq_pos(r["seq"]) + steps) - len(self.eng.seq_pages(r["seq"]))
+                            for r in self.running)
+            if new_pages <= self.eng.pages_free() or len(self.running) <= 1:
+                return
+            r = self.running.pop()
+            self.eng.seq_free(r["seq"])
+            if r["out"] and self.embed_tokens is None:
+                raise RuntimeError("KV pool exhausted and no embed_tokens hook to recompute a preempted sequence")
+            if r["out"][r["base"]:]:
+                tail = self.embed_tokens(torch.tensor(r["out"][r["base"]:], dtype=torch.long, device=r["emb"].device))
+                r["emb"] = torch.cat([r["emb"], tail.to(torch.float32)], dim=0)
+            r["base"], r["seq"] = len(r["out"]), None
+            self.waiting.appendleft(r)
+            self.stats["preemptions"] += 1
+
+    @torch.no_grad()
+    def step(self):
+        self._admit()
+        if not self.running:
+            return []
+        # decode window, bounded by every sequence's token buffer and by the pool's addressable context
+        steps = self.window
+        for r in self.running:
+            n_dev = len(r["out"]) - r["base"] + (1 if r.get("fresh") else 0)
+            steps = min(steps, self.eng.max_new - n_dev, self.eng.max_ctx - 2 - self.eng.seq_pos(r["seq"]))
+        steps = max(steps, 0)
+        starved = None
+        if steps > 0:
+            self._preempt_for(steps)
+            if len(self.running) == 1:
+                r = self.running[0]
+                if self._pages(self.eng.seq_pos(r["seq"]) + steps) - len(self.eng.seq_pages(r["seq"])) > self.eng.pages_free():
+                    starved, steps = r, 0                         # alone and the pool is dry: it ends here ("length")
+        if steps > 0:
+            ids = [r["seq"] for r in self.running]
+            for _ in range(steps):
+                self.eng.seq_decode(ids)
+            self.stats["decode_steps"] += steps * len(ids)
+        self.stats["iterations"] += 1
+        torch.cuda.current_stream().synchronize()
+        events = []
+        for r in list(self.running):
+            cnt = self.eng.check_device_flag(self.eng.seq_counters(r["seq"]).tolist())
+            n_dev = min(cnt[1], self.eng.max_new)                 # tokens of this (re)prefill + its decode steps
+            have = len(r["out"]) - r["base"]
+            new = self.eng.seq_tokens(r["seq"])[have:n_dev].tolist()
+            r["fresh"] = False
+            accepted, reason = [], None
+            for tok in new:
+                accepted.append(tok)
+                if tok in r["eos"]:
+                    reason = "stop"
+                elif len(r["out"]) + len(accepted) >= r["max_tokens"]:
+                    reason = "length"
+                if reason:
+                    break
+            r["out"] += accepted
+            if reason is None and (r is starved or self.eng.seq_pos(r["seq"]) + 2 >= self.eng.max_ctx):
+                reason = "length"                                 # the pool cannot hold another token of this sequence
+            if reason:
+                self.eng.seq_free(r["seq"])
+                self.running.remove(r)
+            if accepted or reason:
+                events.append((r["id"], accepted, reason is not None, reason or ""))
+        return events
+
+
+@dataclass
+class AsyncEngineArgs:
+    """the fields web_interactive_demo.py:942-951 sets, plus the scheduler's knobs (vLLM names)."""
+    model: str = ""
+    dtype: str = "float16"
+    tensor_parallel_size: int = 1
+    trust_remote_code: bool = True
+    gpu_memory_utilization: float = 0.8
+    disable_custom_all_reduce: bool = True
+    limit_mm_per_prompt: Optional[dict] = None
+    max_num_seqs: int = 8
+    max_new_tokens: int = 1024
+    kv_pool_tokens: Optional[int] = None     # size of the paged KV pool (default: max_num_seqs full-length sequences)
+    device: str = "cuda"
+
+
+class AsyncLLMEngine:
+    """`vllm.AsyncLLMEngine` as the interactive demo uses it (web_interactive_demo.py:126, 315-328):
+
+        llm = AsyncLLMEngine.from_engine_args(AsyncEngineArgs(model=path, ...))
+        async for request_output in llm.generate(inputs, sampling_params=sp, request_id=uuid):
+            text = request_output.outputs[0].text          # cumulative
+
+    Requests submitted while others are running are batched by `ContinuousBatcher`: one scheduler thread owns the GPU
+    stream (encoders + prefill of admitted requests, then one decode step for every running sequence per iteration) and
+    posts RequestOutputs to the callers' event loops."""
+
+    def __init__(self, llm: "LLM", max_num_seqs=None, window=1):
+        self.llm = llm
+        eng = llm.model.engine
+        self.batcher = ContinuousBatcher(eng, embed_tokens=lambda ids: llm.model.model.embed_tokens(ids),
+                                         max_batch=max_num_seqs, window=window)
+        self._lock = threading.Lock()
+        self._cv = threading.Condition(self._lock)
+        self._incoming, self._aborts, self._sinks = [], [], {}
+        self._closed = False
+        self._thread = threading.Thread(target=self._loop, daemon=True, name="vita-amd-scheduler")
+        self._thread.start()
+
+    @classmethod
+    def from_engine_args(cls, args: AsyncEngineArgs, **kw):
+        pool = args.kv_pool_tokens
+        llm = LLM(args.model, dtype=args.dtype, tensor_parallel_size=args.tensor_parallel_size,
+                  limit_mm_per_prompt=args.limit_mm_per_prompt, max_new_tokens=args.max_new_tokens, device=args.device,
+                  max_num_seqs=args.max_num_seqs, kv_pool_tokens=pool)
+        return cls(llm, max_num_seqs=args.max_num_seqs, **kw)
+
+    async def get_tokenizer(self):
+        return self.llm.tokenizer
+
+    # -- scheduler thread ----------------------------------------------------------------------------------------------
+    def _post(self, rid, item):
+        sink = self._sinks.get(rid)
+        if sink is not None:
+            loop, q = sink
+            loop.call_soon_threadsafe(q.put_nowait, item)
+
+    def _loop(self):
+        torch.cuda.set_device(self.llm.model.device)
+        state = {}                                   # request id -> (prompt ids, sampling params, token list)
+        while True:
+            with self._cv:
+                while not (self._incoming or self._aborts or self.batcher.has_work() or self._closed):
+                    self._cv.wait()
+                if self._closed:
+                    return
+                incoming, self._incoming = self._incoming, []
+                aborts, self._aborts = self._aborts, []
+            for rid in aborts:
+                self.batcher.abort(rid)
+                state.pop(rid, None)
+            for rid, inputs, sp in incoming:
+                try:
+                    req = self.llm._prepare(inputs, sp)
+                    emb = self.llm._embed(req)
+                    self.batcher.add(rid, emb, req["max_tokens"], req["eos"])
+                    state[rid] = (req["ids"], sp, [])
+                except BaseException as e:          # surfaced to the caller's iterator
+                    self._post(rid, e)
+            try:
+                events = self.batcher.step()
+            except BaseException as e:
+                for rid in list(state):
+                    self._post(rid, e)
+                state.clear()
+                self.batcher.waiting.clear()
+                for r in list(self.batcher.running):
+                    self.batcher.abort(r["id"])
+                continue
+            for rid, new, finished, reason in events:
+                if rid not in state:
+                    continue
+                ids, sp, toks = state[rid]
+                toks += new
+                text = self.llm.tokenizer.decode(toks, skip_special_tokens=sp.skip_special_tokens)
+                self._post(rid, RequestOutput(request_id=str(rid), prompt_token_ids=ids, finished=finished,
+                                              outputs=[CompletionOutput(0, text, list(toks), reason)]))
+                if finished:
+                    state.pop(rid)
+
+    # -- caller side -----------------------------------------------------------------------------------------------------
+    async def generate(self, inputs, sampling_params: SamplingParams = None, request_id=None, **_):
+        sp = sampling_params or SamplingParams()
+        rid = request_id if request_id is not None else os.urandom(8).hex()
+        q = asyncio.Queue()
+        with self._cv:
+            if rid in self._sinks:
+                raise ValueError(f"request id {rid!r} is already running")
+            self._sinks[rid] = (asyncio.get_running_loop(), q)
+            self._incoming.append((rid, inputs, sp))
+            self._cv.notify()
+        try:
+            while True:
+                item = await q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+                if item.finished:
+                    return
+        finally:
+            with self._cv:
+                self._sinks.pop(rid, None)
+                self._aborts.append(rid)          # a consumer that leaves early (interrupt, noise verdict) frees the pages
+                self._cv.notify()
+
+    async def abort(self, request_id):
+        with self._cv:
+            self._aborts.append(request_id)
+            self._cv.notify()
+
+    def shutdown(self):
+        with self._cv:
+            self._closed = True
+            self._cv.notify()
+        self._thread.join(timeout=30)
