@@ -44,6 +44,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
     if (!strcmp(key, "gemv_rows")) { g_tuning.gemv_rows = value; return VH_OK; }
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
     if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
     if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
     if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
@@ -554,19 +555,38 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
         hipStreamWaitEvent(m->cs, m->ev_c[0], 0);
     }
 
+    // py holds 8 * max_prefill * H floats: K-split slabs of the projections (and of the MoE down projection later)
+    const long Sm = m->c.max_prefill;
+    int qkv_slabs = (int)((8L * H) / m->nqkv);
+    if (qkv_slabs > 4) qkv_slabs = 4;
+    const bool stream_attn = vh_tuning()->prefill_attn_gemm == 0 && qkv_slabs >= 1 && (H % 64) == 0 && ((nq * hd) % 64) == 0 &&
+                             H <= 4096 && (m->nqkv % 4) == 0;
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
-        VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.attn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
-        {
+        if (stream_attn) {
+            // weight-streaming projections (vh_gemm_ps.hip): the norm emits the bf16 hi/lo planes, the 35 row tiles of
+            // S = 552 run as 3 m-tiles per 256 weight rows and the kernel picks a K split that fills the CUs
+            // (72 QKV tiles x 3 slabs); the partial slabs are summed by the consumer (RoPE / KV write)
+            VH_TRY(vhk_rmsnorm_route(st, m->px, nullptr, m->pxn_hi, m->pxn_lo, w.attn_norm, Sn, H, m->c.rms_eps, nullptr, 0,
+                                     nullptr, nullptr), "rmsnorm");
+            VhGemmPsArgs g{};
+            g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; g.lda = H;
+            g.W = w.wqkv; g.ldw = H; g.C = m->py; g.ldc = m->nqkv; g.M = Sn; g.N = m->nqkv; g.K = H;
+            g.ksplit = -qkv_slabs; g.c_split_stride = (long)Sm * m->nqkv; g.nslab_out = m->pnslab + 1;
+            VH_TRY(vhk_gemm_ps(st, g), "qkv gemm");
+            VH_TRY(vhk_rope_kv(st, m->py, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
+                               m->c.max_ctx, m->table, m->pnslab + 1, g.c_split_stride), "rope");
+        } else {
+            VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.attn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
             VhGemmArgs g{};
             g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.nseg = 1; g.seglen = H;
             g.W = w.wqkv; g.ldw = H; g.C = m->pqkv; g.ldc = m->nqkv; g.M = Sn; g.N = m->nqkv; g.K = H;
             VH_TRY(vhk_gemm(st, g), "qkv gemm");
+            VH_TRY(vhk_rope_kv(st, m->pqkv, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
+                               m->c.max_ctx, m->table, nullptr, 0), "rope");
         }
-        VH_TRY(vhk_rope_kv(st, m->pqkv, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
-                           m->c.max_ctx, m->table), "rope");
         {
             VhAttnArgs a{};
             a.Q = m->pq; a.ldq = (long)nq * hd; a.hsq = hd;
@@ -578,6 +598,44 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             a.ktable = m->table;
             VH_TRY(vhk_attn(st, a), "attention");
         }
+        if (stream_attn) {
+            // O projection on the streaming kernel: planes of the attention output, K-split slabs, slab sum fused with
+            // the residual add (or feeding the all-reduce under tensor parallelism)
+            const int KO = nq * hd;
+            VH_TRY(vhk_split_planes(st, m->pattn, KO, m->ph_hi, m->ph_lo, KO, Sn, KO), "split planes");
+            VhGemmPsArgs g{};
+            g.A_hi = m->ph_hi; g.A_lo = m->ph_lo; g.lda = KO;
+            g.W = w.wo; g.ldw = KO; g.M = Sn; g.K = KO; g.ksplit = -8;
+            if (tp && overlap) {
+                // column halves: the all-reduce of half 0 (comm stream) runs under the GEMM of half 1 (SURVEY 8(e);
+                // o_proj is RowParallel in the reference: vllm_file/mixtral.py:470-476)
+                for (int h = 0; h < 2; ++h) {
+                    float* part = m->ptmp + (size_t)h * Sn * H2;
+                    float* yh = m->py + (size_t)h * 8 * Sm * H2;
+                    g.W = w.wo + (size_t)h * H2 * g.ldw; g.N = H2; g.C = yh; g.ldc = H2;
+                    g.c_split_stride = Sm * H2; g.nslab_out = m->pnslab + 2 + h;
+                    VH_TRY(vhk_gemm_ps(st, g), "o gemm");
+                    VH_TRY(vhk_sum_slabs(st, part, H2, yh, H2, Sn, H2, m->pnslab + 2 + h, 1, g.c_split_stride, 0), "slab sum");
+                    hipEventRecord(m->ev_c[h], st);
+                    hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
+                    if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                    hipEventRecord(m->ev_r[h], m->cs);
+                }
+                hipStreamWaitEvent(st, m->ev_r[0], 0);
+                hipStreamWaitEvent(st, m->ev_r[1], 0);
+                VH_TRY(vhk_add_halves(st, m->px, m->ptmp, m->ptmp + (size_t)Sn * H2, Sn, H), "add");
+            } else {
+                g.N = H; g.C = m->py; g.ldc = H; g.c_split_stride = Sm * H; g.nslab_out = m->pnslab + 2;
+                VH_TRY(vhk_gemm_ps(st, g), "o gemm");
+                if (tp) {
+                    VH_TRY(vhk_sum_slabs(st, m->ptmp, H, m->py, H, Sn, H, m->pnslab + 2, 1, g.c_split_stride, 0), "slab sum");
+                    if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                    VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+                } else {
+                    VH_TRY(vhk_sum_slabs(st, m->px, H, m->py, H, Sn, H, m->pnslab + 2, 1, g.c_split_stride, 1), "slab sum");
+                }
+            }
+        } else
         {
             VhGemmArgs g{};
             g.A = m->pattn; g.lda = (long)nq * hd; g.a_rows = Sn; g.nseg = 1; g.seglen = nq * hd;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_route(const float* __restrict__
             }
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && E > 0) {
         float lg[8];
         float mx = -INFINITY;
 #pragma unroll
@@ -161,6 +161,26 @@ __global__ void k_add(float* __restrict__ x, const float* __restrict__ y, long n
 }
 
 // x[r, :] += [a[r, :] | b[r, :]]  (a, b: the two column halves [rows][cols/2] of the overlapped TP prefill)
+
+// dst (+)= sum of the K-split partial slabs of a projection (slab k at src + k * stride; count read on the device)
+__global__ void k_sum_slabs(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds, int rows, int cols4,
+                            const int* __restrict__ nslab_dev, int nslab, long stride, int accumulate) {
+    const int ns = nslab_dev ? *nslab_dev : nslab;
+    const long total = (long)rows * cols4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        const float4* sp = reinterpret_cast<const float4*>(src + r * lds) + c;
+        float4 a = *sp;
+        for (int k = 1; k < ns; ++k) {
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(sp) + (size_t)k * stride);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float4* dp = reinterpret_cast<float4*>(dst + r * ldd) + c;
+        if (accumulate) { const float4 o = *dp; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *dp = a;
+    }
+}
 __global__ void k_add_halves(float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b, int rows,
                              int cols4) {
     const long total = (long)rows * cols4;
@@ -262,7 +282,8 @@ __global__ void k_audio_conv1(const float* __restrict__ feats, const float* __re
 __global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __restrict__ q_out,
                           float* __restrict__ kcache, float* __restrict__ vcache,
                           const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int S, int pos0,
-                          int nq, int nkv, int max_ctx, const int* __restrict__ table) {
+                          int nq, int nkv, int max_ctx, const int* __restrict__ table,
+                          const int* __restrict__ nslab_dev, long slab_stride) {
     const int nh = nq + 2 * nkv;
     const long total = (long)S * nh * 64;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -272,7 +293,11 @@ __global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __re
         const int pos = pos0 + s;
         const int row = table ? table[pos >> 6] * 64 + (pos & 63) : pos;   // paged KV cache: physical row of this position
         const float* src = qkv + (size_t)s * ldqkv + hh * 128;
-        const float a = src[d], bq = src[d + 64];
+        float a = src[d], bq = src[d + 64];
+        if (nslab_dev) {                                   // K-split projection: the partial slabs are summed here
+            const int ns = *nslab_dev;
+            for (int k = 1; k < ns; ++k) { a += src[(size_t)k * slab_stride + d]; bq += src[(size_t)k * slab_stride + d + 64]; }
+        }
         if (hh < nq + nkv) {
             const float c = rope_cos[(size_t)pos * 64 + d], sn = rope_sin[(size_t)pos * 64 + d];
             const float ra = a * c - bq * sn, rb = bq * c + a * sn;
@@ -458,10 +483,10 @@ int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const
 }
 int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
                 const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx,
-                const int* table) {
+                const int* table, const int* nslab_dev, long slab_stride) {
     if (S == 0) return 0;
     hipLaunchKernelGGL(k_rope_kv, dim3(grid_for((long)S * (nq + 2 * nkv) * 64, 256)), dim3(256), 0, st, qkv, ldqkv,
-                       q_out, kcache, vcache, rope_cos, rope_sin, S, pos0, nq, nkv, max_ctx, table);
+                       q_out, kcache, vcache, rope_cos, rope_sin, S, pos0, nq, nkv, max_ctx, table, nslab_dev, slab_stride);
     return 0;
 }
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
@@ -473,7 +498,8 @@ int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, co
 }
 int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
                       int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts) {
-    if (cols % 4 != 0 || cols > RR_MAXJ * 1024 || E < 2 || E > 8 || (y_hi && !y_lo) || (!y && !y_hi)) return -1;
+    if (cols % 4 != 0 || cols > RR_MAXJ * 1024 || E == 1 || E < 0 || E > 8 || (y_hi && !y_lo) || (!y && !y_hi)) return -1;   // E = 0: norm only
+    if (E > 0 && (!Wg || !ids || !wts)) return -1;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(k_rmsnorm_route, dim3(rows), dim3(256), 0, st, x, y, y_hi, y_lo, w, rows, cols, eps, Wg, E, ids,
                        wts);
@@ -490,6 +516,14 @@ int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, 
     if (S == 0) return 0;
     hipLaunchKernelGGL(k_moe_combine, dim3(grid_for((long)S * (H / 4), 256)), dim3(256), 0, st, x, y, wts, S, H, nslab,
                        slab_stride, nslab_dev);
+    return 0;
+}
+int vhk_sum_slabs(hipStream_t st, float* dst, long ldd, const float* src, long lds, int rows, int cols,
+                  const int* nslab_dev, int nslab, long stride, int accumulate) {
+    if ((cols % 4) || (ldd % 4) || (lds % 4) || (stride % 4) || rows < 0) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((long)rows * (cols / 4), 256)), dim3(256), 0, st, dst, ldd, src, lds, rows,
+                       cols / 4, nslab_dev, nslab, stride, accumulate);
     return 0;
 }
 int vhk_fill_hash_bf16(hipStream_t st, uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0,

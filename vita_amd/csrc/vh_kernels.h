@@ -10,6 +10,7 @@ struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
     int gemv_rows = 4;        // rows per block of the decode QKV / O GEMVs: 4 (12.9 / 8.3 us), 8 (13.1 / 9.4), 16 (15.8 / 11.7)
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
+    int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
     int prefill_moe_gemm = 0; // MoE prefill GEMMs: 0 = weight-streaming pre-split kernel (vh_gemm_ps, default), 1 = general kernel
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
     int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
@@ -117,7 +118,9 @@ int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const
                     const float* b, float* out, int T, int F, int C);
 int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
                 const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx,
-                const int* table);
+                const int* table, const int* nslab_dev, long slab_stride);   // nslab_dev: qkv is *nslab_dev partial slabs
+int vhk_sum_slabs(hipStream_t st, float* dst, long ldd, const float* src, long lds, int rows, int cols,
+                  const int* nslab_dev, int nslab, long stride, int accumulate);
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
                      const float* img_feats, const float* aud_feats, float* out, int S, int H);
 int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
