@@ -62,6 +62,10 @@ typedef struct {
     float* C; long ldc; const int* c_rowidx;
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
+    float* ws; size_t ws_bytes;   /* optional scratch: lets small launches split K over more blocks (partial sums, then one
+                                     reducing kernel that applies the epilogue); results differ from the unsplit launch
+                                     only by fp32 summation order */
+    int ksplit;                   /* 0 = decided by the library when ws != NULL, 1 = never split, n = n-way */
 } vh_gemm_args;
 int vh_gemm(const vh_gemm_args* args, void* stream);
 

@@ -66,6 +66,29 @@ def test_gemm_epilogue(dev, act):
     assert_close(f"gemm epilogue {act}", got, ref, atol=1e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("ksplit", [0, 1, 3, 8])
+def test_gemm_split_k(dev, ksplit):
+    """split-K (partial slabs + reducing kernel with the whole epilogue) against the fp64 reference, on the encoder shape
+    that leaves half the chip idle unsplit (M = 1025, N = 1024, K = 4096: 136 blocks), in-place residual included."""
+    from vita_amd import ops
+    rng = np.random.default_rng(40)
+    M, N, K = 1025, 1024, 4096
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = _w(rng, N, K)
+    bias, scale = _w(rng, N, std=0.5), _w(rng, N, std=1.0)
+    x = rng.standard_normal((M, N), dtype=np.float32)
+    xd = _dev(x, dev)
+    ops.gemm(_dev(a, dev), _dev(w, dev, torch.bfloat16), bias=_dev(bias, dev), act="gelu", scale=_dev(scale, dev),
+             resid=xd, out=xd, ksplit=ksplit)
+    ref = ACTS["gelu"](a.astype(np.float64) @ w.T + bias) * scale + x
+    assert_close(f"gemm split-K {ksplit}", to_np(xd), ref, atol=2e-5 * np.sqrt(K), rtol=2e-5)
+    # a small-K launch never splits below 4 K-tiles per block, a ragged N (not % 4) never splits
+    a2 = rng.standard_normal((70, 192), dtype=np.float32)
+    w2 = _w(rng, 130, 192)
+    got = to_np(ops.gemm(_dev(a2, dev), _dev(w2, dev, torch.bfloat16), ksplit=ksplit))
+    assert_close("ragged", got, a2.astype(np.float64) @ w2.T.astype(np.float64), atol=1e-4, rtol=2e-5)
+
+
 def test_gemm_inplace_residual(dev):
     """out aliases resid (the x += proj(...) pattern)."""
     from vita_amd import ops
@@ -279,6 +302,47 @@ def test_attention_vit_like(dev):
         r = qkv[b * N:(b + 1) * N].reshape(N, 3, H, d).transpose(1, 2, 0, 3)
         ref = _attn_ref(r[0], r[1], r[2], d ** -0.5)
         assert_close(f"attn vit b{b}", to_np(out[b * N:(b + 1) * N]), ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("groups", [1, 2, 4])
+def test_attention_key_groups(dev, groups, impl):
+    """every key-group instantiation (attn_ksplit: tiles dealt to 1 / 2 / 4 wave groups, merged in group order) gives the
+    single-pass result to fp32 rounding: plain d=64, rel-pos d=64, causal d=128 (4 falls back to 2 there)."""
+    from vita_amd import _lib, ops
+    rng = np.random.default_rng(80)
+    _lib.tune("attn_ksplit", groups)
+    _lib.tune("attn_impl", impl)          # 0 = direct-operand kernel (default), 1 = LDS-tiled kernel
+    try:
+        H, N, d = 2, 333, 64
+        q, k, v, p = (rng.standard_normal((N, H * d), dtype=np.float32) for _ in range(4))
+        bu, bv = rng.standard_normal((H, d), dtype=np.float32), rng.standard_normal((H, d), dtype=np.float32)
+        sp = lambda x: x.reshape(N, H, d).transpose(1, 0, 2)
+        out = torch.empty((N, H * d), dtype=torch.float32, device=dev)
+        kw = dict(B=1, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=H * d, hsq=d, ldk=H * d, hsk=d, ldv=H * d, hsv=d, ldo=H * d,
+                  scale=d ** -0.5)
+        ops.attention(_dev(q, dev), _dev(k, dev), _dev(v, dev), out, **kw)
+        assert_close(f"plain groups={groups}", to_np(out), _attn_ref(sp(q), sp(k), sp(v), d ** -0.5), atol=2e-5)
+        ops.attention(_dev(q, dev), _dev(k, dev), _dev(v, dev), out, klen=301, p=_dev(p, dev), ldp=H * d, hsp=d,
+                      bias_u=_dev(bu, dev), bias_v=_dev(bv, dev), **kw)
+        mask = np.broadcast_to(np.arange(N)[None, :] < 301, (N, N))
+        ref = _attn_ref(sp(q), sp(k), sp(v), d ** -0.5, mask, sp(p), bu[:, None, :], bv[:, None, :])
+        assert_close(f"relpos groups={groups}", to_np(out), ref, atol=5e-5)
+        nq, nkv, d2, max_ctx, Sq, pos0 = 4, 2, 128, 400, 150, 170
+        Sk = pos0 + Sq
+        q2 = rng.standard_normal((Sq, nq * d2), dtype=np.float32)
+        kc = rng.standard_normal((nkv, max_ctx, d2), dtype=np.float32)
+        vc = rng.standard_normal((nkv, max_ctx, d2), dtype=np.float32)
+        out2 = torch.empty((Sq, nq * d2), dtype=torch.float32, device=dev)
+        ops.attention(_dev(q2, dev), _dev(kc, dev), _dev(vc, dev), out2, B=1, Hq=nq, Hkv=nkv, Sq=Sq, Sk=Sk, d=d2,
+                      ldq=nq * d2, hsq=d2, ldk=d2, hsk=max_ctx * d2, ldv=d2, hsv=max_ctx * d2, ldo=nq * d2,
+                      scale=d2 ** -0.5, causal=True, q_off=pos0)
+        cm = np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]
+        ref2 = _attn_ref(q2.reshape(Sq, nq, d2).transpose(1, 0, 2), kc[:, :Sk], vc[:, :Sk], d2 ** -0.5, cm)
+        assert_close(f"causal gqa groups={groups}", to_np(out2), ref2, atol=2e-5)
+    finally:
+        _lib.tune("attn_ksplit", 0)
+        _lib.tune("attn_impl", 0)
 
 
 def test_attention_big_scores(dev):

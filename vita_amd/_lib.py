@@ -24,6 +24,7 @@ class GemmArgs(C.Structure):
         ("C", c_void_p), ("ldc", c_long), ("c_rowidx", c_void_p),
         ("bias", c_void_p), ("scale", c_void_p), ("resid", c_void_p), ("ldr", c_long),
         ("M", c_int), ("N", c_int), ("K", c_int), ("act", c_int),
+        ("ws", c_void_p), ("ws_bytes", C.c_size_t), ("ksplit", c_int),
     ]
 
 

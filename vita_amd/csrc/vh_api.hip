@@ -44,6 +44,8 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
     if (!strcmp(key, "gemv_rows")) { g_tuning.gemv_rows = value; return VH_OK; }
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
+    if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
     if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
     if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
@@ -69,6 +71,7 @@ int vh_gemm(const vh_gemm_args* a, void* stream) {
     g.C = a->C; g.ldc = a->ldc; g.c_rowidx = a->c_rowidx;
     g.bias = a->bias; g.scale = a->scale; g.resid = a->resid; g.ldr = a->ldr;
     g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act;
+    g.ws = a->ws; g.ws_bytes = a->ws_bytes; g.ksplit = a->ksplit;
     if ((a->lda % 4) != 0 || (a->ldw % 8) != 0) return fail(VH_E_SHAPE, "vh_gemm: lda%%4 / ldw%%8 alignment");
     return check_launch("vh_gemm", vhk_gemm(S(stream), g));
 }

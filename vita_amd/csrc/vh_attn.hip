@@ -38,19 +38,31 @@ __device__ __forceinline__ bool key_visible(const VhAttnArgs& p, int q, int key,
     return true;
 }
 
-template <int D, bool REL>
-__global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
+// KS: the keys of a query block are dealt to KS groups of 4 waves, 32-key tile by tile (tile t -> group t % KS), each
+// group running the flash recurrence on its share with its own LDS tiles; the partial (m, l, O) are merged in group
+// order at the end.  With 16 query rows per wave the whole problem is only ~1 wave per SIMD (ViT: 65 x 16 waves on 1024
+// SIMDs): a lone wave per SIMD cannot hide its LDS reads, barriers and the 8-pass fp32 MFMAs behind anything, which is
+// what the KS = 1 kernel measured (143 us against a 28 us matrix-pipe floor).  KS = 4 (d = 64) / 2 (d = 128) puts
+// 4 / 2 waves on every SIMD and shortens every wave's serial loop by the same factor.
+template <int D, bool REL, int KS>
+__global__ __launch_bounds__(256 * KS) void k_attn(const VhAttnArgs p) {
     constexpr int KSTR = D + 2, VSTR = D + 16, NS = D / 4, NT = D / 16;
-    __shared__ __attribute__((aligned(16))) float Kt[AT_KT * KSTR];
-    __shared__ __attribute__((aligned(16))) float Vt[AT_KT * VSTR];
-    __shared__ __attribute__((aligned(16))) float Pt[REL ? AT_KT * KSTR : 2];
-    __shared__ __attribute__((aligned(16))) float Ps[4][16 * AT_PSTR];
+    constexpr int K_SZ = AT_KT * KSTR, V_SZ = AT_KT * VSTR, P_SZ = REL ? AT_KT * KSTR : 0, PS_SZ = 16 * AT_PSTR;
+    constexpr int TILE_SZ = KS * (K_SZ + V_SZ + P_SZ);            // floats: the groups' K / V / P tiles
+    constexpr int MG_SZ = 4 * 64 * (8 + NT * 4);                  // one group's partial state for the merge (aliases the tiles)
+    constexpr int BASE_SZ = TILE_SZ > MG_SZ ? TILE_SZ : MG_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[BASE_SZ + 4 * KS * PS_SZ];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kg = wid >> 2, wq = wid & 3, tl = tid & 255;        // key group, query sub-block, thread within the group
+    float* Kt = smem + kg * K_SZ;
+    float* Vt = smem + KS * K_SZ + kg * V_SZ;
+    float* Pt = smem + KS * (K_SZ + V_SZ) + kg * P_SZ;
+    float* Ps = smem + BASE_SZ + wid * PS_SZ;
     const int h = blockIdx.y, b = blockIdx.z;
     const int hk = h / (p.Hq / p.Hkv);
     const int qblk = blockIdx.x * 64;
-    const int q0 = qblk + wid * 16;
+    const int q0 = qblk + wq * 16;
     const int lr = lane & 15, lg = lane >> 4;
 
     const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
@@ -90,14 +102,13 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
 
     // K/V(/P) tiles are prefetched one tile ahead into NATIVE vector registers with unconditional, clamped
     // 16-byte loads (rows past Sk are zeroed when the tile is written to LDS): the loads of tile t+1 are in
-    // flight during the MFMAs of tile t.  (The first version loaded 8 bytes at a time under a branch inside
-    // the staging loop: every tile began with a synchronous global round trip.)
+    // flight during the MFMAs of tile t.
     constexpr int F4 = AT_KT * (D / 4) / 256;   // 16-byte pieces per thread per operand: 2 (D=64) / 4 (D=128)
     f32x4 kr[F4], vr[F4], pr[REL ? F4 : 1];
     auto load_tile = [&](int kt0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < F4; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tl + i * 256;
             const int row = idx / (D / 4), c4 = idx % (D / 4);
             int key = min(kt0 + row, p.Sk - 1);
             if (p.ktable) key = p.ktable[key >> 6] * 64 + (key & 63);       // paged KV cache (Mixtral prefill of a sequence)
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
     auto store_tile = [&](int kt0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < F4; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tl + i * 256;
             const int row = idx / (D / 4), c4 = idx % (D / 4);
             const bool ok = kt0 + row < p.Sk;
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -127,29 +138,226 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
         }
     };
 
-    if (kloop > 0) load_tile(0);
-    for (int kt0 = 0; kt0 < kloop; kt0 += AT_KT) {
+    // group kg walks tiles kg, kg + KS, ...; the trip count is block-uniform (barriers), a tile past kloop is all
+    // masked keys (loads clamped) and leaves (m, l, O) untouched
+    const int clamp_k = max(kloop - 1, 0);
+    if (kloop > 0) load_tile(min(kg * AT_KT, clamp_k));
+    for (int it0 = 0; it0 < kloop; it0 += KS * AT_KT) {
+        const int kt0 = it0 + kg * AT_KT;
         store_tile(kt0);
         __syncthreads();
-        load_tile(min(kt0 + AT_KT, max(kloop - 1, 0)));   // always issued (clamped): counted by the compiler
+        load_tile(min(kt0 + KS * AT_KT, clamp_k));   // always issued (clamped): counted by the compiler
 
         // ---- S = Q K^T (+ Qv P^T) for two 16-key sub-tiles ---------------------------
         f32x4 sacc[2];
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* kr = &Kt[(jt * 16 + lr) * KSTR + lg];
+            const float* kp = &Kt[(jt * 16 + lr) * KSTR + lg];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kr[4 * s], a, 0, 0, 0);
+            for (int s = 0; s < NS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kp[4 * s], a, 0, 0, 0);
             if (REL) {
-                const float* pr = &Pt[(jt * 16 + lr) * KSTR + lg];
+                const float* pp = &Pt[(jt * 16 + lr) * KSTR + lg];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[s], pr[4 * s], a, 0, 0, 0);
+                for (int s = 0; s < NS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[s], pp[4 * s], a, 0, 0, 0);
             }
             sacc[jt] = a;
         }
 
         // ---- online softmax in D layout --------------------------------------------
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + lg * 4 + r;
+            float s0 = sacc[0][r] * p.scale, s1 = sacc[1][r] * p.scale;
+            if (kt0 >= kloop || !key_visible(p, q, kt0 + lr, kend)) s0 = -INFINITY;
+            if (kt0 >= kloop || !key_visible(p, q, kt0 + 16 + lr, kend)) s1 = -INFINITY;
+            const float mx = grp16_max(fmaxf(s0, s1));
+            const float mn = fmaxf(m[r], mx);
+            float p0, p1;
+            if (mn == -INFINITY) {
+                alpha[r] = 1.f; p0 = 0.f; p1 = 0.f;
+            } else {
+                alpha[r] = __expf(m[r] - mn);
+                p0 = __expf(s0 - mn);
+                p1 = __expf(s1 - mn);
+            }
+            l[r] = l[r] * alpha[r] + grp16_sum(p0 + p1);
+            m[r] = mn;
+            Ps[(lg * 4 + r) * AT_PSTR + lr] = p0;
+            Ps[(lg * 4 + r) * AT_PSTR + 16 + lr] = p1;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t][r] *= alpha[r];
+        __syncthreads();  // P patch visible to the whole wave (block-uniform trip count)
+
+        // ---- O += P V --------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < AT_KT / 4; ++s) {
+            const float pa = Ps[lr * AT_PSTR + 4 * s + lg];
+            const float* vp = &Vt[(4 * s + lg) * VSTR + lr];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * t], o[t], 0, 0, 0);
+        }
+        __syncthreads();  // tiles and P patch are rewritten next iteration
+    }
+
+    // ---- merge the key groups into group 0, in group order (deterministic) ---------------------------------------
+    if (KS > 1) {
+        float* mg = smem + (wq * 64 + lane) * (8 + NT * 4);   // aliases the K/V tiles: the loop's last barrier has passed
+        for (int g = 1; g < KS; ++g) {
+            if (kg == g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mg[r] = m[r]; mg[4 + r] = l[r]; }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mg[8 + t * 4 + r] = o[t][r];
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m2 = mg[r], l2 = mg[4 + r];
+                    const float mn = fmaxf(m[r], m2);
+                    const float a1 = (mn == -INFINITY) ? 1.f : __expf(m[r] - mn);
+                    const float a2 = (mn == -INFINITY) ? 0.f : __expf(m2 - mn);
+                    l[r] = l[r] * a1 + l2 * a2;
+                    m[r] = mn;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t][r] = o[t][r] * a1 + mg[8 + t * 4 + r] * a2;
+                }
+            }
+            __syncthreads();
+        }
+        if (kg != 0) return;
+    }
+
+    float* Ob = p.O + (size_t)b * p.bso + (size_t)h * D;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + lg * 4 + r;
+        if (q >= p.Sq) continue;
+        const float inv = (l[r] > 0.f) ? 1.0f / l[r] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Ob[(size_t)q * p.ldo + 16 * t + lr] = o[t][r] * inv;
+    }
+}
+
+
+// ---- direct-operand variant (default) ----------------------------------------------------------------------------
+// One wave = 16 query rows x one share of the keys; NO LDS tiles and no block barriers in the loop.  The MFMA operand
+// layout of v_mfma_f32_16x16x4_f32 lets every lane fetch its B operands as 16-byte global loads when the reduction
+// index is PERMUTED consistently on both operands:
+//   S = Q K^T : the four MFMAs of chunk c use d = 16c + 4*lg + u (u = 0..3): lane (lr, lg) holds the float4
+//               K[key lr][16c + 4lg ..] and the float4 Q[row lr][16c + 4lg ..] — a dot product does not care about order;
+//   O += P V  : lane lr owns the output columns d = lr*(D/16) + t, so its B operand of step s is the float4 (two for
+//               d = 128) V[key 4s + lg][lr*(D/16) ..]: 4 keys x a whole row per wave instruction, fully coalesced, and the
+//               result is stored with 16-byte stores.
+// Operands come straight from L2/L1 (K/V of a head: 0.5 MB, shared by every query tile of the head and, under GQA, by 4
+// heads), P goes D-layout -> A-layout through a wave-private LDS patch (wave-level ordering only).  The K registers are
+// reloaded for the next tile as soon as S is formed, the V registers after the PV product, so every load has a whole
+// phase to land.  KS waves of a block deal the key tiles among themselves (tile t -> wave t % KS) and merge (m, l, O) once
+// at the end — the only block barrier.  Waves never wait for each other, so occupancy is whatever the registers allow
+// and the launch is 16-row tiles x heads blocks (ViT: 1040) instead of 272 four-wave blocks marching through barriers.
+template <int D, bool REL, int KS>
+__global__ __launch_bounds__(64 * KS) void k_attn_direct(const VhAttnArgs p) {
+    constexpr int NC = D / 16;          // 16-wide chunks of d = K float4s per key row per lane-group = accumulators
+    constexpr int VQ = NC / 4;          // float4s of V per lane per key
+    constexpr int MGW = 8 + NC * 4;
+    __shared__ __attribute__((aligned(16))) float Ps[KS][16 * AT_PSTR];
+    __shared__ __attribute__((aligned(16))) float Mg[(KS > 1 ? KS - 1 : 1) * 64 * MGW];
+
+    const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (p.Hq / p.Hkv);
+    const int q0 = blockIdx.x * 16;
+    const int lr = lane & 15, lg = lane >> 4;
+    float* ps = Ps[kg];
+
+    const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
+    const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
+    const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
+    const float* Pb = REL ? (p.P + (size_t)h * p.hsp) : nullptr;
+
+    f32x4 qa[NC], qb[REL ? NC : 1];
+    {
+        const int q = min(q0 + lr, p.Sq - 1);               // rows past Sq compute on a copy of the last row, never stored
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Qb + (size_t)q * p.ldq + 16 * c + 4 * lg);
+            if (REL) {
+                qa[c] = v + *reinterpret_cast<const f32x4*>(p.bias_u + h * D + 16 * c + 4 * lg);
+                qb[c] = v + *reinterpret_cast<const f32x4*>(p.bias_v + h * D + 16 * c + 4 * lg);
+            } else {
+                qa[c] = v;
+            }
+        }
+    }
+
+    const int kend = min(p.Sk, p.klen);
+    int kloop = kend;
+    if (p.causal) kloop = min(kloop, min(q0 + 15, p.Sq - 1) + p.q_off + 1);
+
+    float m[4], l[4];
+    f32x4 o[NC];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < NC; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 kf[2][NC], pf[REL ? 2 : 1][REL ? NC : 1], vf[AT_KT / 4][VQ];
+    auto phys = [&](int key) __attribute__((always_inline)) {
+        key = min(key, p.Sk - 1);
+        return p.ktable ? p.ktable[key >> 6] * 64 + (key & 63) : key;
+    };
+    auto load_k = [&](int kt0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const size_t row = (size_t)phys(kt0 + 16 * jt + lr);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                kf[jt][c] = *reinterpret_cast<const f32x4*>(Kb + row * p.ldk + 16 * c + 4 * lg);
+                if (REL) pf[jt][c] = *reinterpret_cast<const f32x4*>(Pb + row * p.ldp + 16 * c + 4 * lg);
+            }
+        }
+    };
+    auto load_v = [&](int kt0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < AT_KT / 4; ++s) {
+            const size_t row = (size_t)phys(kt0 + 4 * s + lg);
+#pragma unroll
+            for (int j = 0; j < VQ; ++j) vf[s][j] = *reinterpret_cast<const f32x4*>(Vb + row * p.ldv + lr * NC + 4 * j);
+        }
+    };
+
+    constexpr int STEP = KS * AT_KT;
+    int kt0 = kg * AT_KT;
+    load_k(kt0);
+    load_v(kt0);
+    for (; kt0 < kloop; kt0 += STEP) {
+        // ---- S = Q K^T (+ Qv P^T) for the two 16-key sub-tiles ------------------------------------------------------
+        f32x4 sacc[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c][u], kf[jt][c][u], a, 0, 0, 0);
+            if (REL) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[c][u], pf[jt][c][u], a, 0, 0, 0);
+            }
+            sacc[jt] = a;
+        }
+        load_k(kt0 + STEP);                                  // (clamped) K of this wave's next tile: lands under softmax + PV
+
+        // ---- online softmax in D layout: lane holds S[q0 + 4lg + r][kt0 + 16jt + lr] --------------------------------
         float alpha[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -169,24 +377,58 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
             }
             l[r] = l[r] * alpha[r] + grp16_sum(p0 + p1);
             m[r] = mn;
-            Ps[wid][(lg * 4 + r) * AT_PSTR + lr] = p0;
-            Ps[wid][(lg * 4 + r) * AT_PSTR + 16 + lr] = p1;
+            ps[(lg * 4 + r) * AT_PSTR + lr] = p0;
+            ps[(lg * 4 + r) * AT_PSTR + 16 + lr] = p1;
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NC; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[t][r] *= alpha[r];
-        __syncthreads();  // P patch visible to the whole wave (block-uniform trip count)
+        // the patch is private to this wave: its LDS operations execute in order, only the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- O += P V --------------------------------------------------------------
+        // ---- O += P V -------------------------------------------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < AT_KT / 4; ++s) {
-            const float pa = Ps[wid][lr * AT_PSTR + 4 * s + lg];
-            const float* vr = &Vt[(4 * s + lg) * VSTR + lr];
+            const float pa = ps[lr * AT_PSTR + 4 * s + lg];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vr[16 * t], o[t], 0, 0, 0);
+            for (int t = 0; t < NC; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vf[s][t >> 2][t & 3], o[t], 0, 0, 0);
         }
-        __syncthreads();  // tiles and P patch are rewritten next iteration
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // patch reads are done before the next tile rewrites it
+        load_v(kt0 + STEP);                                  // lands under the next S and softmax
+    }
+
+    // ---- merge the key shares into wave 0, in wave order (deterministic) ---------------------------------------------
+    if (KS > 1) {
+        if (kg > 0) {
+            float* mg = Mg + ((kg - 1) * 64 + lane) * MGW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { mg[r] = m[r]; mg[4 + r] = l[r]; }
+#pragma unroll
+            for (int t = 0; t < NC; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mg[8 + t * 4 + r] = o[t][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+        for (int g = 1; g < KS; ++g) {
+            const float* mg = Mg + ((g - 1) * 64 + lane) * MGW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m2 = mg[r], l2 = mg[4 + r];
+                const float mn = fmaxf(m[r], m2);
+                const float a1 = (mn == -INFINITY) ? 1.f : __expf(m[r] - mn);
+                const float a2 = (mn == -INFINITY) ? 0.f : __expf(m2 - mn);
+                l[r] = l[r] * a1 + l2 * a2;
+                m[r] = mn;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) o[t][r] = o[t][r] * a1 + mg[8 + t * 4 + r] * a2;
+            }
+        }
     }
 
     float* Ob = p.O + (size_t)b * p.bso + (size_t)h * D;
@@ -196,7 +438,9 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
         if (q >= p.Sq) continue;
         const float inv = (l[r] > 0.f) ? 1.0f / l[r] : 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) Ob[(size_t)q * p.ldo + 16 * t + lr] = o[t][r] * inv;
+        for (int j = 0; j < VQ; ++j)
+            *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) =
+                f32x4{o[4 * j][r] * inv, o[4 * j + 1][r] * inv, o[4 * j + 2][r] * inv, o[4 * j + 3][r] * inv};
     }
 }
 
@@ -204,11 +448,42 @@ __global__ __launch_bounds__(256) void k_attn(const VhAttnArgs p) {
 
 int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
     if (a.Sq <= 0 || a.Sk <= 0 || a.Hq % a.Hkv != 0) return -1;
-    const dim3 grid((a.Sq + 63) / 64, a.Hq, a.B), blk(256);
     const bool rel = a.P != nullptr;
-    if (a.d == 64 && !rel) hipLaunchKernelGGL((k_attn<64, false>), grid, blk, 0, st, a);
-    else if (a.d == 64 && rel) hipLaunchKernelGGL((k_attn<64, true>), grid, blk, 0, st, a);
-    else if (a.d == 128 && !rel) hipLaunchKernelGGL((k_attn<128, false>), grid, blk, 0, st, a);
-    else return -1;
+    const int want = vh_tuning()->attn_ksplit;
+    const int kl = a.klen < a.Sk ? a.klen : a.Sk;
+    // direct-operand kernel (default): every operand row must allow 16-byte loads / stores
+    auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    const bool direct_ok = vh_tuning()->attn_impl == 0 && al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
+                           (!rel || (al16(a.bias_u) && al16(a.bias_v) && (a.ldp % 4) == 0 && (a.hsp % 4) == 0)) &&
+                           ((a.ldq | a.hsq | a.bsq | a.ldk | a.hsk | a.bsk | a.ldv | a.hsv | a.ldo | a.bso) % 4) == 0;
+    if (direct_ok && (a.d == 64 || (a.d == 128 && !rel))) {
+        const dim3 g16((a.Sq + 15) / 16, a.Hq, a.B);
+        int ks = want > 0 ? want : 4;
+        if (kl <= AT_KT) ks = 1;
+        else if (kl <= 2 * AT_KT && ks > 2) ks = 2;
+        if (a.d == 128) ks = ks >= 2 ? 2 : 1;
+#define AT_LAUNCH(DD, RR, KK) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK>), g16, dim3(64 * KK), 0, st, a)
+        if (a.d == 64 && !rel) { if (ks == 1) AT_LAUNCH(64, false, 1); else if (ks == 2) AT_LAUNCH(64, false, 2); else AT_LAUNCH(64, false, 4); }
+        else if (a.d == 64) { if (ks == 1) AT_LAUNCH(64, true, 1); else if (ks == 2) AT_LAUNCH(64, true, 2); else AT_LAUNCH(64, true, 4); }
+        else { if (ks == 1) AT_LAUNCH(128, false, 1); else AT_LAUNCH(128, false, 2); }
+#undef AT_LAUNCH
+        return 0;
+    }
+    const dim3 grid((a.Sq + 63) / 64, a.Hq, a.B);
+    // key groups per block: 4 (d = 64) / 2 (d = 64 rel-pos, d = 128) when the context is long enough to deal out (attn_ksplit = 1 keeps
+    // the single-group kernel: tests compare the two)
+    const bool one = want == 1 || kl <= 2 * AT_KT;
+    if (a.d == 64 && !rel) {
+        if (one) hipLaunchKernelGGL((k_attn<64, false, 1>), grid, dim3(256), 0, st, a);
+        else if (want == 2) hipLaunchKernelGGL((k_attn<64, false, 2>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<64, false, 4>), grid, dim3(1024), 0, st, a);
+    } else if (a.d == 64 && rel) {    // (4 groups need 12 spilled VGPRs at the 128-register budget of 1024 threads: auto = 2)
+        if (one) hipLaunchKernelGGL((k_attn<64, true, 1>), grid, dim3(256), 0, st, a);
+        else if (want == 4) hipLaunchKernelGGL((k_attn<64, true, 4>), grid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<64, true, 2>), grid, dim3(512), 0, st, a);
+    } else if (a.d == 128 && !rel) {
+        if (one) hipLaunchKernelGGL((k_attn<128, false, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<128, false, 2>), grid, dim3(512), 0, st, a);
+    } else return -1;
     return 0;
 }

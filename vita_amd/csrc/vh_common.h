@@ -61,25 +61,43 @@ __device__ __forceinline__ uint4 ld_weight16(const void* p) {
 }
 
 // ---- wave / block reductions ----------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Inside a row of 16 lanes the butterfly runs on DPP modifiers (quad_perm xor 1, xor 2, row_half_mirror, row_mirror):
+// VALU-rate, no LDS crossbar.  (__shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): ~100 cycles of exposed
+// latency per step — 28 of them per 32-key tile made the attention softmax longer than its MFMAs.)  Only the two
+// cross-row steps of a full-wave reduction still go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// reduce inside aligned groups of 16 lanes (MFMA 16x16 D-layout rows).
+#define VH_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define VH_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define VH_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i inside each half row
+#define VH_DPP_MIRROR 0x140       // lane i <-> 15 - i inside the row
+// reduce inside aligned groups of 16 lanes (MFMA 16x16 D-layout rows); every lane gets the result.
 __device__ __forceinline__ float grp16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov<VH_DPP_XOR1>(v);
+    v += dpp_mov<VH_DPP_XOR2>(v);
+    v += dpp_mov<VH_DPP_HALF_MIRROR>(v);
+    v += dpp_mov<VH_DPP_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ float grp16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_mov<VH_DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<VH_DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<VH_DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<VH_DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = grp16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = grp16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
@@ -112,4 +130,18 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     if (act == VH_ACT_RELU) return fmaxf(x, 0.f);
     if (act == VH_ACT_SILU) return silu_f(x);
     return x;
+}
+
+// number of compute units of the current device (256 on MI355X)
+inline int vh_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
 }

@@ -701,18 +701,6 @@ __global__ void k_dec_cand_unpack(const float* __restrict__ cand, int world, flo
     if ((int)threadIdx.x < world) { val[threadIdx.x] = cand[2 * threadIdx.x]; idx[threadIdx.x] = (int)cand[2 * threadIdx.x + 1]; }
 }
 
-inline int vh_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
-}
 
 template <typename F>
 inline int pick_nj(int K, F&& f) {

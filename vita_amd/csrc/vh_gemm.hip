@@ -187,13 +187,17 @@ void k_gemm(const VhGemmArgs p) {
     // Two K-tiles of operands are kept in flight in registers (sets 0 / 1): a K-tile iteration is
     // otherwise bounded by one global-load round trip (~1-2 us under load), which is what made every
     // small-M GEMM of the encoders cost ~2 us per 64 of K regardless of its size.
-    const int nkt = p.K / GM_BK;
+    // split-K: blockIdx.y takes the K-tiles [kt_lo, nkt) of its share and writes raw partial sums to its slab
+    const int nkt_all = p.K / GM_BK;
+    const int KSP = gridDim.y;
+    const int kt_lo = (int)(((long)nkt_all * blockIdx.y) / KSP);
+    const int nkt = (int)(((long)nkt_all * (blockIdx.y + 1)) / KSP);
     // loads are issued UNCONDITIONALLY (the tile index is clamped, the last tile is simply re-read): a
     // load under `if (kt + PF < nkt)` makes the number of outstanding loads unknown to hipcc, which then
     // waits vmcnt(0) and drains the younger tile as well
-    load_tile(0, ra0, rw0, keep0);
-    if (PF == 2) load_tile(min(1, nkt - 1), ra1, rw1, keep1);
-    for (int kt = 0; kt < nkt; kt += PF) {
+    load_tile(kt_lo, ra0, rw0, keep0);
+    if (PF == 2) load_tile(min(kt_lo + 1, nkt - 1), ra1, rw1, keep1);
+    for (int kt = kt_lo; kt < nkt; kt += PF) {
         __syncthreads();  // previous tile's fragment reads are done
         store_tile(ra0, rw0, keep0);
         __syncthreads();
@@ -229,7 +233,9 @@ void k_gemm(const VhGemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = n_begin + wn * 64 + j * 16 + (lane & 15);
-                    if (n < p.N) {
+                    if (n < p.N && KSP > 1) {
+                        p.ws[((size_t)blockIdx.y * p.M + m) * p.N + n] = acc[i][j][r];     // epilogue in k_gemm_reduce
+                    } else if (n < p.N) {
                         float v = acc[i][j][r];
                         if (p.bias) v += p.bias[n];
                         v = apply_act(v, p.act);
@@ -243,6 +249,29 @@ void k_gemm(const VhGemmArgs p) {
     }
 }
 
+// sum of the split-K slabs + the GEMM epilogue (4 columns per thread)
+__global__ __launch_bounds__(256) void k_gemm_reduce(const VhGemmArgs p, int ksp) {
+    const int n4 = p.N >> 2;
+    const long total = (long)p.M * n4;
+    const size_t slab = (size_t)p.M * p.N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / n4;
+        const int n = (int)(i - m * n4) * 4;
+        const float* src = p.ws + (size_t)m * p.N + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        for (int k = 1; k < ksp; ++k) v += *reinterpret_cast<const f32x4*>(src + k * slab);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (p.bias) x += p.bias[n + j];
+            x = apply_act(x, p.act);
+            if (p.scale) x *= p.scale[n + j];
+            if (p.resid) x += p.resid[m * p.ldr + n + j];
+            p.C[m * p.ldc + n + j] = x;
+        }
+    }
+}
+
 }  // namespace
 
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
@@ -252,7 +281,21 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
     g.mt_slots = a.group_off ? (a.M / GM_BM + a.ngroups) : (a.M + GM_BM - 1) / GM_BM;  // grouped: upper bound
-    const dim3 grid_glu(((a.N + 63) / 64) * g.mt_slots), grid(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots);
+    // split-K when the launch would leave most CUs with at most one 4-wave block (nothing to overlap a K-tile's load ->
+    // split -> LDS -> barrier chain with): aim at ~3 blocks per CU, keep >= 4 K-tiles per block
+    int ksp = 1;
+    const bool plain = !a.group_off && !a.W_up && !a.c_rowidx && (a.N % 4) == 0 && a.ws != nullptr;
+    if (plain && a.ksplit != 1) {
+        const long blocks = (long)((a.N + GM_BN - 1) / GM_BN) * g.mt_slots;
+        const int nkt = a.K / GM_BK;
+        const long target = 3L * vh_num_cus();
+        ksp = a.ksplit > 1 ? a.ksplit : (blocks >= target * 2 / 3 ? 1 : (int)((target + blocks - 1) / blocks));
+        if (ksp > nkt / 4) ksp = nkt / 4;
+        if (ksp > 8) ksp = 8;
+        while (ksp > 1 && (size_t)ksp * a.M * a.N * sizeof(float) > a.ws_bytes) --ksp;
+        if (ksp < 1) ksp = 1;
+    }
+    const dim3 grid_glu(((a.N + 63) / 64) * g.mt_slots), grid(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots, ksp);
     // two K-tiles in flight pays for the small plain GEMMs (encoders: -5..-9 %), not for the grouped ones (+-0)
     const int pf = vh_tuning()->gemm_prefetch;
     const bool pf2 = pf == 3 || (pf == 2 && a.group_off == nullptr);
@@ -262,6 +305,11 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     } else {
         if (pf2) hipLaunchKernelGGL((k_gemm<false, 2, 3>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_gemm<false, 1, 4>), grid, dim3(256), 0, st, g);
+        if (ksp > 1) {
+            long rg = ((long)a.M * (a.N / 4) + 255) / 256;
+            if (rg > 2048) rg = 2048;
+            hipLaunchKernelGGL(k_gemm_reduce, dim3((int)rg), dim3(256), 0, st, g, ksp);
+        }
     }
     return 0;
 }

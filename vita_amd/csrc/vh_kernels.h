@@ -10,6 +10,8 @@ struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
     int gemv_rows = 4;        // rows per block of the decode QKV / O GEMVs: 4 (12.9 / 8.3 us), 8 (13.1 / 9.4), 16 (15.8 / 11.7)
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
+    int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernel (16 rows per wave, no LDS tiles), 1 = LDS-tiled kernel
+    int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
     int prefill_moe_gemm = 0; // MoE prefill GEMMs: 0 = weight-streaming pre-split kernel (vh_gemm_ps, default), 1 = general kernel
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
@@ -63,6 +65,10 @@ struct VhGemmArgs {
     const float* bias; const float* scale; const float* resid; long ldr;
     int M, N, K, act;
     int mt_slots;                             // set by the launcher: m-tile slots per n-tile
+    // split-K for launches too small to fill the chip (encoder GEMMs: 136 blocks at M = 1025, N = 1024): `ws` is caller
+    // scratch for ksplit * M * N partial sums; a second kernel adds them and applies the epilogue.  ksplit 0 = the
+    // launcher decides (only when ws is given), 1 = off.  Plain (ungrouped, non-gated, no row maps) GEMMs only.
+    float* ws; size_t ws_bytes; int ksplit;
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
 

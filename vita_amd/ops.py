@@ -48,10 +48,24 @@ def _bf16(t, name="weight"):
     return t
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, nbytes):
+    """per-device scratch for split-K partial sums (stream-ordered reuse: every GEMM here runs on the current stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = t
+    return t
+
+
 def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=None, a_rowidx=None, a_rows=None,
          segrow=None, seglen=None, m=None, c_rowidx=None, group_off=None, ngroups=0, w_group_stride=0, lda=None,
-         ldc=None):
-    """out[orow(m), :] = epilogue(A[arow(m, k)] @ w.T).  a: fp32 [rows, lda]; w: bf16 [N, K] (or [E, N, K] grouped)."""
+         ldc=None, ksplit=0):
+    """out[orow(m), :] = epilogue(A[arow(m, k)] @ w.T).  a: fp32 [rows, lda]; w: bf16 [N, K] (or [E, N, K] grouped).
+    ksplit: 0 = the library may split K over more blocks for small launches (plain GEMMs), 1 = never, n = n-way."""
     _dev(a, w, out)
     _f32(_c(a, "a"), "a"); _bf16(w, "w")
     if not w.is_contiguous():
@@ -83,6 +97,10 @@ def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=No
     if resid is not None:
         g.resid = resid.data_ptr(); g.ldr = int(resid.stride(0))
     g.M, g.N, g.K, g.act = M, N, K, ACT[act]
+    g.ksplit = int(ksplit)
+    if ksplit != 1 and group_off is None and w_up is None and c_rowidx is None and M * N <= (8 << 20):
+        ws = _scratch(a.device, 8 * 4 * M * N)
+        g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     check(lib.vh_gemm(C.byref(g), _stream()), "vh_gemm")
     return out
 
