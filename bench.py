@@ -31,7 +31,7 @@ def pmc_traffic(kernel):
     MI355X_MICROARCH.md prescribes; collected by profiles/pmc_pass.sh in its own run — counters cannot be
     read from inside this process).  TP=1 only: the launch moves 1/N of the bytes at TP=N."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
             return int(json.load(f)[kernel]["hbm_read_bytes_per_launch"])
     except Exception:
         return None
