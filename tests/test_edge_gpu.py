@@ -83,4 +83,15 @@ def test_single_token_prompt_and_cache_exhaustion(dev):
         eng.decode(16)
     with pytest.raises(_lib.VitaHipError):            # prefill longer than max_prefill
         eng.prefill(torch.zeros((5, cfg.text.hidden_size), device=dev))
+    # a rejected call leaves the engine consistent and usable: the steps that fitted were kept (positions 1..7), the
+    # host mirror did not run ahead of the device counter, and a fresh prefill + decode reproduces the oracle
+    torch.cuda.synchronize()
+    c = eng.check_device_flag()
+    assert c[0] == 7 and c[1] == 7, c                 # pos = max_ctx - 1; 1 prefill token + 3 + the 3 steps that fitted
+    with pytest.raises(_lib.VitaHipError):
+        eng.decode(1)                                 # still full: refused again, nothing enqueued
+    eng.prefill(torch.from_numpy(emb).to(dev))
+    eng.decode(3)
+    torch.cuda.synchronize()
+    assert eng.generated() == ref_ids
     eng.close()
