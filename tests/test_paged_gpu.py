@@ -160,6 +160,46 @@ def test_continuous_batcher_matches_oracle(dev):
     eng.close()
 
 
+@pytest.mark.parametrize("batched", [1, 2, 0])
+def test_six_sequences_batched_kernels_match_oracle(dev, batched):
+    """six sequences advance together: groups of 4 + 2 through the batched decode kernels (shared attention weights and LM
+    head, every distinct routed expert streamed once) — or one after the other (batch_decode = 0); ids equal the oracle's
+    per-request ids either way, and a late joiner / an early leaver change nothing for the others."""
+    from vita_amd import _lib
+    n_new = 14
+    lens = [40, 97, 64, 130, 20, 75]
+    _, _, eng, reqs = _setup(dev, lens, n_new, seed=11, pool=2048, max_seqs=6)
+    _lib.tune("batch_decode", min(batched, 1))
+    _lib.tune("batch_moe", 1 if batched == 2 else 0)     # 2: also the expert GEMVs with de-duplication
+    try:
+        seqs = []
+        for r in reqs[:5]:
+            sq = eng.seq_alloc()
+            eng.seq_prefill(sq, r["emb"])
+            seqs.append(sq)
+        for _ in range(3):
+            eng.seq_decode(seqs)                       # 5 sequences: 4 + 1
+        late = eng.seq_alloc()
+        eng.seq_prefill(late, reqs[5]["emb"])          # joins after three iterations
+        for _ in range(3):
+            eng.seq_decode(seqs + [late])              # 4 + 2
+        assert _ids(eng, seqs[1], 7) == reqs[1]["ref_ids"][:7]
+        eng.seq_free(seqs[1])                          # leaves early
+        rest = [q for q in seqs if q != seqs[1]] + [late]
+        for _ in range(n_new - 7):
+            eng.seq_decode(rest)                       # 4 + 1
+        for _ in range(3):
+            eng.seq_decode([late])
+        for i, q in enumerate(seqs):
+            if i != 1:
+                assert _ids(eng, q, n_new) == reqs[i]["ref_ids"], i
+        assert _ids(eng, late, n_new) == reqs[5]["ref_ids"]
+    finally:
+        _lib.tune("batch_decode", 1)
+        _lib.tune("batch_moe", 0)
+    eng.close()
+
+
 def test_batcher_preempts_by_recompute_when_the_pool_runs_dry(dev):
     """4 pages for two sequences of 60 and 62 tokens that each grow past a page boundary and then need a third and a
     fourth page... the younger one is preempted, re-queued with prompt + generated tokens, and still ends with the

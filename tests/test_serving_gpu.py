@@ -76,3 +76,40 @@ def test_text_only_and_errors(served, dev):
         llm.generate({"prompt_token_ids": [1, IMG_ID, 5]}, sampling_params=SamplingParams(max_tokens=2))
     with pytest.raises(NotImplementedError):
         llm.generate({"prompt_token_ids": [1, 5]}, sampling_params=SamplingParams(temperature=0.8))
+
+
+# ---- tensor_parallel_size = 2: two LLM processes (one GPU, gloo bootstrap, the library's IPC all-reduce) -------------
+def _tp_llm_worker(rank, world, port, ckpt, prompts, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK="0", VITA_AMD_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from vita_amd.serving import LLM, SamplingParams
+    llm = LLM(model=ckpt, dtype="float16", tensor_parallel_size=world, max_new_tokens=16)
+    try:
+        outs = llm.generate([{"prompt_token_ids": p} for p in prompts],
+                            sampling_params=SamplingParams(temperature=0.01, max_tokens=8))
+        ret[rank] = (llm.collective, [o.outputs[0].token_ids for o in outs])
+        dist.barrier()
+    finally:
+        llm.model.engine.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_llm_tensor_parallel_two_processes(served, dev):
+    """`LLM(..., tensor_parallel_size=2)` under a one-process-per-GPU launch: each process builds its rank's shard, brings up
+    the collective itself and serves the same requests; both ranks return the single-process tokens."""
+    import socket
+    import torch.multiprocessing as mp
+    from vita_amd.serving import SamplingParams
+    llm, _, d = served
+    prompts = [[1, 5, 6, 7, 8], [1, 9, 10, 11, 12, 13, 14, 15, 16, 17]]
+    exp = [llm.generate({"prompt_token_ids": p}, sampling_params=SamplingParams(temperature=0.01, max_tokens=8))[0]
+           .outputs[0].token_ids for p in prompts]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_tp_llm_worker, args=(2, port, d, prompts, ret), nprocs=2, join=True)
+    assert ret[0][0] == ret[1][0] and ret[0][0] in ("ipc", "torch"), dict(ret)
+    assert ret[0][1] == exp and ret[1][1] == exp, (dict(ret), exp)

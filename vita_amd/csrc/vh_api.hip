@@ -44,6 +44,8 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
     if (!strcmp(key, "gemv_rows")) { g_tuning.gemv_rows = value; return VH_OK; }
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
+    if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
@@ -229,6 +231,10 @@ struct vh_mixtral {
     std::vector<int> free_pages;
     float* seq_x = nullptr;            // [max_seqs][4][H]: xa, xb, delta_attn, delta_moe
     int *seq_counters = nullptr, *seq_tokens = nullptr, *seq_table = nullptr;
+    // scratch "lanes" 1..VH_BMAX-1 of the per-step buffers (lane 0 = the single-sequence ones) for batched decode iterations
+    float *l_qkv[VH_BMAX] = {}, *l_part_o[VH_BMAX] = {}, *l_part_ml[VH_BMAX] = {}, *l_attn_out[VH_BMAX] = {}, *l_hbuf[VH_BMAX] = {},
+          *l_blk_val[VH_BMAX] = {}, *l_cand[VH_BMAX] = {};
+    int *l_attn_cnt[VH_BMAX] = {}, *l_route[VH_BMAX] = {}, *l_blk_idx[VH_BMAX] = {};
     const int* table = nullptr;        // device page table of the bound sequence; null = contiguous rows (default state)
     int bound = -1;
     struct { float *xa, *xb, *da, *dm; int *counters, *out_tokens; int host_pos, attn_epoch, poisoned; } dflt{};
@@ -322,6 +328,20 @@ struct vh_mixtral {
             seq_counters = cv.take<int>(n * 4);
             seq_tokens = cv.take<int>(n * (c.max_new > 0 ? c.max_new : 1));
             seq_table = cv.take<int>(n * max_splits);
+            l_qkv[0] = qkv; l_part_o[0] = part_o; l_part_ml[0] = part_ml; l_attn_out[0] = attn_out; l_attn_cnt[0] = attn_cnt;
+            l_hbuf[0] = hbuf; l_route[0] = route; l_blk_val[0] = blk_val; l_blk_idx[0] = blk_idx; l_cand[0] = cand;
+            for (int b = 1; b < VH_BMAX; ++b) {
+                l_qkv[b] = cv.take<float>(nqkv);
+                l_part_o[b] = cv.take<float>((size_t)nq * max_splits * hd);
+                l_part_ml[b] = cv.take<float>((size_t)nq * max_splits * 2);
+                l_attn_out[b] = cv.take<float>((size_t)nq * hd);
+                l_attn_cnt[b] = cv.take<int>(nkv);
+                l_hbuf[b] = cv.take<float>((size_t)2 * I);
+                l_route[b] = cv.take<int>(4);
+                l_blk_val[b] = cv.take<float>(lm_grid);
+                l_blk_idx[b] = cv.take<int>(lm_grid);
+                l_cand[b] = cv.take<float>(2 * (c.tp_world > 0 ? c.tp_world : 1));
+            }
         }
         return cv.off;
     }
@@ -925,6 +945,96 @@ int vh_mixtral_seq_prefill(vh_mixtral_t* m, int s, const float* embeds, int Sn, 
     return rc;
 }
 
+// One decode step of up to VH_BMAX sequences with the batched kernels (weights of the attention side, the LM head and
+// every DISTINCT routed expert are streamed once for the whole group).  Sequence state is addressed in place (slots).
+static int decode_batch_step(vh_mixtral* m, hipStream_t st, const int* ids, int n) {
+    const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float eps = m->c.rms_eps;
+    float *xa[VH_BMAX], *xb[VH_BMAX], *da[VH_BMAX], *dm[VH_BMAX];
+    int* cnt[VH_BMAX];
+    for (int b = 0; b < n; ++b) {
+        float* x = m->seq_x + (size_t)ids[b] * 4 * H;
+        xa[b] = x; xb[b] = x + H; da[b] = x + 2 * H; dm[b] = x + 3 * H;
+        cnt[b] = m->seq_counters + 4 * ids[b];
+    }
+    VhDecBatchAttn at{};
+    VhDecBatchRoute rt{};
+    for (int b = 0; b < n; ++b) {
+        at.qkv[b] = m->l_qkv[b]; at.pos[b] = m->seqs[ids[b]].host_pos;
+        at.table[b] = m->seq_table + (size_t)ids[b] * m->max_splits;
+        at.part_o[b] = m->l_part_o[b]; at.part_ml[b] = m->l_part_ml[b]; at.cnt[b] = m->l_attn_cnt[b];
+        at.attn_out[b] = m->l_attn_out[b];
+        rt.route[b] = m->l_route[b]; rt.hbuf[b] = m->l_hbuf[b];
+    }
+    for (int l = 0; l < m->c.n_layers; ++l) {
+        const vh_mixtral_layer& w = m->L[l];
+        float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        VhDecBatchVec q{};
+        q.n = n;
+        for (int b = 0; b < n; ++b) { q.x_in[b] = xa[b]; q.delta[b] = l == 0 ? nullptr : dm[b]; q.x_out[b] = xb[b]; q.out[b] = m->l_qkv[b]; }
+        VH_TRY(vhk_decb_gemv(st, q, w.attn_norm, eps, w.wqkv, m->nqkv, H, 1), "batched qkv");
+        VH_TRY(vhk_decb_attn(st, at, n, kc, vc, m->rope_cos, m->rope_sin, nq, nkv, m->c.max_ctx, m->max_splits, scale), "batched attn");
+        VhDecBatchVec o{};
+        o.n = n;
+        for (int b = 0; b < n; ++b) { o.x_in[b] = m->l_attn_out[b]; o.out[b] = da[b]; }
+        VH_TRY(vhk_decb_gemv(st, o, nullptr, 0.f, w.wo, H, nq * hd, 0), "batched oproj");
+        for (int b = 0; b < n; ++b)
+            if (m->allreduce(da[b], H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        if (vh_tuning()->batch_moe != 0) {
+            // experimental: every DISTINCT routed expert streamed once for the group (measured SLOWER than one
+            // sequence after the other at B <= 4: 334 + 208 us vs 4 x (79 + 40))
+            VhDecBatchVec g{};
+            g.n = n;
+            for (int b = 0; b < n; ++b) { g.x_in[b] = xb[b]; g.delta[b] = da[b]; g.x_out[b] = xa[b]; }
+            VH_TRY(vhk_decb_gateup(st, g, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, rt), "batched gateup");
+            VhDecBatchOut ot{};
+            for (int b = 0; b < n; ++b) ot.out[b] = dm[b];
+            VH_TRY(vhk_decb_down(st, rt, n, w.w2, H, I, ot), "batched down");
+        } else {
+            for (int b = 0; b < n; ++b) {
+                VH_TRY(vhk_dec_gateup(st, xb[b], da[b], xa[b], w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->l_route[b],
+                                      m->l_hbuf[b], 0), "dec gateup");
+                VH_TRY(vhk_dec_down(st, m->l_hbuf[b], m->l_route[b], w.w2, H, I, dm[b]), "dec down");
+            }
+        }
+        for (int b = 0; b < n; ++b)
+            if (m->allreduce(dm[b], H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+    }
+    {
+        VhDecBatchVec hv{};
+        hv.n = n;
+        VhDecBatchHead hdp{};
+        for (int b = 0; b < n; ++b) {
+            hv.x_in[b] = xa[b]; hv.delta[b] = dm[b];
+            hdp.blk_val[b] = m->l_blk_val[b]; hdp.blk_idx[b] = m->l_blk_idx[b];
+        }
+        if (n >= 3) {
+            VH_TRY(vhk_decb_lmhead(st, hv, m->final_norm, eps, m->lm_head, m->Vn, H, hdp, m->lm_grid, m->v0), "batched lm_head");
+        } else {   // (the batched kernel always multiplies four activation rows: 204 us against 2 x 74)
+            for (int b = 0; b < n; ++b)
+                VH_TRY(vhk_dec_lmhead(st, xa[b], dm[b], m->final_norm, eps, m->lm_head, m->Vn, H, m->logits, m->l_blk_val[b],
+                                      m->l_blk_idx[b], m->lm_grid, cnt[b] + 1, 1, m->v0, m->V), "lm_head");
+        }
+        const bool sharded = m->c.vocab_n > 0 && m->c.tp_world > 1;
+        for (int b = 0; b < n; ++b) {
+            int nblk = m->lm_grid;
+            if (sharded) {
+                VH_TRY(vhk_dec_cand(st, m->l_blk_val[b], m->l_blk_idx[b], m->lm_grid, m->l_cand[b], m->c.tp_rank, m->c.tp_world), "candidates");
+                if (m->allreduce(m->l_cand[b], 2L * m->c.tp_world, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+                VH_TRY(vhk_dec_cand_unpack(st, m->l_cand[b], m->c.tp_world, m->l_blk_val[b], m->l_blk_idx[b]), "candidates");
+                nblk = m->c.tp_world;
+            }
+            VH_TRY(vhk_dec_select(st, m->l_blk_val[b], m->l_blk_idx[b], nblk, m->embed, H, m->V, xa[b], cnt[b], cnt[b] + 1,
+                                  m->seq_tokens + (size_t)ids[b] * (m->c.max_new > 0 ? m->c.max_new : 1), m->c.max_new, 1, 0), "select");
+        }
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VH_E_HIP, "batched decode: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
 int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) {
     if (!m || (!ids && n > 0)) return fail(VH_E_ARG, "vh_mixtral_seq_decode: null pointer");
     hipStream_t st = S(stream);
@@ -935,6 +1045,30 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         if (q.poisoned) return fail(VH_E_ARG, "sequence %d: a previous step failed; free it", ids[i]);
         if (q.host_pos < 1) return fail(VH_E_ARG, "sequence %d has no prompt yet", ids[i]);
         if (q.host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "sequence %d: context limit %d", ids[i], m->c.max_ctx);
+    }
+    // groups of up to VH_BMAX distinct sequences go through the batched kernels (a sequence listed twice in one call
+    // advances twice, one step after the other, as before)
+    if (n >= 2 && vh_tuning()->batch_decode != 0 && m->H <= 4096 && m->nq * m->hd <= 4096) {
+        bool distinct = true;
+        for (int i = 0; i < n && distinct; ++i)
+            for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) { distinct = false; break; }
+        if (distinct) {
+            for (int g0 = 0; g0 < n; g0 += VH_BMAX) {
+                const int gn = n - g0 < VH_BMAX ? n - g0 : VH_BMAX;
+                for (int i = 0; i < gn; ++i) {
+                    const int pr = m->ensure_pages(ids[g0 + i], m->seqs[ids[g0 + i]].host_pos + 1, st);
+                    if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", ids[g0 + i], g0);
+                    if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
+                }
+                const int rc = decode_batch_step(m, st, ids + g0, gn);
+                if (rc != VH_OK) {
+                    for (int i = 0; i < gn; ++i) m->seqs[ids[g0 + i]].poisoned = 1;
+                    return rc;
+                }
+                for (int i = 0; i < gn; ++i) m->seqs[ids[g0 + i]].host_pos += 1;
+            }
+            return VH_OK;
+        }
     }
     for (int i = 0; i < n; ++i) {
         const int s = ids[i];

@@ -60,6 +60,9 @@ __device__ __forceinline__ uint4 ld_weight16(const void* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+#ifndef VH_BLOCKSUM_TRANSPOSE
+#define VH_BLOCKSUM_TRANSPOSE 1
+#endif
 // ---- wave / block reductions ----------------------------------------------
 // Inside a row of 16 lanes the butterfly runs on DPP modifiers (quad_perm xor 1, xor 2, row_half_mirror, row_mirror):
 // VALU-rate, no LDS crossbar.  (__shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): ~100 cycles of exposed
@@ -101,16 +104,87 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- many values per thread: transposing wave reduction ------------------------------------------------------------
+// wave_sum costs 6 exchange steps PER VALUE.  With NV values per lane the butterfly can halve the value set at every
+// step instead: partners exchange the half they do not keep and add, so after the six steps lane L holds the wave total
+// of ONE value (index returned by multi_idx) — sum_k ceil(NV / 2^k) ~ NV exchanges in all instead of 6 NV.  Pairings:
+// row_mirror, row_half_mirror, quad_perm xor 2 / xor 1 (DPP, VALU rate), then lane ^ 16, lane ^ 32 (ds_bpermute).
+// The summation tree differs from wave_sum's, so kernels pick one or the other for all their values.
+template <int CTRL>
+__device__ __forceinline__ float multi_xchg_dpp(float send) { return dpp_mov<CTRL>(send); }
+__host__ __device__ constexpr int multi_bit(int step) { return step == 0 ? 3 : step == 1 ? 2 : step == 2 ? 1 : step == 3 ? 0 : step; }
+template <int N, int STEP>
+struct MultiReduce {
+    static constexpr int H = (N + 1) / 2;
+    __device__ static __forceinline__ float run(float (&v)[N], int lane) {
+        // Partners must hold the SAME value subset, i.e. agree in every lane bit consumed by the earlier steps, and differ
+        // in this step's bit: row_mirror (i <-> 15-i, decided by bit 3) first — everyone still holds everything —, then
+        // row_half_mirror (i <-> 7-i: same bit 3, decided by bit 2), quad xor 2 (bit 1), quad xor 1 (bit 0), lane ^ 16, ^ 32.
+        constexpr int BIT = multi_bit(STEP);
+        const bool upper = (lane >> BIT) & 1;
+        float nv[H];
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const float lo = v[i];
+            const float hi = (i + H < N) ? v[i + H] : 0.f;
+            const float keep = upper ? hi : lo;
+            const float send = upper ? lo : hi;
+            float recv;
+            if (STEP == 0) recv = multi_xchg_dpp<VH_DPP_MIRROR>(send);
+            else if (STEP == 1) recv = multi_xchg_dpp<VH_DPP_HALF_MIRROR>(send);
+            else if (STEP == 2) recv = multi_xchg_dpp<VH_DPP_XOR2>(send);
+            else if (STEP == 3) recv = multi_xchg_dpp<VH_DPP_XOR1>(send);
+            else recv = __shfl_xor(send, 1 << STEP, 64);
+            nv[i] = keep + recv;
+        }
+        if constexpr (STEP == 5) return nv[0];
+        else return MultiReduce<H, STEP + 1>::run(nv, lane);
+    }
+};
+// index of the value whose wave total lane `lane` holds after MultiReduce<NV, 0>::run (>= NV: padding, ignore)
+template <int NV>
+__device__ __forceinline__ int multi_idx(int lane) {
+    int idx = 0, n = NV, real = NV;             // n: (padded) array length at this step, real: entries that are not padding
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int h = (n + 1) / 2;
+        if ((lane >> multi_bit(k)) & 1) { idx += h; real = real > h ? real - h : 0; }
+        else real = real < h ? real : h;
+        n = h;
+    }
+    return real > 0 ? idx : NV;                 // NV = "holds padding"
+}
+// Block (256 threads = 4 waves) totals of NV <= 64 values per thread, left in LDS: tot[i] = sum over the block of v[i].
+// `red` needs 4 * NV floats, `tot` NV floats.  Every thread may read tot[] after the call.  Three barriers.
+template <int NV>
+__device__ __forceinline__ void block256_multi_sum(float (&v)[NV], float* red, float* tot) {
+    static_assert(NV >= 1 && NV <= 64, "one value per lane at the end");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float w = MultiReduce<NV, 0>::run(v, lane);
+    const int idx = multi_idx<NV>(lane);
+    if (idx < NV) red[wid * NV + idx] = w;
+    __syncthreads();
+    if ((int)threadIdx.x < NV) tot[threadIdx.x] = red[threadIdx.x] + red[NV + threadIdx.x] + red[2 * NV + threadIdx.x] + red[3 * NV + threadIdx.x];
+    __syncthreads();
+}
+
 // Sum NV values per thread over a 256-thread block (4 waves). `red` is LDS
 // scratch of >= 4*NV floats. Result broadcast to every thread. Two barriers.
 template <int NV>
 __device__ __forceinline__ void block256_sum(float (&v)[NV], float* red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#if VH_BLOCKSUM_TRANSPOSE
+    // wave level by the transposing butterfly (~NV exchanges instead of 6 NV), block level through LDS as before
+    const float w = MultiReduce<NV, 0>::run(v, lane);
+    const int idx = multi_idx<NV>(lane);
+    if (idx < NV) red[wid * NV + idx] = w;
+#else
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float s = wave_sum(v[i]);
         if (lane == 0) red[wid * NV + i] = s;
     }
+#endif
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = red[i] + red[NV + i] + red[2 * NV + i] + red[3 * NV + i];

@@ -702,6 +702,311 @@ __global__ void k_dec_cand_unpack(const float* __restrict__ cand, int world, flo
 }
 
 
+// ======================================================================================================================
+// Batched decode: ONE iteration of up to VH_BMAX concurrent sequences (continuous batching over the paged KV cache,
+// SURVEY 8(f)#1).  The weights are what a decode step streams (25.7 GB per token); a batch reads the attention-side
+// weights and the LM head ONCE for all its sequences and every expert once per iteration however many sequences routed
+// to it (expected 3.5 unique of 4 picks at B = 2, 5.5 of 8 at B = 4).  Per sequence the arithmetic is the batch-1
+// kernels' (same per-thread accumulation order, same block reduction), so a sequence's ids do not depend on its
+// neighbours.  Sequences are addressed through small by-value pointer tables; slots past `n` repeat the last sequence
+// (their results are never stored) so every load is unconditional.
+template <int NJ, int R, bool NORM>
+__global__ __launch_bounds__(256) void k_decb_gemv(const VhDecBatchVec bt, const float* __restrict__ norm_w, float eps,
+                                                   const uint16_t* __restrict__ W, int N, int K) {
+    constexpr int NV = VH_BMAX * (R + 1);
+    __shared__ float red[4 * NV];
+    __shared__ float tot[NV];
+    const int n0 = blockIdx.x * R;
+    const uint16_t* rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rows[r] = W + (size_t)min(n0 + r, N - 1) * K;
+    uint4 w[R][NJ];
+    gemv_issue<NJ, R>(rows, K, w);
+    float xr[VH_BMAX][NJ][8];
+    float vals[VH_BMAX * (R + 1)];
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b) {
+        const int bb = min(b, bt.n - 1);
+        if (NORM) vals[b * (R + 1) + R] = load_add_norm<NJ>(bt.x_in[bb], bt.delta[bb], norm_w, b < bt.n ? bt.x_out[bb] : nullptr, K, xr[b]);
+        else { load_x<NJ>(bt.x_in[bb], K, xr[b]); vals[b * (R + 1) + R] = 0.f; }
+    }
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b) {
+        float acc[R];
+        gemv_fma<NJ, R>(w, xr[b], acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) vals[b * (R + 1) + r] = acc[r];
+    }
+    block256_multi_sum<NV>(vals, red, tot);      // 20 values: transposing reduction (wave_sum per value: 6 x 20 exchanges)
+    if ((int)threadIdx.x < bt.n * R) {
+        const int b = threadIdx.x / R, r = threadIdx.x - b * R;
+        const float inv = NORM ? rsqrtf(tot[b * (R + 1) + R] / (float)K + eps) : 1.0f;
+        float* o = bt.out[0];
+#pragma unroll
+        for (int q = 1; q < VH_BMAX; ++q) if (b == q) o = bt.out[q];
+        if (n0 + r < N) o[n0 + r] = tot[b * (R + 1) + r] * inv;
+    }
+}
+
+// attention of the batch: grid (nkv, max splits of the batch, n); every sequence has its own position, page table
+// and partial / ticket buffers
+__global__ __launch_bounds__(256) void k_decb_attn(const VhDecBatchAttn bt, float* __restrict__ kcache,
+                                                   float* __restrict__ vcache, const float* __restrict__ rope_cos,
+                                                   const float* __restrict__ rope_sin, int nq, int nkv, int max_ctx,
+                                                   int max_splits, float scale) {
+    const int b = blockIdx.z;
+    const int nsplit = (bt.pos[b] + 1 + DA_KT - 1) / DA_KT;
+    if ((int)blockIdx.y >= nsplit) return;
+    dec_attn_block(blockIdx.x, blockIdx.y, nsplit, bt.qkv[b], kcache, vcache, bt.pos[b], bt.table[b], rope_cos, rope_sin,
+                   bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale);
+}
+
+// top-2 of 8 router probabilities (k_dec_gateup's rule: first maximum wins)
+__device__ __forceinline__ void route_top2(const float (&lg)[8], int E, int& e0, int& e1, float& w0, float& w1) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
+    float pr[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pr[e] = pr[e] / sum;
+    float b0 = -1.f, b1 = -1.f;
+    e0 = 0; e1 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
+    const float t = b0 + b1;
+    w0 = b0 / t; w1 = b1 / t;
+}
+// the distinct experts of a batch, 4 bits each (first-use order), and their count
+__device__ __forceinline__ void uniq_add(unsigned& packed, int& nu, int e) {
+    bool have = false;
+    for (int u = 0; u < nu; ++u) have |= (int)((packed >> (4 * u)) & 15u) == e;
+    if (!have) { packed |= (unsigned)e << (4 * nu); ++nu; }
+}
+
+// router (per sequence) + gate|up GEMV of every DISTINCT routed expert, each expert's rows streamed once and multiplied
+// against every sequence that picked it.  hbuf[b] = [slot 0 | slot 1][I] as in k_dec_gateup.
+template <int NJ, int RP>
+__global__ __launch_bounds__(256) void k_decb_gateup(const VhDecBatchVec bt, const float* __restrict__ norm_w, float eps,
+                                                     const uint16_t* __restrict__ Wg, int E,
+                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
+                                                     int I, int K, const VhDecBatchRoute rt) {
+    __shared__ float red[4 * VH_BMAX * 9];
+    float xr[VH_BMAX][NJ][8];
+    float inv[VH_BMAX];
+    int e0[VH_BMAX], e1[VH_BMAX];
+    {
+        const uint16_t* rrows[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rrows[e] = Wg + (size_t)min(e, E - 1) * K;
+        uint4 wr[8][NJ];
+        gemv_issue<NJ, 8>(rrows, K, wr);
+        float vals[VH_BMAX * 9];
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            const int bb = min(b, bt.n - 1);
+            vals[b * 9 + 8] = load_add_norm<NJ>(bt.x_in[bb], bt.delta[bb], norm_w, b < bt.n ? bt.x_out[bb] : nullptr, K, xr[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            float lg[8];
+            gemv_fma<NJ, 8>(wr, xr[b], lg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vals[b * 9 + e] = lg[e];
+        }
+        block256_sum<VH_BMAX * 9>(vals, red);
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            inv[b] = rsqrtf(vals[b * 9 + 8] / (float)K + eps);
+            float lg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lg[e] = vals[b * 9 + e] * inv[b];
+            float w0, w1;
+            route_top2(lg, E, e0[b], e1[b], w0, w1);
+            if (b < bt.n && blockIdx.x == 0 && threadIdx.x == 0) {
+                int* ro = rt.route[b];
+                ro[0] = e0[b]; ro[1] = e1[b]; ro[2] = __float_as_int(w0); ro[3] = __float_as_int(w1);
+            }
+        }
+    }
+    unsigned packed = 0;
+    int nu = 0;
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b)
+        if (b < bt.n) { uniq_add(packed, nu, e0[b]); uniq_add(packed, nu, e1[b]); }
+
+    const int per_exp = I / RP;
+    const int n_iter = nu * per_exp;
+    __shared__ float red2[4 * 2 * RP];
+    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const int u = it / per_exp;
+        const int i0 = (it - u * per_exp) * RP;
+        const int e = (int)((packed >> (4 * u)) & 15u);
+        const uint16_t* rows[2 * RP];
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            rows[r] = W1 + ((size_t)e * I + i0 + r) * K;
+            rows[RP + r] = W3 + ((size_t)e * I + i0 + r) * K;
+        }
+        uint4 w[2 * RP][NJ];
+        gemv_issue<NJ, 2 * RP>(rows, K, w);
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            if (b >= bt.n) break;
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                if ((slot ? e1[b] : e0[b]) != e) continue;              // block-uniform
+                float acc[2 * RP];
+                gemv_fma<NJ, 2 * RP>(w, xr[b], acc);
+                block256_sum<2 * RP>(acc, red2);
+                if (threadIdx.x < RP) {
+                    float g = 0.f, up = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RP; ++r) if (threadIdx.x == r) { g = acc[r]; up = acc[RP + r]; }
+                    rt.hbuf[b][(size_t)slot * I + i0 + threadIdx.x] = silu_f(g * inv[b]) * (up * inv[b]);
+                }
+            }
+        }
+    }
+}
+
+// down projection of the batch: rows [n0, n0 + R) of every distinct expert are streamed once, two experts in flight
+// (as k_dec_down holds both experts of its one sequence), and multiplied against every (sequence, slot) that picked it
+template <int NJ, int R>
+__global__ __launch_bounds__(256) void k_decb_down(const VhDecBatchRoute rt, int n, const uint16_t* __restrict__ W2, int N,
+                                                   int I, const VhDecBatchOut ot) {
+    __shared__ float red[4 * VH_BMAX * R];
+    int e0[VH_BMAX], e1[VH_BMAX];
+    float w0[VH_BMAX], w1[VH_BMAX];
+    unsigned packed = 0;
+    int nu = 0;
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b) {
+        const int* ro = rt.route[min(b, n - 1)];
+        e0[b] = ro[0]; e1[b] = ro[1]; w0[b] = __int_as_float(ro[2]); w1[b] = __int_as_float(ro[3]);
+        if (b < n) { uniq_add(packed, nu, e0[b]); uniq_add(packed, nu, e1[b]); }
+    }
+    const int n0 = blockIdx.x * R;
+    float tot[VH_BMAX * R];
+#pragma unroll
+    for (int i = 0; i < VH_BMAX * R; ++i) tot[i] = 0.f;
+    for (int u = 0; u < nu; u += 2) {
+        const int ea = (int)((packed >> (4 * u)) & 15u);
+        const bool two = u + 1 < nu;
+        const int eb = two ? (int)((packed >> (4 * (u + 1))) & 15u) : ea;
+        const uint16_t* rowsa[R];
+        const uint16_t* rowsb[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            rowsa[r] = W2 + ((size_t)ea * N + min(n0 + r, N - 1)) * I;
+            rowsb[r] = W2 + ((size_t)eb * N + min(n0 + r, N - 1)) * I;
+        }
+        uint4 wa[R][NJ], wb[R][NJ];
+        gemv_issue<NJ, R>(rowsa, I, wa);
+        gemv_issue<NJ, R>(rowsb, I, wb);
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            if (b >= n) break;
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int es = slot ? e1[b] : e0[b];
+                const float ws = slot ? w1[b] : w0[b];
+                const bool ua = es == ea, ub = two && es == eb;       // block-uniform
+                if (!ua && !ub) continue;
+                float xr[NJ][8];
+                load_x<NJ>(rt.hbuf[b] + (size_t)slot * I, I, xr);
+                float acc[R];
+                if (ua) gemv_fma<NJ, R>(wa, xr, acc); else gemv_fma<NJ, R>(wb, xr, acc);
+#pragma unroll
+                for (int r = 0; r < R; ++r) tot[b * R + r] = fmaf(ws, acc[r], tot[b * R + r]);
+            }
+        }
+    }
+    block256_sum<VH_BMAX * R>(tot, red);
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b) {
+        if (b >= n) break;
+        if (threadIdx.x < R && n0 + threadIdx.x < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = tot[b * R + r];
+            ot.out[b][n0 + threadIdx.x] = v;
+        }
+    }
+}
+
+// final RMSNorm + LM head + per-block argmax for every sequence of the batch (the 424 MB table is read once)
+template <int NJ>
+__global__ __launch_bounds__(256) void k_decb_lmhead(const VhDecBatchVec bt, const float* __restrict__ norm_w, float eps,
+                                                     const uint16_t* __restrict__ W, int V, int K, const VhDecBatchHead hd,
+                                                     int v0) {
+    constexpr int NV = VH_BMAX * (LM_R + 1);
+    __shared__ float red[4 * NV];
+    __shared__ float tot[NV];
+    __shared__ float bv_s[VH_BMAX][LM_R];
+    __shared__ int bi_s[VH_BMAX][LM_R];
+    const int n_iter = (V + LM_R - 1) / LM_R;
+    auto rows_of = [&](int it, const uint16_t* (&rows)[LM_R]) {
+#pragma unroll
+        for (int r = 0; r < LM_R; ++r) rows[r] = W + (size_t)min(it * LM_R + r, V - 1) * K;
+    };
+    int it = blockIdx.x;
+    uint4 wa[LM_R][NJ];
+    const uint16_t* rows[LM_R];
+    if (it < n_iter) { rows_of(it, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
+    float xr[VH_BMAX][NJ][8];
+    float ss[VH_BMAX], inv[VH_BMAX], best[VH_BMAX];
+    int besti[VH_BMAX];
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b) {
+        const int bb = min(b, bt.n - 1);
+        ss[b] = load_add_norm<NJ>(bt.x_in[bb], bt.delta[bb], norm_w, nullptr, K, xr[b]);
+        inv[b] = 0.f; best[b] = -INFINITY; besti[b] = 0x7fffffff;
+    }
+    bool first = true;
+    while (it < n_iter) {
+        float vals[VH_BMAX * (LM_R + 1)];
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            float acc[LM_R];
+            gemv_fma<NJ, LM_R>(wa, xr[b], acc);
+#pragma unroll
+            for (int r = 0; r < LM_R; ++r) vals[b * (LM_R + 1) + r] = acc[r];
+            vals[b * (LM_R + 1) + LM_R] = first ? ss[b] : 0.f;
+        }
+        const int nxt = it + gridDim.x;
+        if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
+        block256_multi_sum<NV>(vals, red, tot);
+        const int n0 = it * LM_R;
+#pragma unroll
+        for (int b = 0; b < VH_BMAX; ++b) {
+            if (first) inv[b] = rsqrtf(tot[b * (LM_R + 1) + LM_R] / (float)K + eps);
+            if (b < bt.n && threadIdx.x < LM_R && n0 + threadIdx.x < V) {
+                float v = tot[b * (LM_R + 1) + threadIdx.x];
+                v *= inv[b];
+                if (hd.logits[b]) hd.logits[b][v0 + n0 + threadIdx.x] = v;
+                if (v > best[b]) { best[b] = v; besti[b] = v0 + n0 + threadIdx.x; }
+            }
+        }
+        first = false;
+        it = nxt;
+    }
+#pragma unroll
+    for (int b = 0; b < VH_BMAX; ++b)
+        if (threadIdx.x < LM_R) { bv_s[b][threadIdx.x] = best[b]; bi_s[b][threadIdx.x] = besti[b]; }
+    __syncthreads();
+    if ((int)threadIdx.x < bt.n) {
+        const int b = threadIdx.x;
+        float bv = bv_s[b][0]; int bi = bi_s[b][0];
+        for (int r = 1; r < LM_R; ++r)
+            if (bv_s[b][r] > bv || (bv_s[b][r] == bv && bi_s[b][r] < bi)) { bv = bv_s[b][r]; bi = bi_s[b][r]; }
+        hd.blk_val[b][blockIdx.x] = bv; hd.blk_idx[b][blockIdx.x] = bi;
+    }
+}
+
 template <typename F>
 inline int pick_nj(int K, F&& f) {
     // chunk slots per thread: K <= NJ * 2048
@@ -842,4 +1147,62 @@ int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int
     hipLaunchKernelGGL(k_dec_select, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, embed, H, vocab, x_next, pos_ptr,
                        ngen_ptr, out_tokens, max_out, mode, set_pos);
     return 0;
+}
+
+// ---- batched decode launchers ---------------------------------------------------------------------------------------
+int vhk_decb_gemv(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int N, int K,
+                  int norm) {
+    if (bt.n < 1 || bt.n > VH_BMAX) return -1;
+    constexpr int R = 4;
+    return pick_nj(K, [&](auto nj) {
+        constexpr int NJ = decltype(nj)::value;
+        if (NJ > 2) return -1;                       // batch slices of the activation live in registers: K <= 4096
+        if (norm) hipLaunchKernelGGL((k_decb_gemv<(NJ > 2 ? 2 : NJ), R, true>), dim3((N + R - 1) / R), dim3(256), 0, st, bt, norm_w, eps, W, N, K);
+        else hipLaunchKernelGGL((k_decb_gemv<(NJ > 2 ? 2 : NJ), R, false>), dim3((N + R - 1) / R), dim3(256), 0, st, bt, norm_w, eps, W, N, K);
+        return 0;
+    });
+}
+int vhk_decb_attn(hipStream_t st, const VhDecBatchAttn& bt, int n, float* kcache, float* vcache, const float* rope_cos,
+                  const float* rope_sin, int nq, int nkv, int max_ctx, int max_splits, float scale) {
+    if (n < 1 || n > VH_BMAX || nq % nkv != 0 || nq / nkv > 4) return -1;
+    int ms = 1;
+    for (int b = 0; b < n; ++b) {
+        const int ns = (bt.pos[b] + 1 + DA_KT - 1) / DA_KT;
+        if (ns < 1 || ns > max_splits) return -1;
+        if (ns > ms) ms = ns;
+    }
+    hipLaunchKernelGGL(k_decb_attn, dim3(nkv, ms, n), dim3(256), 0, st, bt, kcache, vcache, rope_cos, rope_sin, nq, nkv,
+                       max_ctx, max_splits, scale);
+    return 0;
+}
+int vhk_decb_gateup(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* Wg, int E,
+                    const uint16_t* W1, const uint16_t* W3, int I, int K, const VhDecBatchRoute& rt) {
+    constexpr int RP = 4;
+    if (bt.n < 1 || bt.n > VH_BMAX || E > 8 || E < 2 || I % RP != 0) return -1;
+    int grid = vh_tuning()->gateup_grid;
+    if (grid <= 0) grid = 2 * vh_num_cus();
+    return pick_nj(K, [&](auto nj) {
+        constexpr int NJ = decltype(nj)::value;
+        if (NJ > 2) return -1;
+        hipLaunchKernelGGL((k_decb_gateup<(NJ > 2 ? 2 : NJ), RP>), dim3(grid), dim3(256), 0, st, bt, norm_w, eps, Wg, E, W1, W3, I, K, rt);
+        return 0;
+    });
+}
+int vhk_decb_down(hipStream_t st, const VhDecBatchRoute& rt, int n, const uint16_t* W2, int N, int I, const VhDecBatchOut& ot) {
+    constexpr int R = 2;
+    if (n < 1 || n > VH_BMAX) return -1;
+    return pick_nj(I, [&](auto nj) {
+        hipLaunchKernelGGL((k_decb_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, rt, n, W2, N, I, ot);
+        return 0;
+    });
+}
+int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int V, int K,
+                    const VhDecBatchHead& hd, int grid, int v0) {
+    if (bt.n < 1 || bt.n > VH_BMAX) return -1;
+    return pick_nj(K, [&](auto nj) {
+        constexpr int NJ = decltype(nj)::value;
+        if (NJ > 2) return -1;
+        hipLaunchKernelGGL((k_decb_lmhead<(NJ > 2 ? 2 : NJ)>), dim3(grid), dim3(256), 0, st, bt, norm_w, eps, W, V, K, hd, v0);
+        return 0;
+    });
 }

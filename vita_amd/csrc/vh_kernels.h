@@ -10,6 +10,8 @@ struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
     int gemv_rows = 4;        // rows per block of the decode QKV / O GEMVs: 4 (12.9 / 8.3 us), 8 (13.1 / 9.4), 16 (15.8 / 11.7)
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
+    int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
+    int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
     int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernel (16 rows per wave, no LDS tiles), 1 = LDS-tiled kernel
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
@@ -39,6 +41,29 @@ int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* v
                        float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
                        int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out,
                        const int* table);
+// ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
+#define VH_BMAX 4
+struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
+    int n;
+    const float* x_in[VH_BMAX]; const float* delta[VH_BMAX];   // delta: all null or all set
+    float* x_out[VH_BMAX];                                     // nullable: x_in + delta stored by block 0 (NORM kernels)
+    float* out[VH_BMAX];
+};
+struct VhDecBatchAttn {
+    const float* qkv[VH_BMAX]; int pos[VH_BMAX]; const int* table[VH_BMAX];
+    float* part_o[VH_BMAX]; float* part_ml[VH_BMAX]; int* cnt[VH_BMAX]; float* attn_out[VH_BMAX];
+};
+struct VhDecBatchRoute { int* route[VH_BMAX]; float* hbuf[VH_BMAX]; };
+struct VhDecBatchOut { float* out[VH_BMAX]; };
+struct VhDecBatchHead { float* logits[VH_BMAX]; float* blk_val[VH_BMAX]; int* blk_idx[VH_BMAX]; };   // logits[b]: nullable full-vocab row
+int vhk_decb_gemv(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int N, int K, int norm);
+int vhk_decb_attn(hipStream_t st, const VhDecBatchAttn& bt, int n, float* kcache, float* vcache, const float* rope_cos,
+                  const float* rope_sin, int nq, int nkv, int max_ctx, int max_splits, float scale);
+int vhk_decb_gateup(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* Wg, int E,
+                    const uint16_t* W1, const uint16_t* W3, int I, int K, const VhDecBatchRoute& rt);
+int vhk_decb_down(hipStream_t st, const VhDecBatchRoute& rt, int n, const uint16_t* W2, int N, int I, const VhDecBatchOut& ot);
+int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int V, int K,
+                    const VhDecBatchHead& hd, int grid, int v0);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid);
