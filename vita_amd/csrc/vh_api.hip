@@ -44,6 +44,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
     if (!strcmp(key, "gemv_rows")) { g_tuning.gemv_rows = value; return VH_OK; }
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "dec_prefetch")) { g_tuning.dec_prefetch = value; return VH_OK; }
     if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
@@ -847,7 +848,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
         if (fused != 0) {  // long contexts (grid not co-resident) or fusion disabled: two kernels
             VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
                                 m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
-                                scale, m->table), "dec attn");
+                                scale, m->table, w.wo, (size_t)H * nq * hd * 2), "dec attn");
             VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
         }
         if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");

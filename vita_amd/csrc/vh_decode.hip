@@ -322,14 +322,27 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     return true;
 }
 
+// Blocks with blockIdx.y >= nsplit are PREFETCHERS: attention is a latency chain on nkv x nsplit blocks (8.7 us, HBM
+// idle, ~170 CUs without work), so the rest of the launch can pull the O-projection weights, which the next kernel
+// streams, through the memory-side cache (plain loads, results discarded).  Experiment, OFF by default: the launch gets
+// longer than the O-projection gets shorter (211.5 -> 198 tok/s).
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
                                                   float* __restrict__ vcache, const int pos, const int* __restrict__ table,
+                                                  const int nsplit_attn, const u32x4* __restrict__ pf, const long pf_n,
                                                   const float* __restrict__ rope_cos,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
                                                   int max_splits, float scale) {
-    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
+    if ((int)blockIdx.y >= nsplit_attn) {
+        const long nthreads = (long)(gridDim.y - nsplit_attn) * gridDim.x * 256;
+        long i = ((long)(blockIdx.y - nsplit_attn) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        u32x4 acc = u32x4{0u, 0u, 0u, 0u};
+        for (; i < pf_n; i += nthreads) acc |= pf[i];
+        asm volatile("" ::"v"(acc));          // keep the loads
+        return;
+    }
+    dec_attn_block(blockIdx.x, blockIdx.y, nsplit_attn, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
                    part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
 }
 
@@ -1032,7 +1045,7 @@ static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta
 
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                 const uint16_t* W, int N, int K, float* out) {
-    const int r = vh_tuning()->gemv_rows;   // rows per block: 4 (default), 8 or 16 (vh_tune)
+    const int r = vh_tuning()->gemv_rows;   // rows per block: 8 (default), 4 or 16 (vh_tune)
     if (r == 8) return launch_dec_gemv<8, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
     if (r == 16 && K <= 4096) return launch_dec_gemv<16, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
     return launch_dec_gemv<4, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
@@ -1041,12 +1054,18 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table) {
+                 const int* table, const void* prefetch, size_t prefetch_bytes) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits) return -1;
-    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
+    int extra = 0;
+    if (prefetch && prefetch_bytes >= (1u << 20) && vh_tuning()->dec_prefetch > 0) {
+        extra = (vh_tuning()->dec_prefetch * vh_num_cus() + nkv - 1) / nkv;     // dec_prefetch prefetching blocks per CU
+        if (nsplit + extra > 65535) extra = 65535 - nsplit;
+    }
+    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit + extra), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, nsplit,
+                       reinterpret_cast<const u32x4*>(prefetch), (long)(extra ? prefetch_bytes / 16 : 0), rope_cos,
                        rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
     return 0;
 }
@@ -1095,9 +1114,10 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
     if (E > 8 || E < 2 || I % rp != 0) return -1;
     const int n_iter = 2 * (I / rp);
     if (grid <= 0) grid = vh_tuning()->gateup_grid;
-    // two persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so
-    // fewer, longer-lived blocks win — measured 79 us at 512 blocks vs 83 at 1024 and 82 at 1280
-    if (grid <= 0) grid = 2 * vh_num_cus();
+    // 1.5 persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so fewer, longer-lived
+    // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
+    // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
+    if (grid <= 0) grid = 3 * vh_num_cus() / 2;
     if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;

@@ -8,8 +8,11 @@
 // ---- run-time tuning knobs (set through vh_tune(); defaults are the measured-best variants) ---
 struct VhTuning {
     int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
-    int gemv_rows = 4;        // rows per block of the decode QKV / O GEMVs: 4 (12.9 / 8.3 us), 8 (13.1 / 9.4), 16 (15.8 / 11.7)
-    int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 2 blocks per CU)
+    int gemv_rows = 8;        // rows per block of the decode QKV / O GEMVs (r01: 4 won: 12.9 / 8.3 us vs 13.1 / 9.4 at 8; r02 with the
+                              // transposing block reduction 8 is ahead by 0.5 % of a token, 16 behind by 1 %)
+    int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 1.5 blocks per CU)
+    int dec_prefetch = 0;      // decode attention launch: n prefetching blocks per CU pull the O-projection weights through the memory-side
+                               // cache while attention runs (measured: 211.5 -> 198 tok/s at 1, 199 at 2, 202 at 4: off)
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
     int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernel (16 rows per wave, no LDS tiles), 1 = LDS-tiled kernel
@@ -34,7 +37,8 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table);   // table: nullable page table of a paged KV cache (64-token pages)
+                 const int* table,    // table: nullable page table of a paged KV cache (64-token pages)
+                 const void* prefetch, size_t prefetch_bytes);   // nullable: weights of the NEXT kernel, pulled through the memory-side cache by idle CUs
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out);
 int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                        const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
