@@ -47,6 +47,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "dec_prefetch")) { g_tuning.dec_prefetch = value; return VH_OK; }
     if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
+    if (!strcmp(key, "attn_wpe")) { g_tuning.attn_wpe = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
@@ -1011,9 +1012,9 @@ static int decode_batch_step(vh_mixtral* m, hipStream_t st, const int* ids, int 
             hv.x_in[b] = xa[b]; hv.delta[b] = dm[b];
             hdp.blk_val[b] = m->l_blk_val[b]; hdp.blk_idx[b] = m->l_blk_idx[b];
         }
-        if (n >= 3) {
+        if (n >= 2) {   // one pass over the table for the group: 97 us (four activation rows, always) against n x 74
             VH_TRY(vhk_decb_lmhead(st, hv, m->final_norm, eps, m->lm_head, m->Vn, H, hdp, m->lm_grid, m->v0), "batched lm_head");
-        } else {   // (the batched kernel always multiplies four activation rows: 204 us against 2 x 74)
+        } else {
             for (int b = 0; b < n; ++b)
                 VH_TRY(vhk_dec_lmhead(st, xa[b], dm[b], m->final_norm, eps, m->lm_head, m->Vn, H, m->logits, m->l_blk_val[b],
                                       m->l_blk_idx[b], m->lm_grid, cnt[b] + 1, 1, m->v0, m->V), "lm_head");

@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256 * KS) void k_attn(const VhAttnArgs p) {
 // phase to land.  KS waves of a block deal the key tiles among themselves (tile t -> wave t % KS) and merge (m, l, O) once
 // at the end — the only block barrier.  Waves never wait for each other, so occupancy is whatever the registers allow
 // and the launch is 16-row tiles x heads blocks (ViT: 1040) instead of 272 four-wave blocks marching through barriers.
-template <int D, bool REL, int KS>
-__global__ __launch_bounds__(64 * KS) void k_attn_direct(const VhAttnArgs p) {
+template <int D, bool REL, int KS, int WPE>
+__global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_attn_direct(const VhAttnArgs p) {
     constexpr int NC = D / 16;          // 16-wide chunks of d = K float4s per key row per lane-group = accumulators
     constexpr int VQ = NC / 4;          // float4s of V per lane per key
     constexpr int MGW = 8 + NC * 4;
@@ -462,11 +462,22 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
         if (kl <= AT_KT) ks = 1;
         else if (kl <= 2 * AT_KT && ks > 2) ks = 2;
         if (a.d == 128) ks = ks >= 2 ? 2 : 1;
-#define AT_LAUNCH(DD, RR, KK) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK>), g16, dim3(64 * KK), 0, st, a)
-        if (a.d == 64 && !rel) { if (ks == 1) AT_LAUNCH(64, false, 1); else if (ks == 2) AT_LAUNCH(64, false, 2); else AT_LAUNCH(64, false, 4); }
+        // waves per SIMD the register allocation aims at: 3 for the plain d = 64 kernel (<= 168 VGPRs: 768 resident 4-wave
+        // blocks for the ViT's 1040 instead of 512), 2 elsewhere (rel-pos and d = 128 need > 200 registers)
+#define AT_LAUNCH(DD, RR, KK) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, 2>), g16, dim3(64 * KK), 0, st, a)
+#define AT_LAUNCH_W(DD, RR, KK, WW) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, WW>), g16, dim3(64 * KK), 0, st, a)
+        const int wpe = vh_tuning()->attn_wpe;
+        if (a.d == 64 && !rel) {
+            if (ks == 1) AT_LAUNCH(64, false, 1);
+            else if (ks == 2) AT_LAUNCH(64, false, 2);
+            else if (wpe == 2) AT_LAUNCH_W(64, false, 4, 2);
+            else if (wpe == 4) AT_LAUNCH_W(64, false, 4, 4);
+            else AT_LAUNCH_W(64, false, 4, 3);
+        }
         else if (a.d == 64) { if (ks == 1) AT_LAUNCH(64, true, 1); else if (ks == 2) AT_LAUNCH(64, true, 2); else AT_LAUNCH(64, true, 4); }
         else { if (ks == 1) AT_LAUNCH(128, false, 1); else AT_LAUNCH(128, false, 2); }
 #undef AT_LAUNCH
+#undef AT_LAUNCH_W
         return 0;
     }
     const dim3 grid((a.Sq + 63) / 64, a.Hq, a.B);

@@ -15,6 +15,7 @@ struct VhTuning {
                                // cache while attention runs (measured: 211.5 -> 198 tok/s at 1, 199 at 2, 202 at 4: off)
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
+    int attn_wpe = 3;          // plain d = 64 attention (ViT): waves per SIMD the register allocation aims at (2: 182 VGPRs, 3: 145, 4: 128 + spills)
     int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernel (16 rows per wave, no LDS tiles), 1 = LDS-tiled kernel
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
