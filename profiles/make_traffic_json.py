@@ -12,8 +12,8 @@ alg = {   # algorithmic bytes per launch, released geometr
     "k_dec_gateup": ("k_dec_gateup", 2 * 2 * I * H * 2 + E * H * 2),
     "k_dec_down": ("k_dec_down", 2 * H * I * 2),
     "k_dec_lmhead": ("k_dec_lmhead", V * H * 2),
-    "k_dec_gemv_qkv": ("k_dec_gemv<2, 4, true>", NQKV * H * 2),
-    "k_dec_gemv_oproj": ("k_dec_gemv<2, 4, false>", H * H * 2),
+    "k_dec_gemv_qkv": ("k_dec_gemv<2, 8, true>", NQKV * H * 2),
+    "k_dec_gemv_oproj": ("k_dec_gemv<2, 8, false>", H * H * 2),
     "k_gemm_ps_moe_gateup (prefill S=552)": ("k_gemm_ps<true", E * 2 * I * H * 2),
 }
 rows = {}

@@ -12,7 +12,7 @@ tail -c 600 $O/r02_bench_tp1.json
 rm -rf /tmp/kt; (cd $R && timeout 300 rocprofv3 --kernel-trace -d /tmp/kt -o r -- python bench.py --no-cpu-baseline > $O/kt_bench.json 2> $O/kt.err)
 db=$(find /tmp/kt -name '*.db' | head -1)
 python $R/profiles/summarize.py $db 'k_dec_' > $O/r02_kernel_stats_decode.txt
-python $R/profiles/summarize.py $db 'anonymous namespace' 'k_dec_' > $O/r02_kernel_stats_prefill_encoders.txt
+python $R/profiles/summarize.py $db 'anonymous namespace' 'k_dec|k_fill_hash' > $O/r02_kernel_stats_prefill_encoders.txt
 python $R/profiles/layer_trace.py $db k_moe_sort > $O/r02_prefill_layer_trace.txt
 python $R/profiles/layer_trace.py $db k_vit_patchify 3 k_embed_splice > $O/r02_encoder_pass_trace.txt
 for ctr in FETCH_SIZE WRITE_SIZE; do
