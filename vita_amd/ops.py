@@ -99,7 +99,8 @@ def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=No
     g.M, g.N, g.K, g.act = M, N, K, ACT[act]
     g.ksplit = int(ksplit)
     if ksplit != 1 and group_off is None and w_up is None and c_rowidx is None and M * N <= (8 << 20):
-        ws = _scratch(a.device, 8 * 4 * M * N)
+        # room for up to 8 partial-sum slabs, capped at 96 MB (the library lowers the split to what fits)
+        ws = _scratch(a.device, min(8 * 4 * M * N, 96 << 20))
         g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     check(lib.vh_gemm(C.byref(g), _stream()), "vh_gemm")
     return out
