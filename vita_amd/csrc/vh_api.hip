@@ -44,6 +44,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
     if (!strcmp(key, "gemv_rows")) { g_tuning.gemv_rows = value; return VH_OK; }
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "down_grid")) { g_tuning.down_grid = value; return VH_OK; }
     if (!strcmp(key, "dec_prefetch")) { g_tuning.dec_prefetch = value; return VH_OK; }
     if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }

@@ -573,6 +573,59 @@ __global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf
     }
 }
 
+// Persistent form of K_E: a block keeps BOTH intermediate vectors (2 x I floats) in registers and walks row pairs
+// n0, n0 + grid*R, ...: the 2 x 57 KB of activations are read from L2 once per block instead of once per row pair
+// (2048 one-shot blocks re-read 233 MB per launch), and the weight loads of the next pair are issued before the current
+// pair is reduced.
+template <int NJ, int R>
+__global__ __launch_bounds__(256) void k_dec_down_p(const float* __restrict__ hbuf, const int* __restrict__ route,
+                                                    const uint16_t* __restrict__ W2, int N, int I,
+                                                    float* __restrict__ out) {
+    __shared__ float red[4 * R];
+    const int e0 = route[0], e1 = route[1];
+    const float w0 = __int_as_float(route[2]), w1 = __int_as_float(route[3]);
+    auto rows_of = [&](int n0, const uint16_t* (&ra)[R], const uint16_t* (&rb)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ra[r] = W2 + ((size_t)e0 * N + min(n0 + r, N - 1)) * I;
+            rb[r] = W2 + ((size_t)e1 * N + min(n0 + r, N - 1)) * I;
+        }
+    };
+    int n0 = blockIdx.x * R;
+    if (n0 >= N) return;
+    const uint16_t* ra[R];
+    const uint16_t* rb[R];
+    uint4 wa[R][NJ], wb[R][NJ];
+    rows_of(n0, ra, rb);
+    gemv_issue<NJ, R>(ra, I, wa);
+    gemv_issue<NJ, R>(rb, I, wb);
+    float xa[NJ][8], xb[NJ][8];
+    load_x<NJ>(hbuf, I, xa);
+    load_x<NJ>(hbuf + (size_t)I, I, xb);
+    while (true) {
+        float acc0[R], acc1[R], tot[R];
+        gemv_fma<NJ, R>(wa, xa, acc0);
+        gemv_fma<NJ, R>(wb, xb, acc1);
+        const int nxt = n0 + gridDim.x * R;
+        if (nxt < N) {                                   // block-uniform; the loads fly during the reduction below
+            rows_of(nxt, ra, rb);
+            gemv_issue<NJ, R>(ra, I, wa);
+            gemv_issue<NJ, R>(rb, I, wb);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) tot[r] = fmaf(w1, acc1[r], w0 * acc0[r]);
+        block256_sum<R>(tot, red);
+        if (threadIdx.x < R && n0 + threadIdx.x < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = tot[r];
+            out[n0 + threadIdx.x] = v;
+        }
+        if (nxt >= N) break;
+        n0 = nxt;
+    }
+}
+
 // ---- K_F: final RMSNorm + LM head GEMV + per-block argmax ---------------------------
 #define LM_R 8
 template <int NJ>
@@ -1136,6 +1189,13 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
 
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out) {
     constexpr int R = 2;
+    const int pg = vh_tuning()->down_grid;             // > 0: persistent blocks per launch (0 = one block per row pair)
+    if (pg > 0)
+        return pick_nj(I, [&](auto nj) {
+            int grid = pg < (N + R - 1) / R ? pg : (N + R - 1) / R;
+            hipLaunchKernelGGL((k_dec_down_p<decltype(nj)::value, R>), dim3(grid), dim3(256), 0, st, hbuf, route, W2, N, I, out);
+            return 0;
+        });
     return pick_nj(I, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
                            W2, N, I, out);

@@ -11,6 +11,8 @@ struct VhTuning {
     int gemv_rows = 8;        // rows per block of the decode QKV / O GEMVs (r01: 4 won: 12.9 / 8.3 us vs 13.1 / 9.4 at 8; r02 with the
                               // transposing block reduction 8 is ahead by 0.5 % of a token, 16 behind by 1 %)
     int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 1.5 blocks per CU)
+    int down_grid = 0;         // decode down projection: > 0 = that many persistent blocks keeping the activations in registers (measured
+                               // slower: 204-209 vs 211.5 tok/s), 0 = one block per row pair
     int dec_prefetch = 0;      // decode attention launch: n prefetching blocks per CU pull the O-projection weights through the memory-side
                                // cache while attention runs (measured: 211.5 -> 198 tok/s at 1, 199 at 2, 202 at 4: off)
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
