@@ -46,6 +46,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
     if (!strcmp(key, "down_grid")) { g_tuning.down_grid = value; return VH_OK; }
     if (!strcmp(key, "dec_prefetch")) { g_tuning.dec_prefetch = value; return VH_OK; }
+    if (!strcmp(key, "batch_moe_min")) { g_tuning.batch_moe_min = value; return VH_OK; }
     if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
     if (!strcmp(key, "attn_wpe")) { g_tuning.attn_wpe = value; return VH_OK; }
@@ -233,7 +234,7 @@ struct vh_mixtral {
     std::vector<Seq> seqs;
     std::vector<int> free_pages;
     float* seq_x = nullptr;            // [max_seqs][4][H]: xa, xb, delta_attn, delta_moe
-    int *seq_counters = nullptr, *seq_tokens = nullptr, *seq_table = nullptr;
+    int *seq_counters = nullptr, *seq_tokens = nullptr, *seq_table = nullptr, *seq_batch = nullptr;
     // scratch "lanes" 1..VH_BMAX-1 of the per-step buffers (lane 0 = the single-sequence ones) for batched decode iterations
     float *l_qkv[VH_BMAX] = {}, *l_part_o[VH_BMAX] = {}, *l_part_ml[VH_BMAX] = {}, *l_attn_out[VH_BMAX] = {}, *l_hbuf[VH_BMAX] = {},
           *l_blk_val[VH_BMAX] = {}, *l_cand[VH_BMAX] = {};
@@ -331,6 +332,7 @@ struct vh_mixtral {
             seq_counters = cv.take<int>(n * 4);
             seq_tokens = cv.take<int>(n * (c.max_new > 0 ? c.max_new : 1));
             seq_table = cv.take<int>(n * max_splits);
+            seq_batch = cv.take<int>(n);
             l_qkv[0] = qkv; l_part_o[0] = part_o; l_part_ml[0] = part_ml; l_attn_out[0] = attn_out; l_attn_cnt[0] = attn_cnt;
             l_hbuf[0] = hbuf; l_route[0] = route; l_blk_val[0] = blk_val; l_blk_idx[0] = blk_idx; l_cand[0] = cand;
             for (int b = 1; b < VH_BMAX; ++b) {
@@ -948,80 +950,133 @@ int vh_mixtral_seq_prefill(vh_mixtral_t* m, int s, const float* embeds, int Sn, 
     return rc;
 }
 
-// One decode step of up to VH_BMAX sequences with the batched kernels (weights of the attention side, the LM head and
-// every DISTINCT routed expert are streamed once for the whole group).  Sequence state is addressed in place (slots).
-static int decode_batch_step(vh_mixtral* m, hipStream_t st, const int* ids, int n) {
+// One decode ITERATION of n concurrent sequences (n <= max_seqs, all distinct).  The attention side (fused QKV GEMV,
+// split-KV attention, O projection) and the LM head run in groups of up to VH_BMAX sequences per launch (one pass over
+// the shared weights per group).  The MoE of a layer runs
+//   n >= batch_moe_min (default 4): ONCE for the whole iteration on the prefill's weight-streaming GEMM with S = n — rows
+//       sorted by expert, every TOUCHED expert streamed exactly once at ~5 TB/s however many sequences picked it
+//       (k_gemm_ps cfg 0, <= 64 rows per tile, SURVEY 8(f)#1: "continuous batching");
+//   otherwise per sequence with the batch-1 GEMV kernels (de-duplicating GEMV variant behind batch_moe).
+// Sequence state is addressed in place (slots); the MoE delta of a sequence is a row of the shared `ptmp` buffer.
+static int decode_iteration(vh_mixtral* m, hipStream_t st, const int* ids, int n) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
-    float *xa[VH_BMAX], *xb[VH_BMAX], *da[VH_BMAX], *dm[VH_BMAX];
-    int* cnt[VH_BMAX];
+    const bool tp = m->c.tp_world > 1 || vh_tuning()->force_allreduce;
+    std::vector<float*> xa(n), xb(n), da(n), dm(n);
+    std::vector<int*> cnt(n);
     for (int b = 0; b < n; ++b) {
         float* x = m->seq_x + (size_t)ids[b] * 4 * H;
         xa[b] = x; xb[b] = x + H; da[b] = x + 2 * H; dm[b] = x + 3 * H;
         cnt[b] = m->seq_counters + 4 * ids[b];
     }
-    VhDecBatchAttn at{};
-    VhDecBatchRoute rt{};
-    for (int b = 0; b < n; ++b) {
-        at.qkv[b] = m->l_qkv[b]; at.pos[b] = m->seqs[ids[b]].host_pos;
-        at.table[b] = m->seq_table + (size_t)ids[b] * m->max_splits;
-        at.part_o[b] = m->l_part_o[b]; at.part_ml[b] = m->l_part_ml[b]; at.cnt[b] = m->l_attn_cnt[b];
-        at.attn_out[b] = m->l_attn_out[b];
-        rt.route[b] = m->l_route[b]; rt.hbuf[b] = m->l_hbuf[b];
+    const int moe_min = vh_tuning()->batch_moe_min;
+    const bool stream_moe = moe_min > 0 && n >= moe_min && n <= m->c.max_prefill && H <= 4096 && (H % 64) == 0 && (I % 64) == 0;
+    if (stream_moe) {
+        if (hipMemcpyAsync(m->seq_batch, ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(VH_E_HIP, "batch id upload failed");
+        for (int b = 0; b < n; ++b) dm[b] = m->ptmp + (size_t)b * H;       // MoE delta rows of this iteration
     }
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
-        VhDecBatchVec q{};
-        q.n = n;
-        for (int b = 0; b < n; ++b) { q.x_in[b] = xa[b]; q.delta[b] = l == 0 ? nullptr : dm[b]; q.x_out[b] = xb[b]; q.out[b] = m->l_qkv[b]; }
-        VH_TRY(vhk_decb_gemv(st, q, w.attn_norm, eps, w.wqkv, m->nqkv, H, 1), "batched qkv");
-        VH_TRY(vhk_decb_attn(st, at, n, kc, vc, m->rope_cos, m->rope_sin, nq, nkv, m->c.max_ctx, m->max_splits, scale), "batched attn");
-        VhDecBatchVec o{};
-        o.n = n;
-        for (int b = 0; b < n; ++b) { o.x_in[b] = m->l_attn_out[b]; o.out[b] = da[b]; }
-        VH_TRY(vhk_decb_gemv(st, o, nullptr, 0.f, w.wo, H, nq * hd, 0), "batched oproj");
+        for (int g0 = 0; g0 < n; g0 += VH_BMAX) {
+            const int gn = n - g0 < VH_BMAX ? n - g0 : VH_BMAX;
+            VhDecBatchVec q{};
+            VhDecBatchAttn at{};
+            VhDecBatchVec o{};
+            q.n = gn; o.n = gn;
+            for (int b = 0; b < gn; ++b) {
+                const int sb = g0 + b;
+                q.x_in[b] = xa[sb]; q.delta[b] = l == 0 ? nullptr : dm[sb]; q.x_out[b] = xb[sb]; q.out[b] = m->l_qkv[b];
+                at.qkv[b] = m->l_qkv[b]; at.pos[b] = m->seqs[ids[sb]].host_pos;
+                at.table[b] = m->seq_table + (size_t)ids[sb] * m->max_splits;
+                at.part_o[b] = m->l_part_o[b]; at.part_ml[b] = m->l_part_ml[b]; at.cnt[b] = m->l_attn_cnt[b];
+                at.attn_out[b] = m->l_attn_out[b];
+                o.x_in[b] = m->l_attn_out[b]; o.out[b] = da[sb];
+            }
+            VH_TRY(vhk_decb_gemv(st, q, w.attn_norm, eps, w.wqkv, m->nqkv, H, 1), "batched qkv");
+            VH_TRY(vhk_decb_attn(st, at, gn, kc, vc, m->rope_cos, m->rope_sin, nq, nkv, m->c.max_ctx, m->max_splits, scale), "batched attn");
+            VH_TRY(vhk_decb_gemv(st, o, nullptr, 0.f, w.wo, H, nq * hd, 0), "batched oproj");
+        }
         for (int b = 0; b < n; ++b)
             if (m->allreduce(da[b], H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
-        if (vh_tuning()->batch_moe != 0) {
-            // experimental: every DISTINCT routed expert streamed once for the group (measured SLOWER than one
-            // sequence after the other at B <= 4: 334 + 208 us vs 4 x (79 + 40))
-            VhDecBatchVec g{};
-            g.n = n;
-            for (int b = 0; b < n; ++b) { g.x_in[b] = xb[b]; g.delta[b] = da[b]; g.x_out[b] = xa[b]; }
-            VH_TRY(vhk_decb_gateup(st, g, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, rt), "batched gateup");
-            VhDecBatchOut ot{};
-            for (int b = 0; b < n; ++b) ot.out[b] = dm[b];
-            VH_TRY(vhk_decb_down(st, rt, n, w.w2, H, I, ot), "batched down");
+        if (stream_moe) {
+            // x = xb + delta_attn for every sequence -> rows of px (and each sequence's xa, as the GEMV path's x_out)
+            VH_TRY(vhk_gather_rows(st, m->seq_x, m->seq_batch, n, H, m->px), "gather");
+            VH_TRY(vhk_rmsnorm_route(st, m->px, nullptr, m->pxn_hi, m->pxn_lo, w.ffn_norm, n, H, eps, w.wrouter, E, m->pids,
+                                     m->pwts), "rmsnorm + route");
+            VH_TRY(vhk_moe_sort(st, m->pids, n, E, m->pgoff, m->pstok, m->psslot), "sort");
+            VhGemmPsArgs g{};
+            g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; g.lda = H; g.a_rowidx = m->pstok;
+            g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
+            g.group_off = m->pgoff; g.ngroups = E;
+            g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * n; g.N = I; g.K = H; g.ksplit = 1;
+            VH_TRY(vhk_gemm_ps(st, g), "gate/up gemm");
+            int nslab = vh_tuning()->moe_ksplit;
+            if (nslab == 0) nslab = 1;
+            if (nslab > 4) nslab = 4;
+            if (nslab < -4) nslab = -4;
+            if (nslab > (I >> 6)) nslab = 1;
+            const long slab = (long)2 * m->c.max_prefill * H;
+            VhGemmPsArgs d{};
+            d.A_hi = m->ph_hi; d.A_lo = m->ph_lo; d.lda = I;
+            d.W = w.w2; d.ldw = I; d.w_group_stride = (long)H * I;
+            d.group_off = m->pgoff; d.ngroups = E;
+            d.C = m->py; d.ldc = H; d.c_rowidx = m->psslot; d.M = 2 * n; d.N = H; d.K = I;
+            d.ksplit = nslab; d.c_split_stride = slab; d.nslab_out = m->pnslab;
+            VH_TRY(vhk_gemm_ps(st, d), "down gemm");
+            if (hipMemsetAsync(m->ptmp, 0, (size_t)n * H * sizeof(float), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
+            VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, n, H, nslab < 0 ? 1 : nslab, slab, nslab < 0 ? m->pnslab : nullptr), "combine");
+            if (tp && m->allreduce(m->ptmp, (long)n * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         } else {
-            for (int b = 0; b < n; ++b) {
-                VH_TRY(vhk_dec_gateup(st, xb[b], da[b], xa[b], w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->l_route[b],
-                                      m->l_hbuf[b], 0), "dec gateup");
-                VH_TRY(vhk_dec_down(st, m->l_hbuf[b], m->l_route[b], w.w2, H, I, dm[b]), "dec down");
+            for (int g0 = 0; g0 < n; g0 += VH_BMAX) {
+                const int gn = n - g0 < VH_BMAX ? n - g0 : VH_BMAX;
+                if (vh_tuning()->batch_moe != 0) {
+                    // experimental: every DISTINCT routed expert of the group streamed once through the GEMV kernels
+                    // (measured SLOWER than one sequence after the other at B <= 4: 334 + 208 us vs 4 x (79 + 40))
+                    VhDecBatchVec g{};
+                    VhDecBatchRoute rt{};
+                    VhDecBatchOut ot{};
+                    g.n = gn;
+                    for (int b = 0; b < gn; ++b) {
+                        g.x_in[b] = xb[g0 + b]; g.delta[b] = da[g0 + b]; g.x_out[b] = xa[g0 + b];
+                        rt.route[b] = m->l_route[b]; rt.hbuf[b] = m->l_hbuf[b];
+                        ot.out[b] = dm[g0 + b];
+                    }
+                    VH_TRY(vhk_decb_gateup(st, g, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, rt), "batched gateup");
+                    VH_TRY(vhk_decb_down(st, rt, gn, w.w2, H, I, ot), "batched down");
+                } else {
+                    for (int b = 0; b < gn; ++b) {
+                        VH_TRY(vhk_dec_gateup(st, xb[g0 + b], da[g0 + b], xa[g0 + b], w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
+                                              m->l_route[b], m->l_hbuf[b], 0), "dec gateup");
+                        VH_TRY(vhk_dec_down(st, m->l_hbuf[b], m->l_route[b], w.w2, H, I, dm[g0 + b]), "dec down");
+                    }
+                }
             }
+            for (int b = 0; b < n; ++b)
+                if (m->allreduce(dm[b], H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         }
-        for (int b = 0; b < n; ++b)
-            if (m->allreduce(dm[b], H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
     }
-    {
+    const bool sharded = m->c.vocab_n > 0 && m->c.tp_world > 1;
+    for (int g0 = 0; g0 < n; g0 += VH_BMAX) {
+        const int gn = n - g0 < VH_BMAX ? n - g0 : VH_BMAX;
         VhDecBatchVec hv{};
-        hv.n = n;
         VhDecBatchHead hdp{};
-        for (int b = 0; b < n; ++b) {
-            hv.x_in[b] = xa[b]; hv.delta[b] = dm[b];
+        hv.n = gn;
+        for (int b = 0; b < gn; ++b) {
+            hv.x_in[b] = xa[g0 + b]; hv.delta[b] = dm[g0 + b];
             hdp.blk_val[b] = m->l_blk_val[b]; hdp.blk_idx[b] = m->l_blk_idx[b];
         }
-        if (n >= 2) {   // one pass over the table for the group: 97 us (four activation rows, always) against n x 74
+        if (gn >= 2) {   // one pass over the table for the group: 97 us (four activation rows, always) against n x 70
             VH_TRY(vhk_decb_lmhead(st, hv, m->final_norm, eps, m->lm_head, m->Vn, H, hdp, m->lm_grid, m->v0), "batched lm_head");
         } else {
-            for (int b = 0; b < n; ++b)
-                VH_TRY(vhk_dec_lmhead(st, xa[b], dm[b], m->final_norm, eps, m->lm_head, m->Vn, H, m->logits, m->l_blk_val[b],
-                                      m->l_blk_idx[b], m->lm_grid, cnt[b] + 1, 1, m->v0, m->V), "lm_head");
+            VH_TRY(vhk_dec_lmhead(st, xa[g0], dm[g0], m->final_norm, eps, m->lm_head, m->Vn, H, m->logits, m->l_blk_val[0],
+                                  m->l_blk_idx[0], m->lm_grid, cnt[g0] + 1, 1, m->v0, m->V), "lm_head");
         }
-        const bool sharded = m->c.vocab_n > 0 && m->c.tp_world > 1;
-        for (int b = 0; b < n; ++b) {
+        for (int b = 0; b < gn; ++b) {
+            const int sb = g0 + b;
             int nblk = m->lm_grid;
             if (sharded) {
                 VH_TRY(vhk_dec_cand(st, m->l_blk_val[b], m->l_blk_idx[b], m->lm_grid, m->l_cand[b], m->c.tp_rank, m->c.tp_world), "candidates");
@@ -1029,8 +1084,8 @@ static int decode_batch_step(vh_mixtral* m, hipStream_t st, const int* ids, int 
                 VH_TRY(vhk_dec_cand_unpack(st, m->l_cand[b], m->c.tp_world, m->l_blk_val[b], m->l_blk_idx[b]), "candidates");
                 nblk = m->c.tp_world;
             }
-            VH_TRY(vhk_dec_select(st, m->l_blk_val[b], m->l_blk_idx[b], nblk, m->embed, H, m->V, xa[b], cnt[b], cnt[b] + 1,
-                                  m->seq_tokens + (size_t)ids[b] * (m->c.max_new > 0 ? m->c.max_new : 1), m->c.max_new, 1, 0), "select");
+            VH_TRY(vhk_dec_select(st, m->l_blk_val[b], m->l_blk_idx[b], nblk, m->embed, H, m->V, xa[sb], cnt[sb], cnt[sb] + 1,
+                                  m->seq_tokens + (size_t)ids[sb] * (m->c.max_new > 0 ? m->c.max_new : 1), m->c.max_new, 1, 0), "select");
         }
     }
     const hipError_t e = hipGetLastError();
@@ -1049,27 +1104,24 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         if (q.host_pos < 1) return fail(VH_E_ARG, "sequence %d has no prompt yet", ids[i]);
         if (q.host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "sequence %d: context limit %d", ids[i], m->c.max_ctx);
     }
-    // groups of up to VH_BMAX distinct sequences go through the batched kernels (a sequence listed twice in one call
-    // advances twice, one step after the other, as before)
+    // distinct sequences advance together through the batched iteration (a sequence listed twice in one call advances
+    // twice, one step after the other, as before)
     if (n >= 2 && vh_tuning()->batch_decode != 0 && m->H <= 4096 && m->nq * m->hd <= 4096) {
         bool distinct = true;
         for (int i = 0; i < n && distinct; ++i)
             for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) { distinct = false; break; }
         if (distinct) {
-            for (int g0 = 0; g0 < n; g0 += VH_BMAX) {
-                const int gn = n - g0 < VH_BMAX ? n - g0 : VH_BMAX;
-                for (int i = 0; i < gn; ++i) {
-                    const int pr = m->ensure_pages(ids[g0 + i], m->seqs[ids[g0 + i]].host_pos + 1, st);
-                    if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", ids[g0 + i], g0);
-                    if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
-                }
-                const int rc = decode_batch_step(m, st, ids + g0, gn);
-                if (rc != VH_OK) {
-                    for (int i = 0; i < gn; ++i) m->seqs[ids[g0 + i]].poisoned = 1;
-                    return rc;
-                }
-                for (int i = 0; i < gn; ++i) m->seqs[ids[g0 + i]].host_pos += 1;
+            for (int i = 0; i < n; ++i) {
+                const int pr = m->ensure_pages(ids[i], m->seqs[ids[i]].host_pos + 1, st);
+                if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted at sequence %d (nothing of the batch advanced)", ids[i]);
+                if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
             }
+            const int rc = decode_iteration(m, st, ids, n);
+            if (rc != VH_OK) {
+                for (int i = 0; i < n; ++i) m->seqs[ids[i]].poisoned = 1;
+                return rc;
+            }
+            for (int i = 0; i < n; ++i) m->seqs[ids[i]].host_pos += 1;
             return VH_OK;
         }
     }

@@ -422,6 +422,23 @@ inline int grid_for(long total, int block) {
     return (int)g;
 }
 
+// batched decode, streaming-MoE path: residual stream of every sequence of the iteration gathered into contiguous rows.
+// Slot layout (vh_api.hip): seq_x[slot] = {xa, xb, delta_attn, delta_moe}[H]; x = xb + delta_attn is also stored to xa,
+// exactly what k_dec_gateup's prologue leaves there.
+__global__ __launch_bounds__(256) void k_gather_rows(float* __restrict__ seq_x, const int* __restrict__ slots, int H,
+                                                     float* __restrict__ rows) {
+    const int b = blockIdx.x;
+    float* x = seq_x + (size_t)slots[b] * 4 * H;
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x + H);
+    const f32x4* da = reinterpret_cast<const f32x4*>(x + 2 * H);
+    f32x4* xa = reinterpret_cast<f32x4*>(x);
+    f32x4* out = reinterpret_cast<f32x4*>(rows + (size_t)b * H);
+    for (int c = threadIdx.x; c < H / 4; c += 256) {
+        const f32x4 v = xb[c] + da[c];
+        xa[c] = v;
+        out[c] = v;
+    }
+}
 }  // namespace
 
 int vhk_layernorm(hipStream_t st, const float* x, long ldx, float* y, long ldy, const float* w, const float* b,
@@ -516,6 +533,11 @@ int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, 
     if (S == 0) return 0;
     hipLaunchKernelGGL(k_moe_combine, dim3(grid_for((long)S * (H / 4), 256)), dim3(256), 0, st, x, y, wts, S, H, nslab,
                        slab_stride, nslab_dev);
+    return 0;
+}
+int vhk_gather_rows(hipStream_t st, float* seq_x, const int* slots, int n, int H, float* rows) {
+    if (n < 1 || (H % 4) != 0) return -1;
+    hipLaunchKernelGGL(k_gather_rows, dim3(n), dim3(256), 0, st, seq_x, slots, H, rows);
     return 0;
 }
 int vhk_sum_slabs(hipStream_t st, float* dst, long ldd, const float* src, long lds, int rows, int cols,

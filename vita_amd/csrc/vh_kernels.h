@@ -15,6 +15,8 @@ struct VhTuning {
                                // slower: 204-209 vs 211.5 tok/s), 0 = one block per row pair
     int dec_prefetch = 0;      // decode attention launch: n prefetching blocks per CU pull the O-projection weights through the memory-side
                                // cache while attention runs (measured: 211.5 -> 198 tok/s at 1, 199 at 2, 202 at 4: off)
+    int batch_moe_min = 4;     // concurrent sequences: from this many per iteration the layer's MoE runs ONCE on the weight-streaming GEMM
+                               // (S = n rows sorted by expert, every touched expert streamed once); 0 = never
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
     int attn_wpe = 3;          // plain d = 64 attention (ViT): waves per SIMD the register allocation aims at (2: 182 VGPRs, 3: 145, 4: 128 + spills)
@@ -157,6 +159,7 @@ int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const
 int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
                 const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx,
                 const int* table, const int* nslab_dev, long slab_stride);   // nslab_dev: qkv is *nslab_dev partial slabs
+int vhk_gather_rows(hipStream_t st, float* seq_x, const int* slots, int n, int H, float* rows);   // rows[b] = xa[b] = xb[b] + delta_attn[b]
 int vhk_sum_slabs(hipStream_t st, float* dst, long ldd, const float* src, long lds, int rows, int cols,
                   const int* nslab_dev, int nslab, long stride, int accumulate);
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
