@@ -44,7 +44,7 @@ for n, d in sorted(by.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["records"
     busy, mfma = d.get("SQ_BUSY_CU_CYCLES", 0), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
     print(f"{n[:80]:80s} avg_us {d['avg_us']:8.1f}  MFMA_BUSY {mfma:14.0f}  BUSY_CU {busy:14.0f}  util {mfma / busy / 4 if busy else 0:.3f}")
 PY
-(cd $R && timeout 300 python bench.py --no-cpu-baseline --batch 2,4 > $O/r02_bench_concurrent.json 2> $O/conc.err)
+(cd $R && timeout 300 python bench.py --no-cpu-baseline --batch 2,3,4,8,16 > $O/r02_bench_concurrent.json 2> $O/conc.err)
 python -c "import json,sys; j=json.loads(open('$O/r02_bench_concurrent.json').read().strip().splitlines()[-1]); print(j['value'], j.get('concurrent'))"
 head -8 $O/r02_kernel_stats_decode.txt | cut -c1-150; head -14 $O/r02_kernel_stats_prefill_encoders.txt | cut -c1-150
 head -12 $O/r02_pmc_mfma_busy.txt | cut -c1-170; head -8 $O/r02_pmc_FETCH_SIZE.txt | cut -c1-170

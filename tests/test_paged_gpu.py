@@ -169,11 +169,11 @@ def test_six_sequences_batched_kernels_match_oracle(dev, batched):
     n_new = 14
     lens = [40, 97, 64, 130, 20, 75]
     _, _, eng, reqs = _setup(dev, lens, n_new, seed=11, pool=2048, max_seqs=6)
-    # 1: default (iterations of >= 4 sequences run the MoE once on the weight-streaming GEMM, smaller ones per sequence),
+    # 1: default (iterations of >= 3 sequences run the MoE once on the weight-streaming GEMM, smaller ones per sequence),
     # 3: expert GEMVs per sequence at every size, 2: de-duplicating expert GEMVs, 0: one sequence after the other
     _lib.tune("batch_decode", min(batched, 1))
     _lib.tune("batch_moe", 1 if batched == 2 else 0)
-    _lib.tune("batch_moe_min", 4 if batched == 1 else 0)
+    _lib.tune("batch_moe_min", 3 if batched == 1 else 0)
     try:
         seqs = []
         for r in reqs[:5]:
@@ -200,7 +200,7 @@ def test_six_sequences_batched_kernels_match_oracle(dev, batched):
     finally:
         _lib.tune("batch_decode", 1)
         _lib.tune("batch_moe", 0)
-        _lib.tune("batch_moe_min", 4)
+        _lib.tune("batch_moe_min", 3)
     eng.close()
 
 

@@ -953,7 +953,7 @@ int vh_mixtral_seq_prefill(vh_mixtral_t* m, int s, const float* embeds, int Sn, 
 // One decode ITERATION of n concurrent sequences (n <= max_seqs, all distinct).  The attention side (fused QKV GEMV,
 // split-KV attention, O projection) and the LM head run in groups of up to VH_BMAX sequences per launch (one pass over
 // the shared weights per group).  The MoE of a layer runs
-//   n >= batch_moe_min (default 4): ONCE for the whole iteration on the prefill's weight-streaming GEMM with S = n — rows
+//   n >= batch_moe_min (default 3): ONCE for the whole iteration on the prefill's weight-streaming GEMM with S = n — rows
 //       sorted by expert, every TOUCHED expert streamed exactly once at ~5 TB/s however many sequences picked it
 //       (k_gemm_ps cfg 0, <= 64 rows per tile, SURVEY 8(f)#1: "continuous batching");
 //   otherwise per sequence with the batch-1 GEMV kernels (de-duplicating GEMV variant behind batch_moe).

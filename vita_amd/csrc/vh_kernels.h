@@ -15,7 +15,7 @@ struct VhTuning {
                                // slower: 204-209 vs 211.5 tok/s), 0 = one block per row pair
     int dec_prefetch = 0;      // decode attention launch: n prefetching blocks per CU pull the O-projection weights through the memory-side
                                // cache while attention runs (measured: 211.5 -> 198 tok/s at 1, 199 at 2, 202 at 4: off)
-    int batch_moe_min = 4;     // concurrent sequences: from this many per iteration the layer's MoE runs ONCE on the weight-streaming GEMM
+    int batch_moe_min = 3;     // concurrent sequences: from this many per iteration the layer's MoE runs ONCE on the weight-streaming GEMM
                                // (S = n rows sorted by expert, every touched expert streamed once); 0 = never
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
