@@ -233,6 +233,7 @@ struct vh_mixtral {
     };
     std::vector<Seq> seqs;
     std::vector<int> free_pages;
+    std::vector<int> batch_ids_host;   // slot list last uploaded to seq_batch (storage reserved once)
     float* seq_x = nullptr;            // [max_seqs][4][H]: xa, xb, delta_attn, delta_moe
     int *seq_counters = nullptr, *seq_tokens = nullptr, *seq_table = nullptr, *seq_batch = nullptr;
     // scratch "lanes" 1..VH_BMAX-1 of the per-step buffers (lane 0 = the single-sequence ones) for batched decode iterations
@@ -284,6 +285,8 @@ struct vh_mixtral {
         for (Seq& q : seqs) q.pages.assign(max_splits, 0);
         free_pages.clear();
         for (int pg = n_pages() - 1; pg >= 0; --pg) free_pages.push_back(pg);   // page 0 is handed out first
+        batch_ids_host.clear();
+        batch_ids_host.reserve(seqs.size() + 1);
     }
     int rccl_gen = 0;           // bumped by vh_mixtral_cancel_rccl: a pending vh_mixtral_init_rccl then discards its communicator
     int poisoned = 0;           // a decode step failed half-way: only prefill / reset may follow
@@ -973,8 +976,14 @@ static int decode_iteration(vh_mixtral* m, hipStream_t st, const int* ids, int n
     const int moe_min = vh_tuning()->batch_moe_min;
     const bool stream_moe = moe_min > 0 && n >= moe_min && n <= m->c.max_prefill && H <= 4096 && (H % 64) == 0 && (I % 64) == 0;
     if (stream_moe) {
-        if (hipMemcpyAsync(m->seq_batch, ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
-            return fail(VH_E_HIP, "batch id upload failed");
+        // the slot list of the iteration lives on the device for k_gather_rows; it is re-uploaded only when the running
+        // set changed (a pageable-memory upload waits for the stream: doing it every iteration would stop the host from
+        // enqueueing ahead of the GPU).  The source is a member whose storage never moves (reserved at creation).
+        if ((int)m->batch_ids_host.size() != n || memcmp(m->batch_ids_host.data(), ids, (size_t)n * sizeof(int)) != 0) {
+            m->batch_ids_host.assign(ids, ids + n);
+            if (hipMemcpyAsync(m->seq_batch, m->batch_ids_host.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+                return fail(VH_E_HIP, "batch id upload failed");
+        }
         for (int b = 0; b < n; ++b) dm[b] = m->ptmp + (size_t)b * H;       // MoE delta rows of this iteration
     }
     for (int l = 0; l < m->c.n_layers; ++l) {
