@@ -496,7 +496,8 @@ class AsyncLLMEngine:
             loop.call_soon_threadsafe(q.put_nowait, item)
 
     def _loop(self):
-        torch.cuda.set_device(self.llm.model.device)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.llm.model.device)      # kernels launch on the CURRENT device's stream
         state = {}                                   # request id -> (prompt ids, sampling params, token list)
         while True:
             with self._cv:
