@@ -17,7 +17,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import mixtral as om
-from vita_amd.checkpoint import synth_state_dict, tp_slices
+from vita_amd.checkpoint import synth_state_dict, tp_slices, vocab_shard
 from vita_amd.config import VitaConfig
 
 F32 = np.float32
@@ -71,12 +71,27 @@ def _worker(rank, world, port, ret):
         logits = _tp_forward(sd, cfg.text, x, rank, world, n_ar)
         gathered = [torch.zeros(logits.shape[0]) for _ in range(world)]
         dist.all_gather(gathered, torch.from_numpy(logits))
+        # vocab-sharded LM head (ParallelLMHead + logits gather, vllm_file/mixtral.py:939-951) as the engine does it: every
+        # rank scores ITS rows (vita_amd.checkpoint.vocab_shard), keeps one (max, global index) candidate, writes it into
+        # its slot of a zeroed [world][2] vector, the vector is all-reduced (adding zeros is exact; indices < 2^24 are
+        # exact in fp32) and every rank takes the same argmax with the lowest-index tie rule
+        lo, nrows = vocab_shard(cfg.text.vocab_size, rank, world)
+        mine = logits[lo:lo + nrows]
+        cand = np.zeros((world, 2), F32)
+        j = int(np.argmax(mine))                                  # first maximum = lowest index
+        cand[rank] = (mine[j], lo + j)
+        cand = _allreduce(cand)
+        best = max(range(world), key=lambda r: (cand[r, 0], -cand[r, 1]))
+        tok_sharded = int(cand[best, 1])
+        toks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(toks, torch.tensor([tok_sharded]))
         if rank == 0:
             full, _ = om.MixtralOracle(sd, cfg.text).forward(x)
             ret["err"] = float(np.max(np.abs(full[-1] - logits)))
             ret["argmax_same"] = bool(int(np.argmax(full[-1])) == int(np.argmax(logits)))
             ret["ranks_agree"] = bool(all(torch.equal(gathered[0], gi) for gi in gathered))
             ret["n_allreduce"] = n_ar[0]
+            ret["sharded_token_same"] = bool(tok_sharded == int(np.argmax(logits)) and all(int(t[0]) == tok_sharded for t in toks))
             ret["layers"] = cfg.text.num_hidden_layers
     finally:
         dist.destroy_process_group()
@@ -98,6 +113,7 @@ def test_tp2_partition_matches_unsharded_oracle():
         assert ret["n_allreduce"] == 2 * ret["layers"]   # the reference's 2 collectives per layer
         assert ret["err"] < 1e-4, ret["err"]             # fp32 summation-order noise only
         assert ret["argmax_same"]
+        assert ret["sharded_token_same"]                 # the (max, index) exchange of the vocab-sharded head picks the same token
 
 
 def test_tp_slices_cover_real_geometry():
@@ -115,3 +131,11 @@ def test_tp_slices_cover_real_geometry():
         assert kvcov == list(range(0, t.num_key_value_heads * t.head_dim, t.head_dim))
         assert ffcov[0][0] == 0 and ffcov[-1][1] == t.intermediate_size
         assert all(ffcov[i][1] == ffcov[i + 1][0] for i in range(world - 1))
+
+
+def test_vocab_shards_cover_the_table():
+    V = VitaConfig().text.vocab_size
+    for world in (1, 2, 3, 4, 8):
+        rows = [vocab_shard(V, r, world) for r in range(world)]
+        assert rows[0][0] == 0 and sum(n for _, n in rows) == V
+        assert all(rows[r][0] + rows[r][1] == rows[r + 1][0] for r in range(world - 1))
