@@ -80,11 +80,13 @@ def _tp_worker(rank, world, port, overlap, ret):
         rng = np.random.default_rng(5)
         ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
         emb = packed["embed"][torch.as_tensor(ids, device=dev)].float()
-        eng.prefill(emb)
+        row0, _ = eng.prefill(emb)               # sharded head: the returned row is already the full one (collective inside)
+        row0 = row0.cpu()
         eng.decode(9)
         torch.cuda.synchronize()
         lg = eng.logits_all[:10].cpu()
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
+        assert eng.vocab_sharded and torch.equal(row0, lg[0]), "prefill() must return the full-vocabulary row under TP"
         ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n))
         dist.barrier()
         eng.close()

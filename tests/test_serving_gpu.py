@@ -1,7 +1,7 @@
 """vLLM-shaped surface: the app-side contract of web_demo/web_ability_demo.py:203-232 —
 one placeholder id per image / clip, PIL images and CMVN-normalised features in multi_modal_data,
-SamplingParams(temperature=0.01) == greedy — must produce the SAME tokens as the HF-flavour path on the
-same request (whose parity with the reference is pinned in test_model_gpu.py)."""
+SamplingParams(temperature=0.01) == greedy — must produce the tokens of the ORACLE (oracle/encoders.py +
+oracle/mixtral.py on the same state dict and inputs), and the same tokens as the HF-flavour boundary."""
 import json
 import os
 
@@ -64,14 +64,26 @@ def test_generate_image_audio_request(served, dev):
                      do_sample=False, num_beams=1, return_dict_in_generate=True, max_new_tokens=10)
     exp = ref.sequences[0, len(sent):].tolist()
     assert got == exp, (got, exp)
+    # ... and through the oracle: tiles + raw fbank -> fp64 encoders -> splice -> fp32 Mixtral greedy
+    from tests.oracle_e2e import oracle_generate
+    o_ids, _, o_emb = oracle_generate(sd, cfg, sent, pix=pix, fbank=raw, n_new=10)
+    assert o_emb.shape[0] == len(sent) - len(tiles) - 1 + len(tiles) * (cfg.vision.image_size // cfg.vision.patch_size // 2) ** 2 + \
+        audio_feature_size(raw.shape[0])
+    assert got == o_ids[:len(got)], (got, o_ids)
+    assert len(got) == 10 or got[-1] == 2
     assert audio_feature_size(raw.shape[0]) == m.get_audio_encoder()(raw[None], torch.tensor([raw.shape[0]]))["inputs_embeds"].shape[1]
 
 
 def test_text_only_and_errors(served, dev):
+    from oracle import mixtral as om
+    from vita_amd.config import VitaConfig
     from vita_amd.serving import SamplingParams
-    llm, _, _ = served
+    llm, sd, _ = served
     out = llm.generate({"prompt_token_ids": [1, 5, 6, 7, 8]}, sampling_params=SamplingParams(max_tokens=4))
-    assert 1 <= len(out[0].outputs[0].token_ids) <= 4
+    got = out[0].outputs[0].token_ids
+    assert 1 <= len(got) <= 4
+    exp, _ = om.MixtralOracle(sd, VitaConfig.tiny().text).greedy(sd["model.embed_tokens.weight"][[1, 5, 6, 7, 8]], 4)
+    assert got == exp[:len(got)] and (len(got) == 4 or got[-1] == 2), (got, exp)
     with pytest.raises(ValueError):          # placeholder without data (mixtral.py:244-247)
         llm.generate({"prompt_token_ids": [1, IMG_ID, 5]}, sampling_params=SamplingParams(max_tokens=2))
     with pytest.raises(NotImplementedError):
@@ -101,11 +113,16 @@ def test_llm_tensor_parallel_two_processes(served, dev):
     the collective itself and serves the same requests; both ranks return the single-process tokens."""
     import socket
     import torch.multiprocessing as mp
+    from oracle import mixtral as om
+    from vita_amd.config import VitaConfig
     from vita_amd.serving import SamplingParams
-    llm, _, d = served
+    llm, sd, d = served
     prompts = [[1, 5, 6, 7, 8], [1, 9, 10, 11, 12, 13, 14, 15, 16, 17]]
     exp = [llm.generate({"prompt_token_ids": p}, sampling_params=SamplingParams(temperature=0.01, max_tokens=8))[0]
            .outputs[0].token_ids for p in prompts]
+    for p, e in zip(prompts, exp):                      # the single-process tokens are the oracle's
+        o, _ = om.MixtralOracle(sd, VitaConfig.tiny().text).greedy(sd["model.embed_tokens.weight"][p], 8)
+        assert e == o[:len(e)] and (len(e) == 8 or e[-1] == 2), (e, o)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

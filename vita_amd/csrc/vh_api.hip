@@ -63,6 +63,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "moe_ksplit")) { g_tuning.moe_ksplit = value; return VH_OK; }
     if (!strcmp(key, "tp_overlap")) { g_tuning.tp_overlap = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
+    if (!strcmp(key, "ws_pad")) { g_tuning.ws_pad = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -190,13 +191,20 @@ bool load_rccl() {
     return true;
 }
 
-inline size_t al(size_t n) { return (n + 255) & ~size_t(255); }
+inline size_t al(size_t n, size_t a) { return (n + a - 1) & ~(a - 1); }
 
+// Workspace carver.  Buffers of 1 MiB and more start on 2 MiB boundaries (the allocation granule of the device page
+// tables); small ones on 256 B.  The ORDER in vh_mixtral::carve is part of the performance contract: everything the
+// prefill kernels stream sits in front of the KV cache, so its placement does not move with max_new / max_ctx.  (r03 measurement,
+// profiles/r03_layout_*: prefill time does NOT depend on the placement — 52.5 ms under three step settings and five pads
+// on one box, 40.0 ms under two on another; the r02 "39.7 vs 52.6 ms" was the box, not the layout.)
 struct Carver {
     char* base; size_t off;
     template <typename T> T* take(size_t count) {
+        const size_t bytes = count * sizeof(T);
+        off = al(off, bytes >= (1u << 20) ? (size_t(2) << 20) : size_t(256));
         T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-        off += al(count * sizeof(T));
+        off += bytes;
         return p;
     }
 };
@@ -299,36 +307,38 @@ struct vh_mixtral {
     size_t prof_used = 0;
 
     size_t carve(void* ws) {
-        Carver cv{reinterpret_cast<char*>(ws), 0};
+        Carver cv{reinterpret_cast<char*>(ws), (size_t)(vh_tuning()->ws_pad > 0 ? vh_tuning()->ws_pad : 0) * 65536};
         const size_t Sm = (size_t)c.max_prefill;
-        kcache = cv.take<float>((size_t)c.n_layers * nkv * c.max_ctx * hd);
-        vcache = cv.take<float>((size_t)c.n_layers * nkv * c.max_ctx * hd);
+        // ---- prefill scratch first: fixed offsets for a given (max_prefill, geometry) --------------------------------
+        pxn_hi = cv.take<uint16_t>(Sm * H); pxn_lo = cv.take<uint16_t>(Sm * H);
+        ph_hi = cv.take<uint16_t>(2 * Sm * I); ph_lo = cv.take<uint16_t>(2 * Sm * I);
+        px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
+        pqkv = cv.take<float>(Sm * nqkv);
+        pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
+        py = cv.take<float>(4 * 2 * Sm * H);   // py: up to 4 K-split slabs of the MoE down projection / 8 of the projections
+        ptmp = cv.take<float>(Sm * H);
+        ph = cv.take<float>(2 * Sm * I);       // fp32 intermediates of the general-kernel path only
+        pwts = cv.take<float>(2 * Sm);
+        pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
+        pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
+        pnslab = cv.take<int>(4);
+        // ---- decode state ------------------------------------------------------------------------------------------
         xa = cv.take<float>(H); xb = cv.take<float>(H);
         delta_attn = cv.take<float>(H); delta_moe = cv.take<float>(H);
         qkv = cv.take<float>(nqkv);
-        part_o = cv.take<float>((size_t)nq * max_splits * hd);
-        part_ml = cv.take<float>((size_t)nq * max_splits * 2);
         attn_out = cv.take<float>((size_t)nq * hd);
         attn_cnt = cv.take<int>(nkv);  // arrival tickets; zero at creation, reset by each last arriver
         hbuf = cv.take<float>((size_t)2 * I);
-        logits = cv.take<float>((size_t)hist_rows() * V);
         blk_val = cv.take<float>(lm_grid);
         blk_idx = cv.take<int>(lm_grid);
         cand = cv.take<float>(2 * (c.tp_world > 0 ? c.tp_world : 1));
         route = cv.take<int>(4);
         counters = cv.take<int>(4);  // {pos, n_generated, attn_done (monotonic), device error flag}
+        // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
-        px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
-        pqkv = cv.take<float>(Sm * nqkv);
-        pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
-        ph = cv.take<float>(2 * Sm * I); py = cv.take<float>(4 * 2 * Sm * H);   // py: up to 4 K-split slabs
-        pnslab = cv.take<int>(4);
-        pxn_hi = cv.take<uint16_t>(Sm * H); pxn_lo = cv.take<uint16_t>(Sm * H);
-        ph_hi = cv.take<uint16_t>(2 * Sm * I); ph_lo = cv.take<uint16_t>(2 * Sm * I);
-        ptmp = cv.take<float>(Sm * H);
-        pwts = cv.take<float>(2 * Sm);
-        pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
-        pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
+        part_o = cv.take<float>((size_t)nq * max_splits * hd);
+        part_ml = cv.take<float>((size_t)nq * max_splits * 2);
+        logits = cv.take<float>((size_t)hist_rows() * V);
         if (c.max_seqs > 0) {
             const size_t n = (size_t)c.max_seqs;
             seq_x = cv.take<float>(n * 4 * H);
@@ -351,7 +361,9 @@ struct vh_mixtral {
                 l_cand[b] = cv.take<float>(2 * (c.tp_world > 0 ? c.tp_world : 1));
             }
         }
-        return cv.off;
+        kcache = cv.take<float>((size_t)c.n_layers * nkv * c.max_ctx * hd);
+        vcache = cv.take<float>((size_t)c.n_layers * nkv * c.max_ctx * hd);
+        return al(cv.off, 256);
     }
     int hist_rows() const { return c.logit_rows > 1 ? c.logit_rows : 1; }
     void derive() {

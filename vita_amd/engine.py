@@ -128,9 +128,35 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_set_allreduce(self.h, self._ar_cb, None), "vh_mixtral_set_allreduce")
 
     # ---- forward -----------------------------------------------------------------------------
-    def prefill(self, embeds, pos0=0, want_hidden=False, want_route=False):
-        """embeds fp32 [S, hidden] on device.  Returns (logits_of_last_pos view, hidden_dbg or None); with
-        want_route the per-layer top-2 expert ids [layers, S, 2] are left in self.route_ids."""
+    @property
+    def vocab_sharded(self):
+        return bool(self.c.vocab_n) and self.c.tp_world > 1
+
+    def gather_vocab(self, rows):
+        """Full-vocabulary score rows under a vocab-sharded LM head (ParallelLMHead + logits gather,
+        web_demo/vllm_tools/vllm_file/mixtral.py:939-951): a row kept by the engine holds THIS rank's slice and zeros
+        elsewhere, so the sum over ranks is the full row.  Collective: every rank must call it.  Returns a new tensor
+        (the input when the head is not sharded)."""
+        if not self.vocab_sharded:
+            return rows
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise _lib.VitaHipError("vocab-sharded LM head: full logits need torch.distributed (or build the model with "
+                                    "shard_vocab=False)")
+        out = rows.clone()
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(out)
+        else:
+            r = out.cpu()
+            dist.all_reduce(r)
+            out = r.to(rows.device)
+        return out
+
+    def prefill(self, embeds, pos0=0, want_hidden=False, want_route=False, gather_logits=True):
+        """embeds fp32 [S, hidden] on device.  Returns (logits_of_last_pos, hidden_dbg or None); with
+        want_route the per-layer top-2 expert ids [layers, S, 2] are left in self.route_ids.  Under a vocab-sharded
+        head the returned row is all-reduced over the ranks (a collective call on every rank); gather_logits=False returns
+        this rank's raw row (its vocabulary slice, zeros elsewhere) without a collective."""
         if embeds.dtype != torch.float32 or not embeds.is_cuda:
             raise TypeError("embeds must be a float32 GPU tensor")
         embeds = embeds.contiguous()
@@ -150,7 +176,7 @@ class MixtralEngine:
             if want_route:
                 check(self.lib.vh_mixtral_route_debug(self.h, None), "vh_mixtral_route_debug")
         self.n_gen = 1
-        return self.logits_all[0], hid
+        return (self.gather_vocab(self.logits_all[0]) if gather_logits else self.logits_all[0]), hid
 
     def decode(self, n_steps):
         check(self.lib.vh_mixtral_decode(self.h, int(n_steps), self._stream()), "vh_mixtral_decode")
@@ -158,7 +184,8 @@ class MixtralEngine:
 
     @property
     def logits(self):
-        """scores of the most recent step (row n_gen-1 of the history, or the single row)."""
+        """scores of the most recent step (row n_gen-1 of the history, or the single row) as the engine keeps them: under a
+        vocab-sharded head THIS rank's slice and zeros elsewhere — gather_vocab() assembles the full row."""
         return self.logits_all[min(self.n_gen - 1, self.logit_rows - 1) if self.logit_rows > 1 else 0]
 
     def profile(self, stride, max_samples=2048):
@@ -197,7 +224,8 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_seq_free(self.h, int(s)), "vh_mixtral_seq_free")
 
     def seq_prefill(self, s, embeds, want_logits=False):
-        """append embeds [S, hidden] to sequence s; its next greedy token lands in seq_tokens(s)[0]."""
+        """append embeds [S, hidden] to sequence s; its next greedy token lands in seq_tokens(s)[0].  want_logits: the
+        full-vocabulary row (all-reduced over the ranks under a vocab-sharded head: collective)."""
         if embeds.dtype != torch.float32 or not embeds.is_cuda:
             raise TypeError("embeds must be a float32 GPU tensor")
         embeds = embeds.contiguous()
@@ -205,7 +233,7 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_seq_prefill(self.h, int(s), embeds.data_ptr(), embeds.shape[0],
                                               out.data_ptr() if out is not None else None, self._stream()),
               "vh_mixtral_seq_prefill")
-        return out
+        return self.gather_vocab(out) if out is not None else None
 
     def seq_decode(self, seqs):
         """one greedy step for every listed sequence (one continuous-batching iteration)."""

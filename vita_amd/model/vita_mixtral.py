@@ -245,15 +245,7 @@ class VITAMixtralForCausalLM(_HipModule):
             return sequences
         scores = None
         if keep_scores:
-            rows = eng.logits_all[:len(generated)].clone()
-            if eng.c.vocab_n and eng.c.tp_world > 1:
-                # vocab-sharded head: a kept row holds this rank's slice and zeros elsewhere; the sum is the full row
-                import torch.distributed as dist
-                if dist.is_initialized() and dist.get_backend() == "nccl":
-                    dist.all_reduce(rows)
-                elif dist.is_initialized():
-                    r = rows.cpu()
-                    dist.all_reduce(r)
-                    rows = r.to(rows.device)
+            # vocab-sharded head: a kept row holds this rank's slice and zeros elsewhere; the sum is the full row
+            rows = eng.gather_vocab(eng.logits_all[:len(generated)]) if eng.vocab_sharded else eng.logits_all[:len(generated)].clone()
             scores = tuple(rows[i][None] for i in range(len(generated)))
         return GenerateOutput(sequences=sequences, scores=scores, past_key_values=None)
