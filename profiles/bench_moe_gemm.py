@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--H", type=int, default=4096)
     ap.add_argument("--I", type=int, default=14336)
     ap.add_argument("--E", type=int, default=8)
+    ap.add_argument("--ab", default="", help="comma list of ps_cfg values to A/B in interleaved rounds, e.g. 1,2")
+    ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--layers", type=int, default=2, help="distinct weight sets cycled through (defeats cache reuse)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -87,9 +89,9 @@ def main():
         gg = L["w1"][e].double() @ xr
         uu = L["w3"][e].double() @ xr
         href = gg / (1 + torch.exp(-gg)) * uu
-        err_h = max(err_h, float((h[p].double() - href).abs().max()))
+        err_h = max(err_h, float(torch.nan_to_num((h[p].double() - href).abs(), nan=1e30).max()))
         yref = L["w2"][e].double() @ h[p].double()
-        err_y = max(err_y, float((ysum[slot].double() - yref).abs().max()))
+        err_y = max(err_y, float(torch.nan_to_num((ysum[slot].double() - yref).abs(), nan=1e30).max()))
     print(f"max |err| gate/up {err_h:.3e}   down {err_y:.3e}", flush=True)
     assert args.nocheck or (err_h < 5e-4 and err_y < 5e-4), "parity failure"
 
@@ -133,6 +135,31 @@ def main():
     report("stream ksplit=auto (default)", gu, dn)
     gu, dn = time_pair(2)
     report("stream ksplit=2", gu, dn)
+    if args.ab:
+        # interleaved A/B of the kernel variants in ONE process (guide 5.4 rule 24): parity of each against the fp64 sample, then rounds
+        for cfg in [int(c) for c in args.ab.split(",")]:
+            _lib.tune("ps_cfg", cfg)
+            hh, hl, y = run_ps(layers[0], -4)
+            torch.cuda.synchronize()
+            h = hh.float() + hl.float()
+            ysum = y.sum(0)
+            e_h = e_y = 0.0
+            for pp in list(range(0, 2 * S, max(1, (2 * S) // 48))) + [2 * S - 1] + [int(v) - 1 for v in np.cumsum(rows) if v > 0]:
+                slot = int(order[pp]); e = int(flat[slot]); t = slot // 2
+                xr = x[t].double()
+                gg = L["w1"][e].double() @ xr
+                uu = L["w3"][e].double() @ xr
+                href = gg / (1 + torch.exp(-gg)) * uu
+                e_h = max(e_h, float(torch.nan_to_num((h[pp].double() - href).abs(), nan=1e30).max()))
+                e_y = max(e_y, float(torch.nan_to_num((ysum[slot].double() - L["w2"][e].double() @ h[pp].double()).abs(), nan=1e30).max()))
+            print(f"cfg={cfg}: max |err| gate/up {e_h:.3e}   down {e_y:.3e}   (K split {int(nslab.item())})", flush=True)
+            assert args.nocheck or (e_h < 5e-4 and e_y < 5e-4), f"parity failure cfg={cfg}"
+        for rnd in range(args.rounds):
+            for cfg in [int(c) for c in args.ab.split(",")]:
+                _lib.tune("ps_cfg", cfg)
+                gu, dn = time_pair(-4)
+                report(f"round {rnd} cfg={cfg}", gu, dn)
+        _lib.tune("ps_cfg", -1)
     if args.sweep:
         gu, dn = time_pair(1)
         report("stream ksplit=1", gu, dn)

@@ -175,7 +175,17 @@ def test_gemm_grouped_glu_and_scatter(dev):
     assert_close("grouped down + scatter", to_np(y), yref, atol=2e-4)
 
 
-def test_gemm_ps_ksplit_slabs(dev):
+@pytest.fixture(params=[-1, 1, 2], ids=["cfg-auto", "cfg-regstaged", "cfg-ws"])
+def ps_cfg(request):
+    """every vh_gemm_ps test runs on the default selection, the r02 register-staged kernel and the r03 kernel whose
+    weights go straight to registers (vh_gemm_ws.hip)."""
+    from vita_amd import _lib
+    _lib.tune("ps_cfg", request.param)
+    yield request.param
+    _lib.tune("ps_cfg", -1)
+
+
+def test_gemm_ps_ksplit_slabs(dev, ps_cfg):
     """K-split down projection: partial slabs per K range add up to the unsplit product; ragged expert sizes,
     an empty expert, more experts than XCD runs."""
     from vita_amd import ops
@@ -213,8 +223,9 @@ def test_split_planes(dev):
 
 
 @pytest.mark.parametrize("M,N,K,wide", [(1, 64, 64, False), (16, 128, 64, False), (138, 300, 192, False),
-                                        (193, 257, 128, True), (400, 512, 4096, True), (552, 4096, 1024, False)])
-def test_gemm_ps_plain(dev, M, N, K, wide):
+                                        (193, 257, 128, True), (400, 512, 4096, True), (552, 4096, 1024, False),
+                                        (288, 256, 64, False), (289, 96, 128, False), (250, 512, 320, False), (33, 40, 2048, False)])
+def test_gemm_ps_plain(dev, M, N, K, wide, ps_cfg):
     """pre-split skinny GEMM vs fp64 reference on the same bf16 weights: ragged M (row tiles + clamped
     rows), N tails, several 192-row m-tiles, K long enough to wrap the LDS ring many times."""
     from vita_amd import ops
@@ -229,7 +240,7 @@ def test_gemm_ps_plain(dev, M, N, K, wide):
     assert_close(f"gemm_ps {M}x{N}x{K}", to_np(y), ref, atol=3e-4 if K > 1024 else 1e-4)
 
 
-def test_gemm_ps_grouped_glu_and_scatter(dev):
+def test_gemm_ps_grouped_glu_and_scatter(dev, ps_cfg):
     """the MoE pair on the pre-split kernel: gather by sorted token, grouped GLU emitting split planes,
     grouped down GEMM scattered to (token, slot) rows; one expert empty, one above 192 rows."""
     from vita_amd import ops

@@ -178,3 +178,55 @@ def test_oversized_prompt_is_refused_up_front():
     got, fin = _drain(bt)
     # alone in a dry pool: it ends ("length") where the pool ends instead of raising
     assert fin["y"] == "length" and got["y"] == _expected(list(range(1, 97)), len(got["y"])) and 1 <= len(got["y"]) < 50
+
+
+def test_one_failing_request_does_not_touch_the_others():
+    """a prefill that raises ends THAT request with an "error" event; running and later requests go on."""
+    from vita_amd.serving import ContinuousBatcher
+
+    class Flaky(FakeEngine):
+        def seq_prefill(self, s, emb):
+            if int(emb.argmax(dim=1)[0]) == 13:                          # the poisoned prompt
+                raise RuntimeError("prefill rejected")
+            return super().seq_prefill(s, emb)
+
+    eng = Flaky(pool_tokens=64 * 8, max_seqs=2)
+    bt = ContinuousBatcher(eng, window=1)
+    bt.add("ok1", _emb([1, 2, 3]), max_tokens=5)
+    bt.add("bad", _emb([13, 2]), max_tokens=5)
+    bt.add("ok2", _emb([4, 5]), max_tokens=5)
+    got, fin = _drain(bt)
+    assert fin == {"ok1": "length", "bad": "error", "ok2": "length"}
+    assert got["ok1"] == _expected([1, 2, 3], 5) and got["ok2"] == _expected([4, 5], 5) and got["bad"] == []
+    assert isinstance(bt.errors.pop("bad"), RuntimeError) and bt.stats["failed"] == 1
+    assert eng.free == 8 and not eng.seqs                                # the failed request's slot and pages came back
+
+
+def test_prompt_larger_than_the_pool_fails_alone():
+    from vita_amd.serving import ContinuousBatcher
+    eng = FakeEngine(pool_tokens=64 * 2, max_seqs=2, max_prefill=512)
+    bt = ContinuousBatcher(eng, window=1)
+    bt.add("small", _emb([1, 2]), max_tokens=3)
+    got, fin = _drain(bt)
+    eng.max_ctx = 64 * 8                                                  # (lets add() accept the prompt; the POOL stays 2 pages)
+    bt.add("huge", _emb(list(range(1, 90)) * 3), max_tokens=3)           # 267 tokens: 5 pages
+    bt.add("after", _emb([7]), max_tokens=3)
+    g2, f2 = _drain(bt)
+    assert f2 == {"huge": "error", "after": "length"} and g2["after"] == _expected([7], 3)
+    assert "KV pages" in str(bt.errors["huge"])
+
+
+def test_recompute_longer_than_max_prefill_goes_in_chunks():
+    """a preempted sequence comes back as prompt + generated tokens; past max_prefill that is several appending prefills."""
+    from vita_amd.serving import ContinuousBatcher
+    eng = FakeEngine(pool_tokens=64 * 4, max_seqs=2, max_new=100, max_prefill=64)
+    table = torch.eye(FakeEngine.V)
+    bt = ContinuousBatcher(eng, embed_tokens=lambda ids: table[ids], window=4)
+    pa, pb = list(range(1, 61)), list(range(20, 82))[:60]
+    bt.add("a", _emb(pa), max_tokens=90)
+    bt.add("b", _emb(pb), max_tokens=90)
+    got, fin = _drain(bt)
+    assert bt.stats["preemptions"] >= 1 and bt.stats["failed"] == 0
+    assert got["a"] == _expected(pa, 90) and got["b"] == _expected(pb, 90)
+    assert all(c[2] <= 64 for c in eng.calls if c[0] == "prefill")       # no call above max_prefill
+    assert eng.free == 4 and fin == {"a": "length", "b": "length"}

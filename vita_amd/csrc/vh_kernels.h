@@ -27,7 +27,8 @@ struct VhTuning {
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
     int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
     int gemm_prefetch = 2;    // general GEMM: 1 = one K-tile in flight, 2 = two for plain GEMMs (default), 3 = two everywhere
-    int ps_cfg = -1;          // vh_gemm_ps variant: -1 = by rows per group, 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights
+    int ps_cfg = -1;          // vh_gemm_ps variant: -1 = by rows per group, 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights,
+                              // 2 = vh_gemm_ws.hip (weights straight to registers, <= 288 rows per tile)
     int ps_grid = 0;          // vh_gemm_ps persistent grid (0 = one block per CU)
     int ps_nt = -1;           // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
     int tp_overlap = 1;       // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
@@ -124,6 +125,7 @@ struct VhGemmPsArgs {
     int* nslab_out;                                          // device int: the split the kernel used (required when ksplit < 0)
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
+int vhk_gemm_ws(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt);   // vh_gemm_ws.hip (arguments already checked)
 int vhk_split_planes(hipStream_t st, const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows,
                      int cols);
 

@@ -50,7 +50,8 @@ class _Backbone(_HipModule):
 
 class VITAMixtralForCausalLM(_HipModule):
     def __init__(self, cfg: VitaConfig, state_dict, device="cuda:0", packed_llm=None, max_new_tokens=1024,
-                 max_prefill=None, rank=0, world=1, keep_scores=True, max_seqs=0, kv_pool_tokens=None):
+                 max_prefill=None, rank=0, world=1, keep_scores=True, max_seqs=0, kv_pool_tokens=None,
+                 gpu_memory_utilization=None):
         super().__init__()
         from ..checkpoint import pack_mixtral
         self.vcfg_all = cfg
@@ -77,12 +78,37 @@ class VITAMixtralForCausalLM(_HipModule):
         self.model = _Backbone(tower, proj, audio, self.packed["embed"])
         self.max_new_tokens = max_new_tokens
         self.max_prefill = max_prefill or cfg.tokenizer_model_max_length
+        if max_seqs > 0 and kv_pool_tokens is None:
+            kv_pool_tokens = self.default_kv_pool_tokens(max_seqs, gpu_memory_utilization, world)
+        self.kv_pool_tokens = kv_pool_tokens
         self.engine = MixtralEngine(cfg, self.packed, self._device, max_prefill=self.max_prefill,
                                     max_new=max_new_tokens, rank=rank, world=world,
                                     logit_rows=max_new_tokens if keep_scores else 0,
                                     max_seqs=max_seqs, max_ctx=kv_pool_tokens)   # max_seqs > 0: paged KV pool (serving)
         self.lookahead = 8          # decode steps enqueued per host synchronisation in generate()
         self.last_timing = {}
+
+    def default_kv_pool_tokens(self, max_seqs, gpu_memory_utilization=None, world=1):
+        """Paged-KV pool for `max_seqs` concurrent requests when the caller names no size (vLLM sizes its block pool from
+        gpu_memory_utilization; AsyncEngineArgs in web_interactive_demo.py:942-951 sets 0.8): room for every slot to hold a
+        demo-shaped prompt (<= 1024 tokens: 1-2 tiles + audio + text) plus max_new_tokens, in whole 64-token pages, bounded by
+        the stated fraction of the memory that is free once the weights are resident.  (r02 defaulted to ONE sequence's worth
+        shared by all slots: eight demo requests kept preempting each other by recompute.)"""
+        t = self.vcfg_all.text
+        per_seq = -(-(min(self.max_prefill, 1024) + self.max_new_tokens + 1) // 64) * 64
+        pool = max_seqs * per_seq
+        floor = -(-(self.max_prefill + self.max_new_tokens + 1) // 64) * 64          # one full-length sequence always fits
+        nkv_rank = max(1, t.num_key_value_heads // max(1, world))
+        bytes_per_token = 2 * t.num_hidden_layers * nkv_rank * t.head_dim * 4        # fp32 K and V rows of every layer
+        if torch.cuda.is_available():
+            free, _ = torch.cuda.mem_get_info(self._device)
+            cap = int(free * float(gpu_memory_utilization or 0.8)) // bytes_per_token // 64 * 64
+            pool = min(pool, cap)
+        pool = max(pool, floor)
+        import logging
+        logging.getLogger("vita_amd").info("paged KV pool: %d tokens (%d pages, %.2f GB) for %d sequence slots", pool,
+                                           pool // 64, pool * bytes_per_token / 1e9, max_seqs)
+        return pool
 
     # ---- reference surface -------------------------------------------------------------------
     def get_model(self):

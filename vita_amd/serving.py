@@ -133,7 +133,8 @@ class LLM:
             torch.cuda.set_device(torch.device(device))       # kernels launch on the CURRENT device's stream
         self.tokenizer, self.model, self.image_processor, _ = load_pretrained_model(
             model, None, os.path.basename(str(model).rstrip("/")), "mixtral-8x7b", device=device,
-            max_new_tokens=max_new_tokens, max_seqs=int(max_num_seqs), kv_pool_tokens=kv_pool_tokens, **kw)
+            max_new_tokens=max_new_tokens, max_seqs=int(max_num_seqs), kv_pool_tokens=kv_pool_tokens,
+            gpu_memory_utilization=gpu_memory_utilization, **kw)
         self.collective = "none"
         if world > 1:
             from .parallel import setup_tensor_parallel
@@ -318,7 +319,8 @@ class ContinuousBatcher:
         self.window = int(window)
         self.waiting = collections.deque()
         self.running = []                 # admission order
-        self.stats = {"iterations": 0, "prefills": 0, "preemptions": 0, "decode_steps": 0}
+        self.errors = {}                  # request id -> exception of a request that failed alone (event reason "error")
+        self.stats = {"iterations": 0, "prefills": 0, "preemptions": 0, "decode_steps": 0, "failed": 0}
 
     def add(self, request_id, embeds, max_tokens, eos=()):
         S = int(embeds.shape[0])
@@ -346,6 +348,20 @@ class ContinuousBatcher:
     def _pages(self, n_tokens):
         return -(-int(n_tokens) // 64)
 
+    def _prefill(self, r):
+        """the prompt of a request — or, after a preemption, prompt + generated tokens, which may exceed what one prefill call
+        takes — in chunks of max_prefill (seq_prefill appends at the sequence's position)."""
+        emb, mp = r["emb"], int(self.eng.max_prefill)
+        for s0 in range(0, int(emb.shape[0]), mp):
+            self.eng.seq_prefill(r["seq"], emb[s0:s0 + mp])
+
+    def _fail(self, r, exc, events):
+        """ONE request failed (its prompt does not fit, its prefill was rejected): it ends with an "error" event, nobody else
+        is touched.  Device-level failures (spin time-outs, launch errors seen at the synchronisation) still propagate."""
+        self.errors[r["id"]] = exc
+        self.stats["failed"] += 1
+        events.append((r["id"], [], True, "error"))
+
     def _admit(self):
         events = []
         while self.waiting and len(self.running) < self.max_batch:
@@ -353,16 +369,24 @@ class ContinuousBatcher:
             need = self._pages(r["emb"].shape[0] + 1) + len(self.running)       # + one page of headroom per runner
             if need > self.eng.pages_free():
                 if not self.running:
-                    raise RuntimeError(f"request {r['id']}: prompt needs {need} KV pages, the pool has "
-                                       f"{self.eng.pages_free()}")
+                    self.waiting.popleft()
+                    self._fail(r, RuntimeError(f"request {r['id']}: prompt needs {need} KV pages, the pool has "
+                                               f"{self.eng.pages_free()}"), events)
+                    continue
                 break
             self.waiting.popleft()
-            r["seq"] = self.eng.seq_alloc()
             try:
-                self.eng.seq_prefill(r["seq"], r["emb"])
-            except Exception:
+                r["seq"] = self.eng.seq_alloc()
+            except Exception as e:
+                self._fail(r, e, events)
+                continue
+            try:
+                self._prefill(r)
+            except Exception as e:
                 self.eng.seq_free(r["seq"])
-                raise
+                r["seq"] = None
+                self._fail(r, e, events)
+                continue
             r["fresh"] = True                    # its first token (tokens[0]) is not reported yet
             self.running.append(r)
             self.stats["prefills"] += 1
@@ -388,9 +412,9 @@ class ContinuousBatcher:
 
     @torch.no_grad()
     def step(self):
-        self._admit()
+        failed = self._admit()
         if not self.running:
-            return []
+            return failed
         # decode window, bounded by every sequence's token buffer and by the pool's addressable context
         steps = self.window
         for r in self.running:
@@ -411,7 +435,7 @@ class ContinuousBatcher:
             self.stats["decode_steps"] += steps * len(ids)
         self.stats["iterations"] += 1
         torch.cuda.current_stream().synchronize()
-        events = []
+        events = failed
         for r in list(self.running):
             cnt = self.eng.check_device_flag(self.eng.seq_counters(r["seq"]).tolist())
             n_dev = min(cnt[1], self.eng.max_new)                 # tokens of this (re)prefill + its decode steps
@@ -450,7 +474,8 @@ class AsyncEngineArgs:
     limit_mm_per_prompt: Optional[dict] = None
     max_num_seqs: int = 8
     max_new_tokens: int = 1024
-    kv_pool_tokens: Optional[int] = None     # size of the paged KV pool (default: max_num_seqs full-length sequences)
+    kv_pool_tokens: Optional[int] = None     # size of the paged KV pool; default: max_num_seqs x (<= 1024-token prompt + max_new_tokens),
+                                             # bounded by gpu_memory_utilization of the free memory (VITAMixtralForCausalLM.default_kv_pool_tokens)
     device: str = "cuda"
 
 
@@ -481,6 +506,7 @@ class AsyncLLMEngine:
     def from_engine_args(cls, args: AsyncEngineArgs, **kw):
         pool = args.kv_pool_tokens
         llm = LLM(args.model, dtype=args.dtype, tensor_parallel_size=args.tensor_parallel_size,
+                  gpu_memory_utilization=args.gpu_memory_utilization,
                   limit_mm_per_prompt=args.limit_mm_per_prompt, max_new_tokens=args.max_new_tokens, device=args.device,
                   max_num_seqs=args.max_num_seqs, kv_pool_tokens=pool)
         return cls(llm, max_num_seqs=args.max_num_seqs, **kw)
@@ -530,6 +556,10 @@ class AsyncLLMEngine:
                 continue
             for rid, new, finished, reason in events:
                 if rid not in state:
+                    continue
+                if reason == "error":                # this request alone failed (ContinuousBatcher._fail)
+                    self._post(rid, self.batcher.errors.pop(rid, RuntimeError(f"request {rid} failed")))
+                    state.pop(rid)
                     continue
                 ids, sp, toks = state[rid]
                 toks += new
