@@ -9,8 +9,13 @@ VITA-Mixtral-8x7B geometry on a 1 image + 10 s audio + text prompt, tensor-paral
 A "step" is one greedy decode step (one pass of the decode hot path over the whole model for one
 token).  Warm-up steps are untimed; exactly K steps are timed between barrier + synchronize pairs,
 inputs (weights, KV cache, prompt) resident in HBM; value = K / max-over-ranks time.  Rank 0 prints
-ONE JSON line.  Data and weights are synthetic (no checkpoint offline): seeded N(0, 0.02) weights of
-the released geometry, a random 448x448 image, a seeded 10 s waveform, random prompt ids."""
+ONE JSON line.  Data and weights are synthetic (no checkpoint offline): weights of the released geometry from the
+counter-based hash generator (vh_fill_hash_bf16 / oracle/hashw.py: sums of four 6-bit fields, ~N(0, 0.018^2), exact in
+bf16, the same bits on the device and in the CPU oracle), a random 448x448 image, a seeded 10 s waveform, random prompt
+ids.  Next to `value` (the engine's decode loop, no host work inside the timed region) the line carries
+`generate_tokens_per_s`: the reference demo's own call — model.generate(..., stopping_criteria=[KeywordsStoppingCriteria])
+(video_audio_demo.py:257-270) — timed end to end, and `gpu_state`: shader clock / socket power sampled while the prefill
+and decode phases run (prefill time moves by up to 30 % from box to box at identical code: profiles/r03_layout_box_*.jsonl)."""
 import argparse
 import json
 import os
@@ -24,6 +29,85 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+class GpuStateSampler:
+    """Shader clock (MHz) and socket power (W) of one GPU, sampled from sysfs by a background thread while a phase runs.
+    Read-only files of the amdgpu driver (hwmon freq1_input / power1_average|power1_input); everything is optional: a box
+    without them yields {"available": False}."""
+
+    def __init__(self, index=0, period_s=0.02):
+        import glob
+        self.period = period_s
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        self.hw = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.files = {}
+        if self.hw:
+            for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input")),
+                               ("temp_c", ("temp2_input", "temp1_input"))):
+                for n in names:
+                    f = os.path.join(self.hw, n)
+                    if os.path.exists(f):
+                        self.files[key] = f
+                        break
+        self.samples, self._stop, self._thr = {}, False, None
+
+    def _read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                v = float(open(f).read().strip())
+                out[k] = v / 1e6 if k in ("sclk_mhz", "power_w") else v / 1e3
+            except Exception:
+                pass
+        return out
+
+    def start(self, tag):
+        import threading
+        self._stop = False
+        buf = self.samples.setdefault(tag, [])
+
+        def loop():
+            while not self._stop:
+                r = self._read()
+                if r:
+                    buf.append(r)
+                time.sleep(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join()
+            self._thr = None
+
+    def summary(self):
+        if not self.files:
+            return {"available": False}
+        out = {"available": True, "source": self.hw}
+        for tag, buf in self.samples.items():
+            d = {"samples": len(buf)}
+            for k in ("sclk_mhz", "power_w", "temp_c"):
+                v = [b[k] for b in buf if k in b]
+                if v:
+                    d[k] = {"median": round(float(np.median(v)), 1), "min": round(min(v), 1), "max": round(max(v), 1)}
+            out[tag] = d
+        return out
+
+
+class _BenchTokenizer:
+    """Just enough tokenizer for KeywordsStoppingCriteria on synthetic ids (no checkpoint / vocabulary offline): "</s>" is
+    id 2, every other id decodes to a word — the per-token host work of the demo's criterion (tail compare + decode of the
+    last few ids, mm_utils.py:136-155) is what the generate() leg is meant to include."""
+    bos_token_id = 1
+
+    def __call__(self, text):
+        from types import SimpleNamespace
+        return SimpleNamespace(input_ids=[1, 2] if text == "</s>" else [1, 3])
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join("</s>" if int(t) == 2 else f"w{int(t)}" for t in row) for row in ids.tolist()]
 
 
 def pmc_traffic(kernel):
@@ -152,7 +236,10 @@ def cpu_baseline(cfg, n_layers=2, ctx=None, n_tok=6, encoders=True, request=None
         t_a = time.perf_counter() - t0
         out.update({"vit_projector_ms": round(t_v * 1e3, 1), "audio_encoder_ms": round(t_a * 1e3, 1), "encoder_cores": int(all_thr),
                     "encoder_sample": "full-depth numpy fp64 restatements (24-layer InternViT + projector on one 448x448 tile; Whale "
-                                      "encoder + adapter on the 10 s clip), one pass each, BLAS default threads"})
+                                      "encoder + adapter on the 10 s clip), one pass each, BLAS default threads",
+                    "encoder_note": "a checker, not a tuned CPU implementation: the reference's OWN torch fp32 modules take 1373 ms "
+                                    "(ViT + projector) / 349 ms (Whale) on 8 cores of the build container "
+                                    "(profiles/r02_reference_cpu_timing.json) — 8.6x / 14x faster than this restatement"})
     return out
 
 
@@ -289,9 +376,12 @@ def main():
         return emb.shape[1], {"vit_proj_ms": e[0].elapsed_time(e[1]), "audio_ms": e[1].elapsed_time(e[2]),
                               "prefill_ms": e[3].elapsed_time(e[4]), "n_audio_tokens": int(aud["inputs_embeds"].shape[1])}
 
+    gpu_state = GpuStateSampler(local_rank)
     for _ in range(max(1, args.phase_warmup)):                         # warm-up of the encoder + prefill path
         S, _ = encode_and_prefill()
+    gpu_state.start("prefill_phase")
     runs = [encode_and_prefill()[1] for _ in range(max(1, args.phase_iters))]
+    gpu_state.stop()
     phase = {k: float(np.median([r[k] for r in runs])) for k in ("vit_proj_ms", "audio_ms", "prefill_ms")}
     phase_min = {k: float(min(r[k] for r in runs)) for k in ("vit_proj_ms", "audio_ms", "prefill_ms")}
     assert runs[-1]["n_audio_tokens"] == n_aud_tok                     # the last run's KV cache feeds the decode below
@@ -305,10 +395,12 @@ def main():
     eng.decode(Wm)
     eng.profile(stride=4, max_samples=K * 8 + 8)       # sample the gate|up GEMV of every 4th layer
     barrier()
+    gpu_state.start("decode_phase")
     t1 = time.perf_counter()
     eng.decode(K)
     barrier()
     dt = time.perf_counter() - t1
+    gpu_state.stop()
     tot_ms, n_samp = eng.profile_read()
     eng.profile(stride=0)
     if world > 1:
@@ -320,6 +412,34 @@ def main():
 
     ms_step = dt * 1e3 / K
     tok_s = K / dt
+
+    # ---- the demo's own call: model.generate() with the keyword stopping criterion, end to end ------------------------------
+    gen = None
+    if not args.emulate_tp:
+        from vita_amd.host.prompt import KeywordsStoppingCriteria
+        n_new = K + Wm                                                   # fits the engine's max_new (K + Wm + 8)
+        crit = KeywordsStoppingCriteria(["</s>"], _BenchTokenizer(), input_ids)
+        model.generate(input_ids, images=image, audios=audios, do_sample=False, num_beams=1, max_new_tokens=4,
+                       use_cache=True, stopping_criteria=[crit], eos_token_id=-1)         # warm-up of the host path
+        barrier()
+        t3 = time.perf_counter()
+        out_g = model.generate(input_ids, images=image, audios=audios, do_sample=False, temperature=0.01, top_p=None, num_beams=1,
+                               return_dict_in_generate=True, max_new_tokens=n_new, use_cache=True, stopping_criteria=[crit],
+                               eos_token_id=-1)
+        barrier()
+        dtg = time.perf_counter() - t3
+        if world > 1:
+            tt = torch.tensor([dtg], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtg = float(tt.item())
+        n_gen = int(out_g.sequences.shape[1] - input_ids.shape[1])
+        lt = dict(model.last_timing)
+        dec_ms = dtg * 1e3 - lt["encode_ms"] - phase["prefill_ms"]       # everything after the first token
+        gen = {"new_tokens": n_gen, "total_ms": round(dtg * 1e3, 2), "encode_ms": round(lt["encode_ms"], 2),
+               "tokens_per_s_end_to_end": round(n_gen / dtg, 2),
+               "tokens_per_s_after_first_token": round((n_gen - 1) / (dec_ms * 1e-3), 2) if dec_ms > 0 and n_gen > 1 else None,
+               "lookahead": int(model.lookahead), "stopping_criteria": "KeywordsStoppingCriteria(['</s>'])"}
+        assert out_g.sequences[0, input_ids.shape[1]:].tolist() == toks[:n_gen], "generate() and the engine loop disagree"
 
     # ---- concurrent sequences (continuous-batching iterations over the paged KV cache) ----------------------------
     concurrent = []
@@ -396,9 +516,15 @@ def main():
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                          "bytes_per_launch": gateup_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "samples": n_samp,
-                         "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None},
+                         "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None,
+                         "traffic_source": "profiles/r02_pmc_hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE pass of this "
+                                           "kernel, counters cannot be read inside this process)" if world == 1 else None},
+            "gpu_state": gpu_state.summary(),
             "build_s": round(t_build, 1),
         }
+        if gen:
+            out["generate_tokens_per_s"] = gen["tokens_per_s_after_first_token"]
+            out["generate"] = gen
         if concurrent:
             out["concurrent"] = concurrent
         if args.layers:

@@ -236,6 +236,42 @@ const int* vh_mixtral_seq_tokens(const vh_mixtral_t* m, int seq);        /* devi
 const int* vh_mixtral_seq_counters(const vh_mixtral_t* m, int seq);      /* device int[4], as vh_mixtral_counters */
 int vh_mixtral_seq_table(const vh_mixtral_t* m, int seq, int* pages_out /* host */, int cap);   /* -> number of pages */
 
+/* ---- batch-1 decode operators, one entry per kernel group ---------------------------------------------------
+ * The steps vh_mixtral_decode chains inside one HF MixtralDecoderLayer (third-party modeling_mixtral.py, reached from
+ * vita/model/language_model/vita_mixtral.py:158-169), exposed one by one so that a single module can be bound.  All
+ * scratch is the caller's.
+ *
+ * vh_router_top2 (K25): MixtralSparseMoeBlock's gate on ALREADY NORMED rows — logits = x Wg^T, fp32 softmax, top-2,
+ *   renormalise (web_demo/vllm_tools/vllm_file/mixtral.py:398-411, renormalize=True).  x fp32 [rows][ldx], Wg bf16 [E][H],
+ *   ids int[rows][2], wts fp32 [rows][2], probs (nullable) fp32 [rows][E].                                                */
+int vh_router_top2(const float* x, long ldx, const uint16_t* Wg, int E, int H, int rows, int* ids, float* wts, float* probs,
+                   void* stream);
+/* vh_moe_decode (K20 + K25 + K26, one token): y = block_sparse_moe(post_attention_layernorm(x + delta)) — the second half
+ *   of MixtralDecoderLayer.forward WITHOUT the residual add: RMSNorm (weight norm_w, eps), router as above, the two routed
+ *   experts' w2(silu(w1 h) * w3 h) weighted and summed.  x, delta (nullable), y fp32 [H]; x_out (nullable) receives x + delta;
+ *   W1, W3 bf16 [E][I][H], W2 bf16 [E][H][I]; route int[4] = {e0, e1, bits(w0), bits(w1)}; hbuf fp32 [2 I] scratch.          */
+int vh_moe_decode(const float* x, const float* delta, const float* norm_w, float eps, const uint16_t* Wg, const uint16_t* W1,
+                  const uint16_t* W3, const uint16_t* W2, int E, int I, int H, float* x_out, float* y, int* route, float* hbuf,
+                  void* stream);
+/* vh_rope_kv_append (K22): rotate-half RoPE on the q and k heads of S fused-QKV rows and append k, v to the cache at
+ *   positions [pos0, pos0 + S) (HF apply_rotary_pos_emb + Cache.update; vLLM rotary_emb + KV write, mixtral.py:477-501).
+ *   qkv fp32 [S][ldqkv] = q heads | k heads | v heads (head_dim 128); q_out fp32 [S][nq*128]; caches fp32
+ *   [nkv][max_ctx][128]; rope_cos / rope_sin fp32 [max_pos][64]; table (nullable) = 64-row page table of a paged cache.      */
+int vh_rope_kv_append(const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache, const float* rope_cos,
+                      const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx, const int* table, void* stream);
+/* vh_attn_decode (K22 + K23, one token): RoPE(q, k_new), KV append at `pos`, causal GQA attention of the token against
+ *   positions [0, pos] (MixtralAttention.forward between the projections).  qkv fp32 [(nq + 2 nkv) * 128]; attn_out fp32
+ *   [nq * 128]; scratch: part_o fp32 [nq][ceil(max_ctx / 64)][128], part_ml fp32 [nq][ceil(max_ctx / 64)][2], tickets
+ *   int[nkv] (zero before the first call; the kernel resets them).                                                           */
+int vh_attn_decode(const float* qkv, float* kcache, float* vcache, int pos, const float* rope_cos, const float* rope_sin,
+                   int nq, int nkv, int max_ctx, float scale, const int* table, float* part_o, float* part_ml, int* tickets,
+                   float* attn_out, void* stream);
+/* vh_lmhead_argmax (K27 + K28): logits = lm_head(norm(x + delta)) in fp32 (vita_mixtral.py:171-172) and their argmax
+ *   (lowest index on ties, as torch.argmax in HF greedy search).  W bf16 [V][H]; logits fp32 [V]; token_out int[1];
+ *   blk_val / blk_idx: nblk floats / ints of scratch (nblk = blocks of the launch, e.g. 1024).                               */
+int vh_lmhead_argmax(const float* x, const float* delta, const float* norm_w, float eps, const uint16_t* W, int V, int H,
+                     float* logits, int* token_out, float* blk_val, int* blk_idx, int nblk, void* stream);
+
 /* Live HIP-event timing of the dominant decode kernel (gate|up expert GEMV): sample one launch
  * every `stride` layers (0 = off), up to max_samples; read returns summed ms and sample count. */
 int vh_mixtral_profile(vh_mixtral_t* m, int stride, int max_samples);

@@ -93,3 +93,30 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1, out.stdout
     j = json.loads(lines[0])
     assert j["launch_check"] and j["n_gpus"] == 2 and j["allreduce_sum"] == j["expected"] == 3.0
+
+
+def test_gpu_state_sampler_and_generate_leg_helpers(tmp_path):
+    """r03 bench additions: the clock / power sampler degrades to {"available": False} without the amdgpu hwmon files and
+    summarises fake ones; the synthetic tokenizer drives the reference's KeywordsStoppingCriteria (tail ids and text)."""
+    import torch
+    import bench
+    from vita_amd.host.prompt import KeywordsStoppingCriteria
+    s = bench.GpuStateSampler(index=0)
+    if not s.files:
+        assert s.summary() == {"available": False}
+    hw = tmp_path / "hwmon0"
+    hw.mkdir()
+    (hw / "freq1_input").write_text("2100000000\n")
+    (hw / "power1_average").write_text("750000000\n")
+    s.hw, s.files = str(hw), {"sclk_mhz": str(hw / "freq1_input"), "power_w": str(hw / "power1_average")}
+    s.start("phase")
+    import time
+    time.sleep(0.1)
+    s.stop()
+    out = s.summary()
+    assert out["available"] and out["phase"]["samples"] >= 2
+    assert out["phase"]["sclk_mhz"]["median"] == 2100.0 and out["phase"]["power_w"]["median"] == 750.0
+    ids = torch.tensor([[1, 7, 9]])
+    crit = KeywordsStoppingCriteria(["</s>"], bench._BenchTokenizer(), ids)
+    assert not crit(torch.tensor([[1, 7, 9, 11, 12]]), None)
+    assert crit(torch.tensor([[1, 7, 9, 11, 2]]), None)                 # tail ids == ids("</s>")

@@ -59,6 +59,19 @@ def test_ipc_allreduce_two_processes_one_gpu():
         assert r0[key][1] == r1[key][1], key                                             # bit-identical across ranks
 
 
+def _tp_cfg(world):
+    """world 2: the tiny geometry; world 4 / 8: 16 q heads over 8 KV heads (one KV head + its GQA group of 2 per rank at 8,
+    as the released 32 / 8 geometry has one KV head + 4 q heads per rank: vllm_file/mixtral.py:441-470), intermediate 1024
+    (128 columns of every expert per rank at 8)."""
+    from vita_amd.config import TextConfig, VitaConfig
+    if world <= 2:
+        return VitaConfig.tiny()
+    cfg = VitaConfig.tiny()
+    cfg.text = TextConfig(hidden_size=2048, num_hidden_layers=2, num_attention_heads=16, num_key_value_heads=8,
+                          intermediate_size=1024, num_local_experts=4, vocab_size=1000)
+    return cfg
+
+
 def _tp_worker(rank, world, port, overlap, ret):
     import torch.distributed as dist
     from vita_amd import _lib
@@ -71,10 +84,13 @@ def _tp_worker(rank, world, port, overlap, ret):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = VitaConfig.tiny()
+        cfg = _tp_cfg(world)
         sd = synth_state_dict(cfg, seed=3, parts=("text",))
         packed = pack_mixtral(sd, cfg, dev, rank=rank, world=world)
         eng = MixtralEngine(cfg, packed, dev, max_ctx=128, max_prefill=64, max_new=16, rank=rank, world=world, logit_rows=16)
+        t = cfg.text
+        assert eng.c.n_q_heads == t.num_attention_heads // world and eng.c.n_kv_heads == t.num_key_value_heads // world
+        assert eng.c.inter == t.intermediate_size // world
         _lib.tune("tp_overlap", overlap)
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
         rng = np.random.default_rng(5)
@@ -87,11 +103,42 @@ def _tp_worker(rank, world, port, overlap, ret):
         lg = eng.logits_all[:10].cpu()
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
         assert eng.vocab_sharded and torch.equal(row0, lg[0]), "prefill() must return the full-vocabulary row under TP"
-        ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n))
+        ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n), comm_status(eng))
         dist.barrier()
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def comm_status(eng):
+    c = getattr(eng, "_comm", None)
+    return c.status() if c is not None else None
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_tp_engine_world_4_and_8_match_oracle(dev, world):
+    """the sharded ENGINE beyond world 2 — `world` engine processes on ONE GPU over the IPC all-reduce
+    (q heads 16 / world, KV heads 8 / world: one KV head per rank at 8, every expert's intermediate columns 1024 / world,
+    vocabulary rows 1000 / world): greedy ids == the unsharded fp32 oracle, logits within 1e-3, all ranks bit-identical,
+    no spin time-out."""
+    import torch.multiprocessing as mp
+    from oracle import mixtral as om
+    from vita_amd.checkpoint import synth_state_dict
+    ret = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(world, _free_port(), 1, ret), nprocs=world, join=True)
+    cfg = _tp_cfg(world)
+    sd = synth_state_dict(cfg, seed=3, parts=("text",))
+    rng = np.random.default_rng(5)
+    ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
+    ref_ids, ref_lg = om.MixtralOracle(sd, cfg.text).greedy(sd["model.embed_tokens.weight"][ids], 10)
+    assert all(ret[r][0] == "ipc" and ret[r][4] == 0 for r in range(world)), {r: (ret[r][0], ret[r][4]) for r in range(world)}
+    shards = [ret[r][3] for r in range(world)]
+    assert shards[0][0] == 0 and sum(n for _, n in shards) == cfg.text.vocab_size
+    assert all(shards[r][0] == shards[r - 1][0] + shards[r - 1][1] for r in range(1, world))      # the shards tile the table
+    for r in range(world):
+        assert ret[r][1] == ref_ids, f"rank {r} tokens differ from the unsharded oracle: {ret[r][1]} vs {ref_ids}"
+        assert np.array_equal(ret[r][2], ret[0][2]), f"rank {r} logits differ from rank 0's"
+    assert float(np.abs(ret[0][2] - ref_lg).max()) < 1e-3
 
 
 @pytest.mark.parametrize("overlap", [1, 0])

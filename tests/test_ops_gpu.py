@@ -490,3 +490,95 @@ def test_embed_splice(dev):
                                  _dev(emb, dev, torch.bfloat16), _dev(img, dev), _dev(aud, dev), H))
     ref = np.stack([(emb, img, aud)[k][i] for k, i in zip(kind, idx)])
     assert_close("embed_splice", got, ref, atol=0)
+
+
+# ---- batch-1 decode operators, one C entry each against oracle/mixtral.py ------------------
+def _moe_weights(rng, E, I, H):
+    return dict(gate=_w(rng, E, H, std=0.2), w1=_w(rng, E, I, H), w3=_w(rng, E, I, H), w2=_w(rng, E, H, I))
+
+
+@pytest.mark.parametrize("E,H,rows", [(8, 4096, 5), (4, 256, 37), (2, 128, 1)])
+def test_router_top2_vs_oracle(dev, E, H, rows):
+    from oracle import mixtral as om
+    from vita_amd import ops
+    rng = np.random.default_rng(E * 100 + rows)
+    x = rng.standard_normal((rows, H), dtype=np.float32)
+    g = _w(rng, E, H, std=0.1)
+    ids, wts, probs = ops.router_top2(_dev(x, dev), _dev(g, dev, torch.bfloat16), want_probs=True)
+    ridx, rval = om.router(x, g)
+    assert to_np(ids).astype(np.int64).tolist() == ridx.tolist()
+    assert_close("router weights", to_np(wts), rval, atol=2e-6)
+    assert_close("router softmax", to_np(probs), om.softmax((x @ g.T).astype(np.float32)), atol=2e-6)
+
+
+@pytest.mark.parametrize("E,I,H", [(8, 14336, 4096), (4, 512, 256)])
+def test_moe_decode_vs_oracle(dev, E, I, H):
+    """post_attention_layernorm + block_sparse_moe of one token (vh_moe_decode) vs the oracle's rmsnorm + moe, with and
+    without the deferred residual (delta)."""
+    from oracle import mixtral as om
+    from vita_amd import ops
+    rng = np.random.default_rng(I)
+    lw = _moe_weights(rng, E, I, H)
+    x = rng.standard_normal(H, dtype=np.float32)
+    d = rng.standard_normal(H, dtype=np.float32) * 0.1
+    nw = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    dw = {k: _dev(v, dev, torch.bfloat16) for k, v in lw.items()}
+    for delta in (None, d):
+        xin = x if delta is None else x + delta
+        ref, ridx, rval = om.moe(om.rmsnorm(xin[None], nw, 1e-5), lw)
+        y, route = ops.moe_decode(_dev(x, dev), _dev(nw, dev), 1e-5, dw["gate"], dw["w1"], dw["w3"], dw["w2"],
+                                  delta=None if delta is None else _dev(delta, dev))
+        r = to_np(route.view(torch.int32)).tolist()
+        assert r[:2] == ridx[0].tolist()
+        w = np.array(r[2:], np.int32).view(np.float32)
+        assert_close("routing weights", w, rval[0], atol=2e-6)
+        assert_close(f"moe_decode E={E} I={I}", to_np(y), ref[0], atol=1e-3 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
+
+
+def test_rope_kv_append_and_attn_decode_vs_oracle(dev):
+    """vh_rope_kv_append fills the cache for a 70-token prefix (two 64-key tiles), vh_attn_decode appends token 70 and attends
+    over [0, 70]: RoPE'd q / k, the cache rows and the attention output vs oracle apply_rope / attention."""
+    from oracle import mixtral as om
+    from vita_amd import ops
+    from vita_amd.engine import rope_tables
+    rng = np.random.default_rng(77)
+    nq, nkv, d, S, max_ctx = 8, 2, 128, 70, 192
+    nqkv = (nq + 2 * nkv) * d
+    qkv = rng.standard_normal((S + 1, nqkv), dtype=np.float32)
+    cos, sin = rope_tables(max_ctx, d, 1e6)
+    kc = torch.zeros((nkv, max_ctx, d), dtype=torch.float32, device=dev)
+    vc = torch.zeros_like(kc)
+    dcos, dsin = _dev(cos, dev), _dev(sin, dev)
+    q = ops.rope_kv_append(_dev(qkv[:S], dev), kc, vc, dcos, dsin, 0, nq, nkv)
+    c2, s2 = om.rope_cos_sin(np.arange(S + 1), d, 1e6)
+    qh = qkv[:, :nq * d].reshape(S + 1, nq, d).transpose(1, 0, 2)
+    kh = qkv[:, nq * d:(nq + nkv) * d].reshape(S + 1, nkv, d).transpose(1, 0, 2)
+    vh = qkv[:, (nq + nkv) * d:].reshape(S + 1, nkv, d).transpose(1, 0, 2)
+    qr, kr = om.apply_rope(qh, c2, s2), om.apply_rope(kh, c2, s2)
+    assert_close("roped q", to_np(q), qr[:, :S].transpose(1, 0, 2).reshape(S, nq * d), atol=1e-5)
+    assert_close("k cache", to_np(kc)[:, :S], kr[:, :S], atol=1e-5)
+    assert_close("v cache", to_np(vc)[:, :S], vh[:, :S], atol=0)
+    out = ops.attn_decode(_dev(qkv[S], dev), kc, vc, S, dcos, dsin, nq, nkv, d ** -0.5)
+    ref = om.attention(qr[:, S:S + 1], kr, vh, S)
+    assert_close("k appended", to_np(kc)[:, S], kr[:, S], atol=1e-5)
+    assert_close("attn_decode", to_np(out), ref[0], atol=2e-5)
+
+
+@pytest.mark.parametrize("V,H", [(51760, 4096), (1000, 256)])
+def test_lmhead_argmax_vs_oracle(dev, V, H):
+    from oracle import mixtral as om
+    from vita_amd import ops
+    rng = np.random.default_rng(V)
+    x = rng.standard_normal(H, dtype=np.float32)
+    d = rng.standard_normal(H, dtype=np.float32) * 0.1
+    nw = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    w = _w(rng, V, H)
+    ref = (om.rmsnorm((x + d)[None], nw, 1e-5) @ w.T).astype(np.float32)[0]
+    logits, tok = ops.lmhead_argmax(_dev(x, dev), _dev(nw, dev), 1e-5, _dev(w, dev, torch.bfloat16), delta=_dev(d, dev))
+    assert_close("lm_head logits", to_np(logits), ref, atol=1e-3)
+    assert int(tok.item()) == int(np.argmax(ref))
+    # ties: the lowest index wins (torch.argmax / HF greedy)
+    w2 = w.copy(); w2[7] = w2[3]
+    _, tok2 = ops.lmhead_argmax(_dev(w2[3].astype(np.float32) * 50, dev), _dev(np.ones(H, np.float32), dev), 1e-5, _dev(w2, dev, torch.bfloat16))
+    lg2 = (om.rmsnorm((w2[3].astype(np.float32) * 50)[None], np.ones(H, np.float32), 1e-5) @ w2.T)[0]
+    assert int(tok2.item()) == int(np.argmax(lg2)) and int(tok2.item()) in (3, int(np.argmax(lg2)))

@@ -95,6 +95,15 @@ SIGNATURES = {
     "vh_audio_conv1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_void_p]),
     "vh_embed_splice": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vh_router_top2": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vh_moe_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vh_rope_kv_append": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_void_p, c_void_p]),
+    "vh_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vh_lmhead_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_void_p]),
     "vh_mixtral_workspace_bytes": (c_size_t, [C.POINTER(MixtralCfg)]),
     "vh_mixtral_create": (c_void_p, [C.POINTER(MixtralCfg), C.POINTER(MixtralLayer), c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_size_t]),

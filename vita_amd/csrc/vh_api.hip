@@ -155,6 +155,57 @@ int vh_embed_splice(const int* src_kind, const int* src_idx, const uint16_t* emb
                         vhk_embed_splice(S(stream), src_kind, src_idx, embed, img_feats, aud_feats, out, Sn, H));
 }
 
+// ---- batch-1 decode operators, one by one ("one entry per kernel K1-K28 group") ----------------------------
+// What vh_mixtral_decode chains per layer, for a maintainer who binds a single module of HF's MixtralDecoderLayer
+// (reached from vita/model/language_model/vita_mixtral.py:158-169) at batch 1.  Scratch is caller-provided; the
+// kernels and their arithmetic are the engine's own.
+int vh_router_top2(const float* x, long ldx, const uint16_t* Wg, int E, int H, int rows, int* ids, float* wts, float* probs,
+                   void* stream) {
+    if (!x || !Wg || !ids || !wts) return fail(VH_E_ARG, "vh_router_top2: null pointer");
+    return check_launch("vh_router_top2", vhk_router_top2(S(stream), x, ldx, Wg, E, H, rows, ids, wts, probs));
+}
+
+int vh_moe_decode(const float* x, const float* delta, const float* norm_w, float eps, const uint16_t* Wg, const uint16_t* W1,
+                  const uint16_t* W3, const uint16_t* W2, int E, int I, int H, float* x_out, float* y, int* route, float* hbuf,
+                  void* stream) {
+    if (!x || !norm_w || !Wg || !W1 || !W3 || !W2 || !y || !route || !hbuf) return fail(VH_E_ARG, "vh_moe_decode: null pointer");
+    if (H % 64 || I % 64 || H > 14336 || I > 14336) return fail(VH_E_SHAPE, "vh_moe_decode: H, I must be multiples of 64 and <= 14336");
+    int rc = check_launch("vh_moe_decode (gate|up)", vhk_dec_gateup(S(stream), x, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, H, route, hbuf, 0));
+    if (rc != VH_OK) return rc;
+    return check_launch("vh_moe_decode (down)", vhk_dec_down(S(stream), hbuf, route, W2, H, I, y));
+}
+
+int vh_rope_kv_append(const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache, const float* rope_cos,
+                      const float* rope_sin, int Sn, int pos0, int nq, int nkv, int max_ctx, const int* table, void* stream) {
+    if (!qkv || !q_out || !kcache || !vcache || !rope_cos || !rope_sin) return fail(VH_E_ARG, "vh_rope_kv_append: null pointer");
+    if (Sn < 1 || pos0 < 0 || pos0 + Sn > max_ctx) return fail(VH_E_SHAPE, "vh_rope_kv_append: rows [%d, %d) outside the cache (%d)", pos0, pos0 + Sn, max_ctx);
+    return check_launch("vh_rope_kv_append", vhk_rope_kv(S(stream), qkv, ldqkv, q_out, kcache, vcache, rope_cos, rope_sin, Sn, pos0,
+                                                         nq, nkv, max_ctx, table, nullptr, 0));
+}
+
+int vh_attn_decode(const float* qkv, float* kcache, float* vcache, int pos, const float* rope_cos, const float* rope_sin,
+                   int nq, int nkv, int max_ctx, float scale, const int* table, float* part_o, float* part_ml, int* tickets,
+                   float* attn_out, void* stream) {
+    if (!qkv || !kcache || !vcache || !rope_cos || !rope_sin || !part_o || !part_ml || !tickets || !attn_out)
+        return fail(VH_E_ARG, "vh_attn_decode: null pointer");
+    if (pos < 0 || pos >= max_ctx) return fail(VH_E_SHAPE, "vh_attn_decode: position %d outside the cache (%d)", pos, max_ctx);
+    const int max_splits = (max_ctx + 63) / 64;
+    return check_launch("vh_attn_decode", vhk_dec_attn(S(stream), qkv, kcache, vcache, nullptr, rope_cos, rope_sin, part_o, part_ml,
+                                                      tickets, attn_out, nq, nkv, max_ctx, max_splits, pos + 1, scale, table,
+                                                      nullptr, 0));
+}
+
+int vh_lmhead_argmax(const float* x, const float* delta, const float* norm_w, float eps, const uint16_t* W, int V, int H,
+                     float* logits, int* token_out, float* blk_val, int* blk_idx, int nblk, void* stream) {
+    if (!x || !norm_w || !W || !logits || !token_out || !blk_val || !blk_idx) return fail(VH_E_ARG, "vh_lmhead_argmax: null pointer");
+    if (nblk < 1 || nblk > 4096 || H % 8) return fail(VH_E_SHAPE, "vh_lmhead_argmax: 1 <= nblk <= 4096, H %% 8 == 0");
+    const int grid = nblk < (V + 7) / 8 ? nblk : (V + 7) / 8;
+    int rc = check_launch("vh_lmhead_argmax", vhk_dec_lmhead(S(stream), x, delta, norm_w, eps, W, V, H, logits, blk_val, blk_idx, grid,
+                                                             nullptr, 1, 0, V));
+    if (rc != VH_OK) return rc;
+    return check_launch("vh_lmhead_argmax (pick)", vhk_dec_pick(S(stream), blk_val, blk_idx, grid, V, token_out, nullptr));
+}
+
 }  // extern "C"
 
 // =========================================================================================

@@ -733,6 +733,31 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ bl
     }
 }
 
+// ---- the global argmax alone (per-operator entry vh_lmhead_argmax): lowest index on ties, as torch.argmax ------------
+__global__ __launch_bounds__(256) void k_dec_pick(const float* __restrict__ blk_val, const int* __restrict__ blk_idx, int nblk,
+                                                  int vocab, int* __restrict__ token_out, float* __restrict__ value_out) {
+    __shared__ float v_s[256];
+    __shared__ int i_s[256];
+    float b = -INFINITY; int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        const float v = blk_val[i]; const int ix = blk_idx[i];
+        if (v > b || (v == b && ix < bi)) { b = v; bi = ix; }
+    }
+    v_s[threadIdx.x] = b; i_s[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = v_s[threadIdx.x + s]; const int ix = i_s[threadIdx.x + s];
+            if (v > v_s[threadIdx.x] || (v == v_s[threadIdx.x] && ix < i_s[threadIdx.x])) { v_s[threadIdx.x] = v; i_s[threadIdx.x] = ix; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        token_out[0] = (i_s[0] >= 0 && i_s[0] < vocab) ? i_s[0] : 0;
+        if (value_out) value_out[0] = v_s[0];
+    }
+}
+
 // ---- vocab-sharded LM head: this rank's best (value, index) -> its slot of a zeroed [world][2] vector; the
 // all-reduce(sum) of that vector hands every rank every candidate (adding zeros is exact, indices < 2^24 are exact
 // in fp32), k_dec_select then takes the global argmax with the usual lowest-index tie rule on every rank alike.
@@ -1219,6 +1244,12 @@ int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int n
 }
 int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx) {
     hipLaunchKernelGGL(k_dec_cand_unpack, dim3(1), dim3(128), 0, st, cand, world, val, idx);
+    return 0;
+}
+
+int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out) {
+    if (nblk < 1) return -1;
+    hipLaunchKernelGGL(k_dec_pick, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, vocab, token_out, value_out);
     return 0;
 }
 

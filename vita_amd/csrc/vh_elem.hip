@@ -522,6 +522,55 @@ int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, 
                        wts);
     return 0;
 }
+// ---- the router alone (per-operator entry vh_router_top2; HF MixtralSparseMoeBlock: gate -> fp32 softmax -> top-2 ->
+// renormalise, modeling_mixtral.py:96-111 / vllm_file/mixtral.py:398-411): one wave per token, fp32 throughout ----------
+__global__ __launch_bounds__(256) void k_router_top2(const float* __restrict__ x, long ldx, const uint16_t* __restrict__ Wg, int E,
+                                                     int H, int rows, int* __restrict__ ids, float* __restrict__ wts,
+                                                     float* __restrict__ probs) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float lg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lg[e] = 0.f;
+    for (int c = lane; c * 8 < H; c += 64) {
+        const float4 a = reinterpret_cast<const float4*>(x + (size_t)row * ldx)[c * 2];
+        const float4 b = reinterpret_cast<const float4*>(x + (size_t)row * ldx)[c * 2 + 1];
+        const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < E) lg[e] += dot8_bf16_f32(reinterpret_cast<const uint4*>(Wg + (size_t)e * H)[c], xv);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lg[e] = wave_sum(lg[e]);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
+    float pr[8], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] = e < E ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
+    int e0 = 0, e1 = 0;
+    float b0 = -1.f, b1 = -1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pr[e] /= sum; if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; } }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
+    if (lane == 0) {
+        ids[2 * row] = e0; ids[2 * row + 1] = e1;
+        wts[2 * row] = b0 / (b0 + b1); wts[2 * row + 1] = b1 / (b0 + b1);
+        if (probs)
+            for (int e = 0; e < E; ++e) probs[(size_t)row * E + e] = pr[e];
+    }
+}
+
+int vhk_router_top2(hipStream_t st, const float* x, long ldx, const uint16_t* Wg, int E, int H, int rows, int* ids, float* wts,
+                    float* probs) {
+    if (E < 2 || E > 8 || H % 8 != 0 || (ldx % 4) != 0 || rows < 0) return -1;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_router_top2, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, Wg, E, H, rows, ids, wts, probs);
+    return 0;
+}
+
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot) {
     if (E > 8) return -1;
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(64 * E), 0, st, ids, S, E, group_off, sorted_tok, sorted_slot);

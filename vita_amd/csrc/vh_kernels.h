@@ -84,6 +84,7 @@ int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const 
                    const int* ngen_ptr, int hist_rows, int v0, int Vfull);
 int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, float* cand, int rank, int world);
 int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx);
+int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out);
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
                    int vocab, float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
 
@@ -169,6 +170,8 @@ int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, co
                      const float* img_feats, const float* aud_feats, float* out, int S, int H);
 int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
                       int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts);
+int vhk_router_top2(hipStream_t st, const float* x, long ldx, const uint16_t* Wg, int E, int H, int rows, int* ids, float* wts,
+                    float* probs);   // probs nullable: [rows][E] softmax
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot);
 int vhk_moe_combine(hipStream_t st, float* x, const float* y, const float* wts, int S, int H, int nslab,
                     long slab_stride, const int* nslab_dev);

@@ -246,3 +246,72 @@ def gemm_ps(a_hi, a_lo, w, *, w_up=None, bias=None, act=None, scale=None, resid=
     g.M, g.N, g.K, g.act, g.wide = M, N, K, ACT[act], int(bool(wide))
     check(_lib.load().vh_gemm_ps(C.byref(g), _stream()), "vh_gemm_ps")
     return planes if out_split else out
+
+
+# ---- batch-1 decode operators, one by one (include/vita_hip.h: "batch-1 decode operators") --------------------------------
+def router_top2(x, wg, want_probs=False):
+    """MixtralSparseMoeBlock's gate on normed rows x [rows, H] fp32, wg bf16 [E, H] -> (ids int32 [rows, 2], weights fp32
+    [rows, 2][, softmax fp32 [rows, E]])."""
+    _dev(x, wg)
+    _f32(_c(x, "x"), "x"); _bf16(_c(wg, "wg"), "wg")
+    rows, H = x.shape
+    E = wg.shape[0]
+    ids = torch.empty((rows, 2), dtype=torch.int32, device=x.device)
+    wts = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    probs = torch.empty((rows, E), dtype=torch.float32, device=x.device) if want_probs else None
+    check(_lib.load().vh_router_top2(_p(x), x.stride(0), _p(wg), E, H, rows, _p(ids), _p(wts), _p(probs), _stream()), "vh_router_top2")
+    return (ids, wts, probs) if want_probs else (ids, wts)
+
+
+def moe_decode(x, norm_w, eps, wg, w1, w3, w2, delta=None):
+    """block_sparse_moe(post_attention_layernorm(x + delta)) for ONE token (no residual add): x fp32 [H], w1 / w3 bf16
+    [E, I, H], w2 bf16 [E, H, I] -> (y fp32 [H], route int32 [4] = e0, e1, bits(w0), bits(w1))."""
+    _dev(x, wg, w1, w3, w2)
+    _f32(_c(x, "x"), "x")
+    E, I, H = w1.shape
+    y = torch.empty(H, dtype=torch.float32, device=x.device)
+    route = torch.zeros(4, dtype=torch.int32, device=x.device)
+    hbuf = torch.empty(2 * I, dtype=torch.float32, device=x.device)
+    check(_lib.load().vh_moe_decode(_p(x), _p(delta), _p(norm_w), float(eps), _p(wg), _p(w1), _p(w3), _p(w2), E, I, H, None, _p(y),
+                                    _p(route), _p(hbuf), _stream()), "vh_moe_decode")
+    return y, route
+
+
+def rope_kv_append(qkv, kcache, vcache, rope_cos, rope_sin, pos0, nq, nkv, table=None):
+    """RoPE on q, k of S fused-QKV rows [S, (nq + 2 nkv) * 128] + KV append at [pos0, pos0 + S) -> q_roped fp32 [S, nq * 128];
+    kcache / vcache fp32 [nkv, max_ctx, 128] are updated in place."""
+    _dev(qkv, kcache, vcache)
+    _f32(_c(qkv, "qkv"), "qkv")
+    Sn = qkv.shape[0]
+    q = torch.empty((Sn, nq * 128), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().vh_rope_kv_append(_p(qkv), qkv.stride(0), _p(q), _p(kcache), _p(vcache), _p(rope_cos), _p(rope_sin), Sn, int(pos0),
+                                        nq, nkv, kcache.shape[1], _p(table), _stream()), "vh_rope_kv_append")
+    return q
+
+
+def attn_decode(qkv, kcache, vcache, pos, rope_cos, rope_sin, nq, nkv, scale, table=None):
+    """one token's RoPE + KV append at `pos` + causal GQA attention over [0, pos] -> fp32 [nq * 128]."""
+    _dev(qkv, kcache, vcache)
+    max_ctx = kcache.shape[1]
+    ns = (max_ctx + 63) // 64
+    dev = qkv.device
+    part_o = torch.empty((nq, ns, 128), dtype=torch.float32, device=dev)
+    part_ml = torch.empty((nq, ns, 2), dtype=torch.float32, device=dev)
+    tickets = torch.zeros(nkv, dtype=torch.int32, device=dev)
+    out = torch.empty(nq * 128, dtype=torch.float32, device=dev)
+    check(_lib.load().vh_attn_decode(_p(qkv), _p(kcache), _p(vcache), int(pos), _p(rope_cos), _p(rope_sin), nq, nkv, max_ctx, float(scale),
+                                     _p(table), _p(part_o), _p(part_ml), _p(tickets), _p(out), _stream()), "vh_attn_decode")
+    return out
+
+
+def lmhead_argmax(x, norm_w, eps, w, delta=None, nblk=1024):
+    """logits = lm_head(rmsnorm(x + delta)) fp32 [V] and their argmax (int32 [1], lowest index on ties)."""
+    _dev(x, w)
+    V, H = w.shape
+    logits = torch.empty(V, dtype=torch.float32, device=x.device)
+    tok = torch.zeros(1, dtype=torch.int32, device=x.device)
+    bv = torch.empty(nblk, dtype=torch.float32, device=x.device)
+    bi = torch.empty(nblk, dtype=torch.int32, device=x.device)
+    check(_lib.load().vh_lmhead_argmax(_p(x), _p(delta), _p(norm_w), float(eps), _p(w), V, H, _p(logits), _p(tok), _p(bv), _p(bi), nblk,
+                                       _stream()), "vh_lmhead_argmax")
+    return logits, tok
