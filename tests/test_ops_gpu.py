@@ -555,13 +555,15 @@ def test_rope_kv_append_and_attn_decode_vs_oracle(dev):
     kh = qkv[:, nq * d:(nq + nkv) * d].reshape(S + 1, nkv, d).transpose(1, 0, 2)
     vh = qkv[:, (nq + nkv) * d:].reshape(S + 1, nkv, d).transpose(1, 0, 2)
     qr, kr = om.apply_rope(qh, c2, s2), om.apply_rope(kh, c2, s2)
-    assert_close("roped q", to_np(q), qr[:, :S].transpose(1, 0, 2).reshape(S, nq * d), atol=1e-5)
-    assert_close("k cache", to_np(kc)[:, :S], kr[:, :S], atol=1e-5)
+    # (the engine's tables are built in fp32 from float32(theta) ** ..., the oracle's inv_freq in fp64 then rounded: HF's order;
+    # the angle differs by ~1e-6 relative at position 69: a few 1e-5 on values up to 4)
+    assert_close("roped q", to_np(q), qr[:, :S].transpose(1, 0, 2).reshape(S, nq * d), atol=5e-5)
+    assert_close("k cache", to_np(kc)[:, :S], kr[:, :S], atol=5e-5)
     assert_close("v cache", to_np(vc)[:, :S], vh[:, :S], atol=0)
     out = ops.attn_decode(_dev(qkv[S], dev), kc, vc, S, dcos, dsin, nq, nkv, d ** -0.5)
     ref = om.attention(qr[:, S:S + 1], kr, vh, S)
-    assert_close("k appended", to_np(kc)[:, S], kr[:, S], atol=1e-5)
-    assert_close("attn_decode", to_np(out), ref[0], atol=2e-5)
+    assert_close("k appended", to_np(kc)[:, S], kr[:, S], atol=5e-5)
+    assert_close("attn_decode", to_np(out), ref[0], atol=5e-5)
 
 
 @pytest.mark.parametrize("V,H", [(51760, 4096), (1000, 256)])
