@@ -187,7 +187,10 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* unique_id_128_bytes /* hos
  * device memory) and writes its 64-byte IPC handle to handle_out; the caller gathers the world's handles (any bootstrap:
  * torch.distributed, MPI, a file) and passes them, rank-major, to vh_comm_connect.  vh_comm_allreduce sums `count` fp32
  * values in place across the ranks (every rank must call it, in the same order, with the same count); results are
- * bit-identical on all ranks.  vh_comm_status: 0, or the phase whose bounded spin timed out. */
+ * bit-identical on all ranks.  vh_comm_status: 0, or the phase whose bounded spin timed out (sticky: once set, every
+ * later poll gives up at once).  vh_comm_create FAILS when fine-grained memory cannot be allocated, unless the caller
+ * declared that all ranks share one device (vh_tune("comm_allow_coarse", 1): same-device tests).  The 32-bit granule tag
+ * wraps every 2^32 calls; the library then re-zeroes its regions between two barriers (collective, same call on all ranks). */
 typedef struct vh_comm vh_comm_t;
 vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_out);
 int vh_comm_connect(vh_comm_t* c, const void* handles);
@@ -196,6 +199,8 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream);
 int vh_comm_status(vh_comm_t* c);
 void vh_comm_destroy(vh_comm_t* c);
 const char* vh_comm_last_error(void);
+int vh_comm_is_fine_grained(const vh_comm_t* c);              /* 1: the receive buffer is peer-coherent (required across devices) */
+int vh_comm_debug_set_calls(vh_comm_t* c, uint64_t calls);    /* tests: continue from this call count on EVERY rank (tag wrap at 2^32) */
 /* Route the engine's per-layer all-reduces through `c` (messages above its capacity keep using the RCCL / callback
  * collective installed before); null detaches it.  The engine does not own `c`. */
 int vh_mixtral_use_comm(vh_mixtral_t* m, vh_comm_t* c);

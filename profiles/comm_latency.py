@@ -18,7 +18,7 @@ def worker(rank, world, port, ret):
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    comm = IpcComm(rank, world, 1024 * 4096)
+    comm = IpcComm(rank, world, 1024 * 4096, same_device=True)
     handles = [None] * world
     dist.all_gather_object(handles, comm.handle)
     comm.connect(handles)

@@ -26,7 +26,7 @@ def _worker(rank, world, port, ret):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        comm = IpcComm(rank, world, 1 << 21)
+        comm = IpcComm(rank, world, 1 << 21, same_device=True)
         handles = [None] * world
         dist.all_gather_object(handles, comm.handle)
         comm.connect(handles)
@@ -42,6 +42,20 @@ def _worker(rank, world, port, ret):
             torch.cuda.synchronize()
             assert comm.status() == 0
             out[(it, n)] = (float((y.cpu() - ref).abs().max()), y.cpu().numpy().tobytes())
+        # the 32-bit granule tag wraps after 2^32 calls: jump every rank to just below it and cross it with mixed sizes
+        # (parity tracked separately from the tag, barrier + re-zero + barrier at the wrap)
+        assert comm.lib.vh_comm_debug_set_calls(comm.ptr, (1 << 32) - 3) == 0
+        dist.barrier()
+        for it, n in enumerate([4096, 70000, 4096, 4096, 1000, 4096]):
+            parts = [torch.randn(n, generator=torch.Generator(device="cpu").manual_seed(9000 + 100 * it + r)) for r in range(world)]
+            ref = parts[0].clone()
+            for p in parts[1:]:
+                ref += p
+            y = comm.allreduce(parts[rank].to(dev))
+            torch.cuda.synchronize()
+            assert comm.status() == 0
+            out[("wrap", it, n)] = (float((y.cpu() - ref).abs().max()), y.cpu().numpy().tobytes())
+        out[("fine_grained",)] = (0.0, bytes([int(comm.fine_grained)]))
         ret[rank] = out
         dist.barrier()
         comm.destroy()

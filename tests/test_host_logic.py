@@ -313,3 +313,20 @@ def test_video_front_end_matches_reference_function(tmp_path):
         for k in [k for k in sys.modules if mine(k)]:
             sys.modules.pop(k)
         sys.modules.update(saved)
+
+
+def test_asset_tiles_through_the_host_image_processor():
+    """the reference's own asset (asset/vita_log2.png -> 5 tiles by ITS dynamic_preprocess, tests/golden/assets_request.npz):
+    the product's CLIP-style processor reproduces HF CLIPImageProcessor's pixel tensor on them (corner patch + per-tile
+    mean recorded by oracle/make_golden_assets.py) — the host half of the released-geometry assets request of
+    tests/test_assets_gpu.py."""
+    from PIL import Image
+    from vita_amd.host.image_processing import make_image_processor
+    g = np.load(os.path.join(GOLD, "assets_request.npz"))
+    tiles = [Image.fromarray(t) for t in g["tiles"]]
+    assert len(tiles) == 5 and tiles[0].size == (448, 448)
+    pix = make_image_processor(448).preprocess(tiles, return_tensors="np")["pixel_values"]
+    pix = np.asarray(pix, np.float32)
+    assert pix.shape == (5, 3, 448, 448)
+    np.testing.assert_allclose(pix[:, :, :8, :8], g["pix_check"], atol=1e-6)
+    np.testing.assert_allclose(pix.mean(axis=(1, 2, 3)), g["pix_mean"], atol=1e-6)

@@ -118,6 +118,8 @@ SIGNATURES = {
     "vh_comm_status": (c_int, [c_void_p]),
     "vh_comm_destroy": (None, [c_void_p]),
     "vh_comm_last_error": (C.c_char_p, []),
+    "vh_comm_debug_set_calls": (c_int, [c_void_p, C.c_uint64]),
+    "vh_comm_is_fine_grained": (c_int, [c_void_p]),
     "vh_mixtral_use_comm": (c_int, [c_void_p, c_void_p]),
     "vh_mixtral_cancel_rccl": (c_int, [c_void_p]),
     "vh_mixtral_route_debug": (c_int, [c_void_p, c_void_p]),

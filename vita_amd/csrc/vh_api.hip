@@ -64,6 +64,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "tp_overlap")) { g_tuning.tp_overlap = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     if (!strcmp(key, "ws_pad")) { g_tuning.ws_pad = value; return VH_OK; }
+    if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 

@@ -25,6 +25,7 @@
 
 #include "../../include/vita_hip.h"
 #include "vh_common.h"
+#include "vh_kernels.h"
 
 #define VH_COMM_MAX_WORLD 8
 #define VH_COMM_ONESHOT_MAX 32768          // elements: 256 KB of granules per peer slot
@@ -38,9 +39,16 @@ struct vh_comm {
     uint64_t* peer[VH_COMM_MAX_WORLD];       // every rank's buffer as mapped here (peer[rank] == local)
     bool opened[VH_COMM_MAX_WORLD];
     int* err;                                // device error word
-    uint32_t epoch;
+    uint64_t calls;                          // all-reduces issued (every rank counts the same calls: the API is collective)
+    uint32_t generation;                     // tag wraps survived (barrier tags)
     bool connected;
+    bool fine_grained;                       // the receive buffer is uncached / coherent for peer stores
 };
+// buffer layout (granules): [2 parity regions][2 barrier rows of VH_COMM_MAX_WORLD].  The 32-bit tag of a call is the low
+// word of the call counter (0 is skipped: "never written"); the parity region is the counter's low bit, tracked
+// SEPARATELY from the tag, so consecutive calls always alternate regions even across a tag wrap.  When the tag wraps
+// (2^32 calls: days of serving) every rank runs the same re-initialisation at the same call: barrier, zero both regions,
+// barrier — a granule left from 2^32 calls ago can then never match a new tag.
 
 namespace {
 
@@ -51,11 +59,14 @@ __device__ __forceinline__ void put(uint64_t* p, uint32_t tag, float v) {
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // poll one granule until its tag is `tag`; returns the value (0 and *err = code on time-out)
+// A time-out (dead peer) is sticky: once the error word is set every later poll of every kernel gives up after ONE look,
+// so a lost peer costs one spin limit in all, not one per granule.
 __device__ __forceinline__ float get(const uint64_t* p, uint32_t tag, int* err, int code) {
     unsigned spins = 0;
     for (;;) {
         const u64 x = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((uint32_t)(x >> 32) == tag) return __uint_as_float((uint32_t)x);
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0.f;
         if (++spins > VH_COMM_SPIN_LIMIT) {
             __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return 0.f;
@@ -100,6 +111,13 @@ __global__ __launch_bounds__(256) void k_ar_twoshot(float* __restrict__ buf, lon
     for (long i = t0; i < count; i += nthr) buf[i] = get(local + (size_t)world * slice + i, tag, err, 3);
 }
 
+// all ranks have reached this point of their streams: rank r raises row[r] in every peer's barrier row, then waits for all
+__global__ void k_comm_barrier(Peers bars, uint64_t* local_bar, int rank, int world, uint32_t tag, int* err) {
+    const int t = threadIdx.x;
+    if (t < world) put(bars.p[t] + rank, tag, 0.f);
+    if (t < world) (void)get(local_bar + t, tag, err, 4);
+}
+
 thread_local char g_cerr[256] = "";
 int cfail(int code, const char* msg, hipError_t e = hipSuccess) {
     if (e != hipSuccess) snprintf(g_cerr, sizeof(g_cerr), "%s: %s", msg, hipGetErrorString(e));
@@ -107,11 +125,34 @@ int cfail(int code, const char* msg, hipError_t e = hipSuccess) {
     return code;
 }
 
+// tag wrap: barrier (everybody finished every earlier all-reduce) -> zero both parity regions -> barrier (nobody pushes a
+// new tag into a region that is not zeroed yet).  Barrier rows use the generation counter as their tag.
+int comm_rewind(vh_comm* c, hipStream_t st) {
+    for (int phase = 0; phase < 2; ++phase) {
+        c->generation += 1;
+        Peers bars{};
+        for (int r = 0; r < c->world; ++r) bars.p[r] = c->peer[r] + 2 * c->region + (size_t)phase * VH_COMM_MAX_WORLD;
+        hipLaunchKernelGGL(k_comm_barrier, dim3(1), dim3(64), 0, st, bars, c->local + 2 * c->region + (size_t)phase * VH_COMM_MAX_WORLD,
+                           c->rank, c->world, c->generation, c->err);
+        if (phase == 0 && hipMemsetAsync(c->local, 0, 2 * c->region * sizeof(uint64_t), st) != hipSuccess)
+            return cfail(VH_E_HIP, "vh_comm: re-zero at the tag wrap failed");
+    }
+    return VH_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* vh_comm_last_error(void) { return g_cerr; }
+
+// tests: continue from a given call count (e.g. 2^32 - 3 to cross the tag wrap); every rank must set the same value
+int vh_comm_debug_set_calls(vh_comm_t* c, uint64_t calls) {
+    if (!c) return VH_E_ARG;
+    c->calls = calls;
+    return VH_OK;
+}
+int vh_comm_is_fine_grained(const vh_comm_t* c) { return c && c->fine_grained ? 1 : 0; }
 
 vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_out) {
     if (rank < 0 || world < 2 || world > VH_COMM_MAX_WORLD || rank >= world || cap_elems == 0 || !handle_out) {
@@ -124,10 +165,19 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     const size_t oneshot = (size_t)world * (cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX);
     const size_t twoshot = 2 * cap_elems + 2 * (size_t)world;
     c->region = oneshot > twoshot ? oneshot : twoshot;
-    const size_t bytes = 2 * c->region * sizeof(uint64_t);
+    const size_t bytes = (2 * c->region + 2 * VH_COMM_MAX_WORLD) * sizeof(uint64_t);
     hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->local), bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) {   // (same-device tests do not need the coherent flavour)
+    c->fine_grained = e == hipSuccess;
+    if (e != hipSuccess) {
+        // A coarse-grained buffer is only correct when every rank sits on THIS device (same-device tests): across
+        // devices a peer's stores may never become visible to a spinning kernel — refuse instead of timing out later.
         (void)hipGetLastError();
+        if (!vh_tuning()->comm_allow_coarse) {
+            cfail(VH_E_COMM, "vh_comm_create: fine-grained (peer-coherent) device memory is not available and the ranks are "
+                             "not declared to share one device (vh_tune(\"comm_allow_coarse\", 1))", e);
+            delete c;
+            return nullptr;
+        }
         e = hipMalloc(reinterpret_cast<void**>(&c->local), bytes);
     }
     if (e != hipSuccess) { cfail(VH_E_HIP, "vh_comm_create: buffer allocation", e); delete c; return nullptr; }
@@ -144,7 +194,8 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     memcpy(handle_out, &h, sizeof(h));
     c->peer[rank] = c->local;
-    c->epoch = 0;
+    c->calls = 0;
+    c->generation = 0;
     return c;
 }
 
@@ -172,22 +223,29 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
     if (count < 0 || (size_t)count > c->cap) return cfail(VH_E_SHAPE, "vh_comm_allreduce: message above the capacity");
     if (count == 0) return VH_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    c->epoch += 1;
-    if (c->epoch == 0) c->epoch = 1;                       // tag 0 = never written
-    uint64_t* local = c->local + (size_t)(c->epoch & 1) * c->region;
+    c->calls += 1;
+    uint32_t tag = (uint32_t)c->calls;
+    if (tag == 0) {                                        // the tag wrapped: same call on every rank (collective API)
+        const int rc = comm_rewind(c, st);
+        if (rc != VH_OK) return rc;
+        c->calls += 1;                                     // tag 0 means "never written": skip it (keeps the parity alternating
+        tag = (uint32_t)c->calls;                          // only approximately here, which is safe right after the re-zero)
+    }
+    const size_t par = (size_t)(c->calls & 1);
+    uint64_t* local = c->local + par * c->region;
     Peers peers{};
-    for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r] + (size_t)(c->epoch & 1) * c->region;
+    for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r] + par * c->region;
     if (count <= VH_COMM_ONESHOT_MAX) {
         const size_t cap1 = c->cap < VH_COMM_ONESHOT_MAX ? c->cap : VH_COMM_ONESHOT_MAX;
         const int grid = (int)((count + 255) / 256);
         hipLaunchKernelGGL(k_ar_oneshot, dim3(grid), dim3(256), 0, st, buf, count, peers, local, cap1, c->rank, c->world,
-                           c->epoch, c->err);
+                           tag, c->err);
     } else {
         const long slice = (count + c->world - 1) / c->world;
         long g = (count + 255) / 256;
         if (g > 128) g = 128;                              // fully resident next to the compute stream's kernels
         hipLaunchKernelGGL(k_ar_twoshot, dim3((int)g), dim3(256), 0, st, buf, count, peers, local, slice, c->rank, c->world,
-                           c->epoch, c->err);
+                           tag, c->err);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cfail(VH_E_HIP, "vh_comm_allreduce: launch", e);

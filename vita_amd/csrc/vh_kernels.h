@@ -34,6 +34,8 @@ struct VhTuning {
     int tp_overlap = 1;       // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
     int moe_ksplit = -4;      // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
+    int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
+                               // fine-grained allocation fails (same-device tests); 0 = fail loudly instead
     int ws_pad = 0;          // experiments: 64-KB units of padding in front of the engine workspace (placement sensitivity sweeps)
 };
 VhTuning* vh_tuning();

@@ -63,9 +63,12 @@ class IpcComm:
     """The library's own all-reduce over IPC-mapped peer buffers (include/vita_hip.h vh_comm_*): create on every rank,
     exchange the 64-byte handles through any bootstrap channel, connect, then allreduce(tensor) in lock step."""
 
-    def __init__(self, rank, world, cap_elems):
+    def __init__(self, rank, world, cap_elems, same_device=False):
+        """same_device: every rank runs on ONE GPU (tests): only then may the library fall back to a coarse-grained receive
+        buffer when fine-grained (peer-coherent) memory cannot be allocated; across devices it refuses instead."""
         from . import _lib
         self.lib = _lib.load()
+        _lib.tune("comm_allow_coarse", 1 if same_device else 0)
         self._handle = ctypes.create_string_buffer(64)
         self.rank, self.world = int(rank), int(world)
         self.ptr = self.lib.vh_comm_create(self.rank, self.world, int(cap_elems), self._handle)
@@ -99,10 +102,24 @@ class IpcComm:
     def status(self):
         return int(self.lib.vh_comm_status(self.ptr))
 
+    @property
+    def fine_grained(self):
+        return bool(self.lib.vh_comm_is_fine_grained(self.ptr))
+
     def destroy(self):
         if self.ptr:
             self.lib.vh_comm_destroy(self.ptr)
             self.ptr = None
+
+
+def ranks_share_one_device(dist, device, world):
+    """True when every rank of the group drives the same physical GPU (same host, same visible-device list, same index)."""
+    import socket
+    me = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""),
+          os.environ.get("CUDA_VISIBLE_DEVICES", ""), torch.device(device).index or 0)
+    all_ = [None] * world
+    dist.all_gather_object(all_, me)
+    return all(a == all_[0] for a in all_)
 
 
 def ipc_allreduce(eng, rank, world, dist, device, backend):
@@ -110,7 +127,7 @@ def ipc_allreduce(eng, rank, world, dist, device, backend):
     rank's self-test passed (the engine then routes its all-reduces through it)."""
     comm, ok = None, 0
     try:
-        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden)
+        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden, same_device=ranks_share_one_device(dist, device, world))
         handles = [None] * world
         dist.all_gather_object(handles, comm.handle)
         comm.connect(handles)
