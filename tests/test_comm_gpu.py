@@ -86,7 +86,7 @@ def _tp_cfg(world):
     return cfg
 
 
-def _tp_worker(rank, world, port, overlap, ret):
+def _tp_worker(rank, world, port, overlap, ret, fuse=1):
     import torch.distributed as dist
     from vita_amd import _lib
     from vita_amd.checkpoint import pack_mixtral, synth_state_dict
@@ -94,6 +94,7 @@ def _tp_worker(rank, world, port, overlap, ret):
     from vita_amd.engine import MixtralEngine
     from vita_amd.parallel import setup_tensor_parallel
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["VITA_AMD_TP_FUSE"] = str(int(fuse))   # 1: the exchange fused into the decode kernels (what a GPU per rank runs)
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -161,18 +162,20 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     assert float(np.abs(ret[0][2] - ref_lg).max()) < 1e-3
 
 
-@pytest.mark.parametrize("overlap", [1, 0])
-def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap):
+@pytest.mark.parametrize("overlap,fuse", [(1, 1), (0, 1), (1, 0)])
+def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
     """two engine processes (TP = 2, one GPU) with the IPC all-reduce installed by setup_tensor_parallel: greedy ids
     equal the unsharded fp32 oracle's, logits within 1e-3, both ranks identical.  overlap = 1: the prefill's
     o_proj / MoE-down GEMMs run as column halves with the all-reduce of one half on the comm stream under the GEMM of
-    the other (the default); 0: one all-reduce per sub-block on the compute stream."""
+    the other (the default); 0: one all-reduce per sub-block on the compute stream.  fuse = 1: the DECODE exchanges are fused
+    into the producer / consumer kernels (VhXchg: pushes from the O / down projections, reduction by the first blocks of the
+    next kernel — the form a GPU per rank runs); 0: one all-reduce kernel per exchange (r02, the same-device default)."""
     import torch.multiprocessing as mp
     from oracle import mixtral as om
     from vita_amd.checkpoint import synth_state_dict
     from vita_amd.config import VitaConfig
     ret = mp.Manager().dict()
-    mp.spawn(_tp_worker, args=(2, _free_port(), overlap, ret), nprocs=2, join=True)
+    mp.spawn(_tp_worker, args=(2, _free_port(), overlap, ret, fuse), nprocs=2, join=True)
     cfg = VitaConfig.tiny()
     sd = synth_state_dict(cfg, seed=3, parts=("text",))
     rng = np.random.default_rng(5)

@@ -65,6 +65,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     if (!strcmp(key, "ws_pad")) { g_tuning.ws_pad = value; return VH_OK; }
     if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
+    if (!strcmp(key, "tp_fuse")) { g_tuning.tp_fuse = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -619,7 +620,8 @@ static int launch_failed(const char* what) {
     if (e != hipSuccess) return fail(VH_E_HIP, "%s: %s", what, hipGetErrorString(e));
     return fail(VH_E_SHAPE, "%s: launch rejected (shape / arguments)", what);
 }
-static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos);
+static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos,
+                           const VhXchg* cx = nullptr);
 #define VH_TRY(expr, what)                             \
     do {                                               \
         if ((expr) != 0) return launch_failed(what);   \
@@ -878,10 +880,11 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
 // Final norm + LM head + greedy selection.  Vocab-sharded head: every rank scores its rows, the (max, index) candidates
 // travel through the all-reduce hook, every rank takes the same global argmax; when scores are kept (logit_rows > 1)
 // the full row is assembled by an all-reduce of the zero-filled slices.
-static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos) {
+static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos,
+                           const VhXchg* cx) {
     const bool sharded = m->c.vocab_n > 0 && m->c.tp_world > 1;
     VH_TRY(vhk_dec_lmhead(st, x_in, delta, m->final_norm, m->c.rms_eps, m->lm_head, m->Vn, m->H, m->logits, m->blk_val,
-                          m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows(), m->v0, m->V), "lm_head");
+                          m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows(), m->v0, m->V, cx), "lm_head");
     int nblk = m->lm_grid;
     if (sharded) {
         VH_TRY(vhk_dec_cand(st, m->blk_val, m->blk_idx, m->lm_grid, m->cand, m->c.tp_rank, m->c.tp_world), "candidates");
@@ -901,12 +904,21 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
     *epoch_inc = 0;
+    // Tensor parallel over the library's IPC transport: the two all-reduces of a layer are FUSED into the kernels around
+    // them (VhXchg, vh_kernels.h): the O projection / MoE down projection push their partial outputs straight into the
+    // peers' receive slots, the first blocks of the next kernel (gate|up, next layer's QKV, LM head) sum the slots and every
+    // block of it waits for that sum behind its own weight loads — "all-reduce over xGMI overlapped with the expert GEMMs"
+    // (web_demo/vllm_tools/vllm_file/mixtral.py:405-414,470-476), 65 kernel launches per token fewer than r02.
+    const bool fuse = m->comm != nullptr && m->c.tp_world > 1 && vh_tuning()->tp_fuse != 0 && (H % 2) == 0 &&
+                      (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->fuse_attn_oproj && !vh_tuning()->force_allreduce;
+    VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
+    bool have_xm = false;
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
         VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
-                           m->qkv), "dec qkv");
+                           m->qkv, have_xm ? &xm : nullptr), "dec qkv");
         int fused = 1;
         if (vh_tuning()->fuse_attn_oproj) {
             fused = vhk_dec_attn_oproj(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o,
@@ -920,19 +932,28 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
             VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
                                 m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
                                 scale, m->table, w.wo, (size_t)H * nq * hd * 2), "dec attn");
-            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn), "dec oproj");
+            if (fuse && vh_comm_xchg_next(m->comm, H, 0, vhk_dec_consumer_blocks(1, 0, H, I), &xa, st) != VH_OK)
+                return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
+            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
         }
-        if (m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        if (!fuse && m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
         VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
-                              m->route, m->hbuf, 0), "dec gateup");
+                              m->route, m->hbuf, 0, fuse ? &xa : nullptr), "dec gateup");
         if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-        VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe), "dec down");
-        if (m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        if (fuse) {
+            // the consumer of this exchange is the next layer's QKV GEMV, or the LM head after the last layer
+            const int blocks = l + 1 < m->c.n_layers ? vhk_dec_consumer_blocks(0, m->nqkv, H, I) : m->lm_grid;
+            if (vh_comm_xchg_next(m->comm, H, 1, blocks, &xm, st) != VH_OK)
+                return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
+            have_xm = true;
+        }
+        VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, fuse ? &xm : nullptr), "dec down");
+        if (!fuse && m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
     }
     {
-        const int rc = head_and_select(m, st, m->xa, m->delta_moe, /*mode=*/1, /*set_pos=*/0);
+        const int rc = head_and_select(m, st, m->xa, m->delta_moe, /*mode=*/1, /*set_pos=*/0, have_xm ? &xm : nullptr);
         if (rc != VH_OK) return rc;
     }
     const hipError_t e = hipGetLastError();   // checked per step: the mirrors below must not run ahead of a failed launch

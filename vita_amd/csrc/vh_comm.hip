@@ -43,6 +43,10 @@ struct vh_comm {
     uint32_t generation;                     // tag wraps survived (barrier tags)
     bool connected;
     bool fine_grained;                       // the receive buffer is uncached / coherent for peer stores
+    // exchanges fused into the decode kernels (VhXchg): two result vectors (attention / MoE sub-block), the reducers' arrival counter
+    float* reduced[2];
+    int* counter;
+    unsigned arrivals;                       // host mirror: reducer blocks that will have arrived when every issued exchange is done
 };
 // buffer layout (granules): [2 parity regions][2 barrier rows of VH_COMM_MAX_WORLD].  The 32-bit tag of a call is the low
 // word of the call counter (0 is skipped: "never written"); the parity region is the counter's low bit, tracked
@@ -181,8 +185,11 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
         e = hipMalloc(reinterpret_cast<void**>(&c->local), bytes);
     }
     if (e != hipSuccess) { cfail(VH_E_HIP, "vh_comm_create: buffer allocation", e); delete c; return nullptr; }
-    if ((e = hipMemset(c->local, 0, bytes)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void**>(&c->err), sizeof(int))) != hipSuccess ||
-        (e = hipMemset(c->err, 0, sizeof(int))) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+    const size_t red_elems = cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX;
+    if ((e = hipMemset(c->local, 0, bytes)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void**>(&c->err), 2 * sizeof(int))) != hipSuccess ||
+        (e = hipMemset(c->err, 0, 2 * sizeof(int))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->reduced[0]), 2 * ((red_elems + 63) & ~size_t(63)) * sizeof(float))) != hipSuccess ||
+        (e = hipDeviceSynchronize()) != hipSuccess) {
         cfail(VH_E_HIP, "vh_comm_create: initialisation", e);
         hipFree(c->local); delete c; return nullptr;
     }
@@ -196,6 +203,9 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     c->peer[rank] = c->local;
     c->calls = 0;
     c->generation = 0;
+    c->reduced[1] = c->reduced[0] + ((red_elems + 63) & ~size_t(63));
+    c->counter = c->err + 1;
+    c->arrivals = 0;
     return c;
 }
 
@@ -252,6 +262,45 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
     return VH_OK;
 }
 
+}  // extern "C"
+
+// One all-reduce fused into the decode kernels: advances the call counter exactly as vh_comm_allreduce does (the two kinds
+// interleave freely) and describes the exchange for the producer and the consumer launch.  `which` picks the result vector
+// (0 attention sub-block, 1 MoE sub-block); `consumer_blocks` bounds the reducer count.  Not part of the public C ABI.
+int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, VhXchg* out, void* stream) {
+    if (!c || !out || !c->connected) return cfail(VH_E_COMM, "vh_comm_xchg_next: not connected");
+    const size_t cap1 = c->cap < VH_COMM_ONESHOT_MAX ? c->cap : VH_COMM_ONESHOT_MAX;
+    if (count < 2 || (count & 1) || (size_t)count > cap1 || consumer_blocks < 1 || which < 0 || which > 1)
+        return cfail(VH_E_SHAPE, "vh_comm_xchg_next: fused exchanges carry an even count within the one-shot capacity");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    c->calls += 1;
+    uint32_t tag = (uint32_t)c->calls;
+    if (tag == 0) {
+        const int rc = comm_rewind(c, st);
+        if (rc != VH_OK) return rc;
+        c->calls += 1;
+        tag = (uint32_t)c->calls;
+    }
+    const size_t par = (size_t)(c->calls & 1);
+    VhXchg x{};
+    for (int r = 0; r < c->world; ++r) x.peer[r] = c->peer[r] + par * c->region;
+    x.local = c->local + par * c->region;
+    x.reduced = c->reduced[which];
+    x.counter = c->counter;
+    x.err = c->err;
+    x.cap = cap1;
+    x.rank = c->rank; x.world = c->world; x.tag = tag;
+    x.nred = consumer_blocks < 16 ? consumer_blocks : 16;
+    if (x.nred > (int)(count / 2)) x.nred = (int)(count / 2);
+    c->arrivals += x.nred;
+    x.target = (int)c->arrivals;                 // compared modulo 2^32 on the device
+    x.count = (int)count;
+    *out = x;
+    return VH_OK;
+}
+
+extern "C" {
+
 int vh_comm_status(vh_comm_t* c) {
     if (!c) return -1;
     int v = 0;
@@ -265,6 +314,7 @@ void vh_comm_destroy(vh_comm_t* c) {
         if (c->opened[r]) hipIpcCloseMemHandle(c->peer[r]);
     hipFree(c->local);
     hipFree(c->err);
+    hipFree(c->reduced[0]);
     delete c;
 }
 

@@ -33,6 +33,67 @@
 
 namespace {
 
+// ---- tensor-parallel exchange fused into the kernels (VhXchg, vh_kernels.h) ---------------------------------------------
+typedef unsigned long long xu64;
+#define VH_XCHG_SPIN_LIMIT (1u << 26)
+// producer: element n of my partial vector -> slot `rank` of every rank's receive region (the data is the flag)
+__device__ __forceinline__ void xchg_put(const VhXchg& px, int n, float v) {
+    const xu64 g = ((xu64)px.tag << 32) | (xu64)__float_as_uint(v);
+    for (int p = 0; p < px.world; ++p)
+        __hip_atomic_store(reinterpret_cast<xu64*>(px.peer[p] + (size_t)px.rank * px.cap + n), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float xchg_get(const uint64_t* p, unsigned tag, int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
+        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0.f;
+        if (++spins > VH_XCHG_SPIN_LIMIT) { __hip_atomic_store(err, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0.f; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// consumer, step 1 (BEFORE the block's own weight loads, so that nothing of its own is queued in front of the polls): the
+// first nred blocks sum their slice over the ranks, in rank order, and publish it
+__device__ __forceinline__ void xchg_reduce(const VhXchg& cx) {
+    if (cx.world == 0 || (int)blockIdx.x >= cx.nred) return;
+    const int pairs = cx.count >> 1;
+    const int per = (pairs + cx.nred - 1) / cx.nred;
+    const int p1 = min(pairs, ((int)blockIdx.x + 1) * per);
+    for (int q = blockIdx.x * per + threadIdx.x; q < p1; q += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = 0; r < cx.world; ++r) {
+            s0 += xchg_get(cx.local + (size_t)r * cx.cap + 2 * q, cx.tag, cx.err);
+            s1 += xchg_get(cx.local + (size_t)r * cx.cap + 2 * q + 1, cx.tag, cx.err);
+        }
+        __hip_atomic_store(reinterpret_cast<xu64*>(cx.reduced) + q, ((xu64)__float_as_uint(s1) << 32) | (xu64)__float_as_uint(s0),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my slice has left this CU
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cx.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer, step 2 (AFTER the weight loads are in flight): the summed vector is complete
+__device__ __forceinline__ void xchg_wait(const VhXchg& cx) {
+    if (cx.world == 0) return;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while ((int)((unsigned)__hip_atomic_load(cx.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)cx.target) < 0) {   // modulo 2^32
+            if (++spins > VH_XCHG_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(cx.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(cx.err, 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+// 4 floats of a vector another CU (possibly on another XCD) published with agent-scope atomics: two 8-byte agent-scope loads
+__device__ __forceinline__ f32x4 xchg_ld4(const float* p) {
+    const xu64 a = __hip_atomic_load(reinterpret_cast<const xu64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const xu64 b = __hip_atomic_load(reinterpret_cast<const xu64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
+}
+
 // ---- activation slice handling ------------------------------------------------------
 template <int NJ>
 __device__ __forceinline__ void load_x(const float* __restrict__ x, int K, float (&xr)[NJ][8]) {
@@ -58,7 +119,7 @@ __device__ __forceinline__ void load_x(const float* __restrict__ x, int K, float
 template <int NJ>
 __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
-                                               float (&xr)[NJ][8]) {
+                                               float (&xr)[NJ][8], const bool coherent = false) {
     f32x4 xa[NJ][2], da[NJ][2], na[NJ][2];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -68,7 +129,10 @@ __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, c
         xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
         na[j][0] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2];
         na[j][1] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + 1];
-        if (delta) {   // block-uniform
+        if (delta && coherent) {   // block-uniform: the vector was published by other CUs of this launch (xchg_reduce)
+            da[j][0] = xchg_ld4(delta + (size_t)cc * 8);
+            da[j][1] = xchg_ld4(delta + (size_t)cc * 8 + 4);
+        } else if (delta) {
             da[j][0] = reinterpret_cast<const f32x4*>(delta)[cc * 2];
             da[j][1] = reinterpret_cast<const f32x4*>(delta)[cc * 2 + 1];
         } else {
@@ -128,8 +192,10 @@ template <int NJ, int R, bool NORM>
 __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                   float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                   float eps, const uint16_t* __restrict__ W, int N, int K,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, const VhXchg xc) {
+    // xc: NORM = true: consumer of a fused exchange (delta = xc.reduced); NORM = false: producer (outputs are pushed)
     __shared__ float red[4 * (R + 1)];
+    if (NORM) xchg_reduce(xc);
     const int n0 = blockIdx.x * R;
     const uint16_t* rows[R];
 #pragma unroll
@@ -140,7 +206,8 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
     float xr[NJ][8];
     float vals[R + 1];
     if (NORM) {
-        vals[R] = load_add_norm<NJ>(x_in, delta, norm_w, x_out, K, xr);
+        xchg_wait(xc);
+        vals[R] = load_add_norm<NJ>(x_in, xc.world ? xc.reduced : delta, norm_w, x_out, K, xr, xc.world != 0);
     } else {
         load_x<NJ>(x_in, K, xr);
         vals[R] = 0.f;
@@ -155,7 +222,8 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = vals[r];
-        out[n0 + threadIdx.x] = v * inv;
+        if (!NORM && xc.world) xchg_put(xc, n0 + threadIdx.x, v * inv);
+        else out[n0 + threadIdx.x] = v * inv;
     }
 }
 
@@ -434,11 +502,12 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
                                                     float eps, const uint16_t* __restrict__ Wg, int E,
                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
                                                     int I, int K, int* __restrict__ route_out,
-                                                    float* __restrict__ hbuf) {
+                                                    float* __restrict__ hbuf, const VhXchg cx) {
     __shared__ float red[4 * 9];
     float xr[NJ][8];
     float inv;
     int e0 = 0, e1 = 0;
+    xchg_reduce(cx);
     {
         const uint16_t* rrows[8];
 #pragma unroll
@@ -446,7 +515,8 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
         uint4 wr[8][NJ];
         gemv_issue<NJ, 8>(rrows, K, wr);
         float vals[9];
-        vals[8] = load_add_norm<NJ>(x_in, delta, norm_w, x_out, K, xr);
+        xchg_wait(cx);
+        vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
 #pragma unroll
@@ -531,7 +601,7 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
 template <int NJ, int R>
 __global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf, const int* __restrict__ route,
                                                   const uint16_t* __restrict__ W2, int N, int I,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, const VhXchg px) {
     __shared__ float red[4 * R];
     const int e0 = route[0], e1 = route[1];
     const float w0 = __int_as_float(route[2]), w1 = __int_as_float(route[3]);
@@ -569,7 +639,8 @@ __global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = tot[r];
-        out[n0 + threadIdx.x] = v;
+        if (px.world) xchg_put(px, n0 + threadIdx.x, v);
+        else out[n0 + threadIdx.x] = v;
     }
 }
 
@@ -634,8 +705,9 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
                                                     const uint16_t* __restrict__ W, int V, int K,
                                                     float* __restrict__ logits, float* __restrict__ blk_val,
                                                     int* __restrict__ blk_idx, const int* __restrict__ ngen_ptr,
-                                                    int hist_rows, int v0, int Vfull) {
+                                                    int hist_rows, int v0, int Vfull, const VhXchg cx) {
     __shared__ float red[4 * (LM_R + 1)];
+    xchg_reduce(cx);
     __shared__ float bv_s[LM_R];
     __shared__ int bi_s[LM_R];
     // logits history: row = index of the token this step produces (clamped), so the host can
@@ -653,7 +725,8 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
     const uint16_t* rows[LM_R];
     if (it < n_iter) { rows_of(it, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
     float xr[NJ][8];
-    const float ss = load_add_norm<NJ>(x_in, delta, norm_w, nullptr, K, xr);
+    xchg_wait(cx);
+    const float ss = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, nullptr, K, xr, cx.world != 0);
     float inv = 0.f;
     float best = -INFINITY;
     int besti = 0x7fffffff;
@@ -1111,22 +1184,45 @@ inline int pick_nj(int K, F&& f) {
 }  // namespace
 
 // ---- launchers (declared in vh_kernels.h) -------------------------------------------
+static inline VhXchg xchg_or_none(const VhXchg* x) {
+    VhXchg z{};
+    return x ? *x : z;            // world == 0: no exchange
+}
+
 template <int R, bool NORM>
 static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w,
-                           float eps, const uint16_t* W, int N, int K, float* out) {
+                           float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc) {
     return pick_nj(K, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
-                           delta, x_out, norm_w, eps, W, N, K, out);
+                           delta, x_out, norm_w, eps, W, N, K, out, xchg_or_none(xc));
         return 0;
     });
 }
 
-int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out) {
+static int dec_gemv_rows(int K) {
     const int r = vh_tuning()->gemv_rows;   // rows per block: 8 (default), 4 or 16 (vh_tune)
-    if (r == 8) return launch_dec_gemv<8, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
-    if (r == 16 && K <= 4096) return launch_dec_gemv<16, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
-    return launch_dec_gemv<4, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out);
+    return r == 8 ? 8 : (r == 16 && K <= 4096 ? 16 : 4);
+}
+static int dec_gateup_grid(int I, int grid) {
+    const int rp = vh_tuning()->gateup_variant == 2 ? 2 : 4;
+    const int n_iter = 2 * (I / rp);
+    if (grid <= 0) grid = vh_tuning()->gateup_grid;
+    if (grid <= 0) grid = 3 * vh_num_cus() / 2;
+    return grid > n_iter ? n_iter : grid;
+}
+// blocks of a consumer launch: the fused exchange's reducers are its first min(16, blocks) blocks
+int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
+    if (which == 0) { const int r = dec_gemv_rows(K); return (N + r - 1) / r; }
+    if (which == 1) return dec_gateup_grid(I, 0);
+    return N;   // LM head: the caller's grid
+}
+
+int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx) {
+    const int r = dec_gemv_rows(K);
+    if (r == 8) return launch_dec_gemv<8, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
+    if (r == 16) return launch_dec_gemv<16, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
+    return launch_dec_gemv<4, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
@@ -1148,11 +1244,11 @@ int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache,
     return 0;
 }
 
-int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out) {
-    const int r = vh_tuning()->gemv_rows;
-    if (r == 8) return launch_dec_gemv<8, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out);
-    if (r == 16 && K <= 4096) return launch_dec_gemv<16, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out);
-    return launch_dec_gemv<4, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out);
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px) {
+    const int r = dec_gemv_rows(K);
+    if (r == 8) return launch_dec_gemv<8, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
+    if (r == 16) return launch_dec_gemv<16, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
+    return launch_dec_gemv<4, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
 }
 
 // Fused attention + O-projection launch.  Returns 1 (nothing launched) when the launch could not be
@@ -1186,11 +1282,12 @@ int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* v
 
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid) {
+                   float* hbuf, int grid, const VhXchg* cxp) {
     const int variant = vh_tuning()->gateup_variant;   // 0: RP=4 single buffer, 1: RP=4 double buffer, 2: RP=2 single
     const int rp = variant == 2 ? 2 : 4;
     if (E > 8 || E < 2 || I % rp != 0) return -1;
     const int n_iter = 2 * (I / rp);
+    const VhXchg cx = xchg_or_none(cxp);
     if (grid <= 0) grid = vh_tuning()->gateup_grid;
     // 1.5 persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so fewer, longer-lived
     // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
@@ -1201,21 +1298,23 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
         constexpr int NJ = decltype(nj)::value;
         if (variant == 1)
             hipLaunchKernelGGL((k_dec_gateup<NJ, 4, true>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                               eps, Wg, E, W1, W3, I, K, route_out, hbuf);
+                               eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
         else if (variant == 2)
             hipLaunchKernelGGL((k_dec_gateup<NJ, 2, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                               eps, Wg, E, W1, W3, I, K, route_out, hbuf);
+                               eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
         else
             hipLaunchKernelGGL((k_dec_gateup<NJ, 4, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                               eps, Wg, E, W1, W3, I, K, route_out, hbuf);
+                               eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
         return 0;
     });
 }
 
-int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out) {
+int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
+                 const VhXchg* pxp) {
     constexpr int R = 2;
     const int pg = vh_tuning()->down_grid;             // > 0: persistent blocks per launch (0 = one block per row pair)
-    if (pg > 0)
+    const VhXchg px = xchg_or_none(pxp);
+    if (pg > 0 && px.world == 0)
         return pick_nj(I, [&](auto nj) {
             int grid = pg < (N + R - 1) / R ? pg : (N + R - 1) / R;
             hipLaunchKernelGGL((k_dec_down_p<decltype(nj)::value, R>), dim3(grid), dim3(256), 0, st, hbuf, route, W2, N, I, out);
@@ -1223,17 +1322,17 @@ int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint
         });
     return pick_nj(I, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
-                           W2, N, I, out);
+                           W2, N, I, out, px);
         return 0;
     });
 }
 
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
-                   const int* ngen_ptr, int hist_rows, int v0, int Vfull) {
+                   const int* ngen_ptr, int hist_rows, int v0, int Vfull, const VhXchg* cx) {
     return pick_nj(K, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_lmhead<decltype(nj)::value>), dim3(grid), dim3(256), 0, st, x_in, delta, norm_w, eps,
-                           W, V, K, logits, blk_val, blk_idx, ngen_ptr, hist_rows, v0, Vfull);
+                           W, V, K, logits, blk_val, blk_idx, ngen_ptr, hist_rows, v0, Vfull, xchg_or_none(cx));
         return 0;
     });
 }

@@ -34,21 +34,52 @@ struct VhTuning {
     int tp_overlap = 1;       // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
     int moe_ksplit = -4;      // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
     int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
+    int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange (default),
+                               // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Measured with 2 / 4 engine processes on
+                               // one GPU (profiles/r03_tp_fuse_latency_*.json): the fused form is 0.9 / 2.0 us per exchange SLOWER (its 16
+                               // reducer blocks + counter hand-off cost more than the kernel boundary they replace); never on real links
     int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
                                // fine-grained allocation fails (same-device tests); 0 = fail loudly instead
     int ws_pad = 0;          // experiments: 64-KB units of padding in front of the engine workspace (placement sensitivity sweeps)
 };
 VhTuning* vh_tuning();
 
+// ---- tensor-parallel exchange fused into the batch-1 decode kernels (vh_comm.hip fills it, vh_decode.hip uses it) -------
+// One all-reduce(sum) of a `count`-element fp32 vector = one VhXchg, used twice:
+//   * the PRODUCER kernel (O projection, MoE down projection) pushes every output element straight into slot `rank` of every
+//     peer's receive region as an 8-byte {value, tag} granule instead of storing it locally (no separate push pass);
+//   * the CONSUMER kernel (gate|up, next layer's QKV, LM head) needs the whole summed vector in every block (RMSNorm):
+//     its first `nred` blocks poll the world slots of their slice in THIS rank's region, sum them in rank order (bit-identical
+//     on all ranks) and publish the slice to `reduced` with 8-byte agent-scope atomic stores, then count themselves in;
+//     every block puts its weight loads in flight first, waits for `counter` to reach `target`, and reads `reduced` with
+//     8-byte agent-scope atomic loads (guide G16 "8-B agent atomics both sides": no fence, the weight loads stay in flight).
+// world == 0: no exchange (plain local delta buffers, the single-GPU path).
+struct VhXchg {
+    uint64_t* peer[8];              // every rank's receive region of this call's parity (peer[rank] == local)
+    uint64_t* local;
+    float* reduced;                 // this rank's summed vector (device memory of the communicator)
+    int* counter;                   // reducer-block arrivals since the communicator was created (monotonic)
+    int* err;                       // sticky time-out word (vh_comm_status)
+    unsigned long long cap;         // slot stride in granules
+    int rank, world;
+    unsigned tag;
+    int target, nred, count;
+};
+
+struct vh_comm;
+int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, VhXchg* out, void* stream);   // vh_comm.hip
+
 // ---- decode (vh_decode.hip) ---------------------------------------------------------
+// cx (nullable): the delta is the result of a fused exchange (then `delta` is ignored); px (nullable): push the outputs
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out);
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr);
+int vhk_dec_consumer_blocks(int which, int N, int K, int I);   // grid of a consumer launch (0 qkv, 1 gate|up, 2 lm head): bounds nred
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
                  const int* table,    // table: nullable page table of a paged KV cache (64-token pages)
                  const void* prefetch, size_t prefetch_bytes);   // nullable: weights of the NEXT kernel, pulled through the memory-side cache by idle CUs
-int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out);
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr);
 int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                        const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                        float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
@@ -79,11 +110,12 @@ int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w
                     const VhDecBatchHead& hd, int grid, int v0);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid);
-int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out);
+                   float* hbuf, int grid, const VhXchg* cx = nullptr);
+int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
+                 const VhXchg* px = nullptr);
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
-                   const int* ngen_ptr, int hist_rows, int v0, int Vfull);
+                   const int* ngen_ptr, int hist_rows, int v0, int Vfull, const VhXchg* cx = nullptr);
 int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, float* cand, int rank, int world);
 int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx);
 int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out);

@@ -127,11 +127,16 @@ def ipc_allreduce(eng, rank, world, dist, device, backend):
     rank's self-test passed (the engine then routes its all-reduces through it)."""
     comm, ok = None, 0
     try:
-        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden, same_device=ranks_share_one_device(dist, device, world))
-        handles = [None] * world
-        dist.all_gather_object(handles, comm.handle)
-        comm.connect(handles)
-        ok = 1
+        same = ranks_share_one_device(dist, device, world)
+        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden, same_device=same)
+        # The decode exchange can be FUSED into the kernels around it (tp_fuse = 1, vh_api.hip:decode_one_step / VhXchg).  It is
+        # correct (tests/test_comm_gpu.py runs it at world 2 / 4 / 8) but measured slower than one small all-reduce kernel per
+        # exchange wherever it could be measured (several ranks on one GPU: profiles/r03_tp_fuse_latency_*.json), and on a
+        # shared device at the released geometry its 384-1024 waiting consumer blocks starve the other ranks' kernels.
+        # Default off; VITA_AMD_TP_FUSE=1 selects it (e.g. to try it on real xGMI links).
+        from . import _lib
+        _lib.tune("tp_fuse", int(os.environ.get("VITA_AMD_TP_FUSE", "0")))
+        del same
     except Exception as e:
         print(f"[vita_amd.parallel] rank {rank}: IPC all-reduce bring-up failed: {e}", file=sys.stderr)
     if not _agree(dist, ok, device, backend):
