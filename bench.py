@@ -110,15 +110,27 @@ class _BenchTokenizer:
         return [" ".join("</s>" if int(t) == 2 else f"w{int(t)}" for t in row) for row in ids.tolist()]
 
 
+TRAFFIC_FILES = ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+
+
+def traffic_source():
+    for name in TRAFFIC_FILES:
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            return "profiles/" + name
+    return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass (FETCH_SIZE, corrected as
     MI355X_MICROARCH.md prescribes; collected by profiles/pmc_pass.sh in its own run — counters cannot be
     read from inside this process).  TP=1 only: the launch moves 1/N of the bytes at TP=N."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) as f:
-            return int(json.load(f)[kernel]["hbm_read_bytes_per_launch"])
-    except Exception:
-        return None
+    for name in TRAFFIC_FILES:                       # newest committed pass first
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return int(json.load(f)[kernel]["hbm_read_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def native_rccl_or_fallback(eng, rank, dist, dev, backend, timeout_s=180):
@@ -517,8 +529,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                          "bytes_per_launch": gateup_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "samples": n_samp,
                          "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None,
-                         "traffic_source": "profiles/r02_pmc_hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE pass of this "
-                                           "kernel, counters cannot be read inside this process)" if world == 1 else None},
+                         "traffic_source": (f"{traffic_source()} (static: rocprofv3 --pmc FETCH_SIZE pass of this kernel, "
+                                            "counters cannot be read inside this process)") if world == 1 else None},
             "gpu_state": gpu_state.summary(),
             "build_s": round(t_build, 1),
         }

@@ -332,16 +332,25 @@ __global__ __launch_bounds__(256) void k_embed_splice(const int* __restrict__ ki
 
 // counting sort of the 2S (token, slot) entries by expert: wave e owns expert e.
 // sorted order inside an expert is ascending entry index -> deterministic.
+// The ids are staged in LDS by all waves at once (ONE memory round trip; r02 scanned global memory chunk by chunk, twice:
+// 36 dependent L2 round trips = 12.6 us per layer for 1104 entries); chunks of MS_CHUNK entries for long prompts.
+#define MS_CHUNK 8192
 __global__ void k_moe_sort(const int* __restrict__ ids, int S, int E, int* __restrict__ group_off,
                            int* __restrict__ sorted_tok, int* __restrict__ sorted_slot) {
     __shared__ int cnt[8];
+    __shared__ signed char ids_s[MS_CHUNK];
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int n = 2 * S;
     int c = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const bool f = (i < n) && (ids[i] == e);
-        c += __popcll(__ballot(f));
+    for (int b0 = 0; b0 < n; b0 += MS_CHUNK) {
+        const int nb = min(MS_CHUNK, n - b0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) ids_s[i] = (signed char)ids[b0 + i];
+        __syncthreads();
+        for (int i0 = 0; i0 < nb; i0 += 64) {
+            const int i = i0 + lane;
+            c += __popcll(__ballot((i < nb) && (ids_s[i] == e)));
+        }
     }
     if (lane == 0) cnt[e] = c;
     __syncthreads();
@@ -352,16 +361,24 @@ __global__ void k_moe_sort(const int* __restrict__ ids, int S, int E, int* __res
         if (e == E - 1) group_off[E] = base + c;
     }
     int run = base;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        const bool f = (i < n) && (ids[i] == e);
-        const unsigned long long bal = __ballot(f);
-        if (f) {
-            const int p = run + __popcll(bal & ((1ull << lane) - 1ull));
-            sorted_tok[p] = i >> 1;
-            sorted_slot[p] = i;
+    for (int b0 = 0; b0 < n; b0 += MS_CHUNK) {
+        const int nb = min(MS_CHUNK, n - b0);
+        if (n > MS_CHUNK) {                              // (a single chunk is still resident from the counting pass)
+            __syncthreads();
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) ids_s[i] = (signed char)ids[b0 + i];
+            __syncthreads();
         }
-        run += __popcll(bal);
+        for (int i0 = 0; i0 < nb; i0 += 64) {
+            const int i = i0 + lane;
+            const bool f = (i < nb) && (ids_s[i] == e);
+            const unsigned long long bal = __ballot(f);
+            if (f) {
+                const int p = run + __popcll(bal & ((1ull << lane) - 1ull));
+                sorted_tok[p] = (b0 + i) >> 1;
+                sorted_slot[p] = b0 + i;
+            }
+            run += __popcll(bal);
+        }
     }
 }
 

@@ -136,7 +136,10 @@ def ipc_allreduce(eng, rank, world, dist, device, backend):
         # Default off; VITA_AMD_TP_FUSE=1 selects it (e.g. to try it on real xGMI links).
         from . import _lib
         _lib.tune("tp_fuse", int(os.environ.get("VITA_AMD_TP_FUSE", "0")))
-        del same
+        handles = [None] * world
+        dist.all_gather_object(handles, comm.handle)
+        comm.connect(handles)
+        ok = 1
     except Exception as e:
         print(f"[vita_amd.parallel] rank {rank}: IPC all-reduce bring-up failed: {e}", file=sys.stderr)
     if not _agree(dist, ok, device, backend):
