@@ -39,8 +39,17 @@ class GpuStateSampler:
     def __init__(self, index=0, period_s=0.02):
         import glob
         self.period = period_s
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        self.hw = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.hw = None
+        try:   # the hwmon directory of THIS device: torch index -> PCI address -> sysfs (a node exposes every GPU's card*)
+            p = torch.cuda.get_device_properties(index)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            hw = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*"))
+            self.hw = hw[0] if hw else None
+        except Exception:
+            pass
+        if self.hw is None:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+            self.hw = cards[0] if len(cards) == 1 else None          # ambiguous with several cards: report nothing
         self.files = {}
         if self.hw:
             for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input")),
@@ -373,6 +382,8 @@ def main():
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
+    emb_last = None
+
     def encode_and_prefill():
         e = [ev() for _ in range(5)]
         e[0].record()
@@ -385,6 +396,8 @@ def main():
         eng.prefill(emb[0])
         e[4].record()
         torch.cuda.synchronize()
+        nonlocal emb_last
+        emb_last = emb[0]
         return emb.shape[1], {"vit_proj_ms": e[0].elapsed_time(e[1]), "audio_ms": e[1].elapsed_time(e[2]),
                               "prefill_ms": e[3].elapsed_time(e[4]), "n_audio_tokens": int(aud["inputs_embeds"].shape[1])}
 
@@ -394,6 +407,17 @@ def main():
     gpu_state.start("prefill_phase")
     runs = [encode_and_prefill()[1] for _ in range(max(1, args.phase_iters))]
     gpu_state.stop()
+    if gpu_state.files and not args.layers:
+        # clock / power settle over hundreds of ms (and the hwmon power is a moving average): keep the prefill running for
+        # ~1.5 s and keep only what was sampled in the second half — the state the timed prefill passes converge to
+        gpu_state.start("prefill_steady")
+        t_end = time.perf_counter() + 1.5
+        while time.perf_counter() < t_end:
+            eng.prefill(emb_last)
+            torch.cuda.synchronize()
+        gpu_state.stop()
+        buf = gpu_state.samples["prefill_steady"]
+        del buf[:len(buf) // 2]
     phase = {k: float(np.median([r[k] for r in runs])) for k in ("vit_proj_ms", "audio_ms", "prefill_ms")}
     phase_min = {k: float(min(r[k] for r in runs)) for k in ("vit_proj_ms", "audio_ms", "prefill_ms")}
     assert runs[-1]["n_audio_tokens"] == n_aud_tok                     # the last run's KV cache feeds the decode below
