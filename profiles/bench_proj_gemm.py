@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the prefill projections on the streaming GEMM (vh_gemm_ps): QKV (M = S, N = 6144, K = 4096) and
+O (N = 4096) with the device-chosen K split, as vh_api.hip:prefill_impl launches them; prints us per launch and the slab
+count.  VITA_AMD_LIB selects an ablated build (profiles/ablate_ps.sh: PS_ABLATE=32 drops the epilogue stores).
+   python profiles/bench_proj_gemm.py [--S 552] [--iters 20]"""
+import argparse, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vita_amd import _lib, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--S", type=int, default=552)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--check", action="store_true")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+S, H = args.S, 4096
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn((S, H), device=dev, generator=g)
+xh, xl = ops.split_planes(x)
+out = {}
+nslab = torch.zeros(1, dtype=torch.int32, device=dev)
+for name, N, ks in (("qkv", 6144, -4), ("o", 4096, -8)):
+    ws = [(torch.randn((N, H), device=dev, generator=g) * 0.02).to(torch.bfloat16) for _ in range(3)]
+    y = torch.empty((abs(ks), S, N), dtype=torch.float32, device=dev)
+    def run(w):
+        ops.gemm_ps(xh, xl, w, out=y, ksplit=ks, nslab_out=nslab)
+    run(ws[0]); torch.cuda.synchronize()
+    if args.check:
+        ref = x.double() @ ws[0].double().T
+        err = float((y[:int(nslab.item())].sum(0).double() - ref).abs().max())
+        assert err < 5e-3, err
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+    ev[0].record()
+    for i in range(args.iters):
+        run(ws[i % 3]); ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(args.iters)]
+    out[name] = {"us_median": round(float(np.median(ts)), 1), "us_min": round(min(ts), 1), "slabs": int(nslab.item())}
+print(json.dumps(out))

@@ -42,7 +42,7 @@ typedef __attribute__((address_space(3))) void* lds_void_t;
 typedef const __attribute__((address_space(1))) void* glb_void_t;
 
 // timing experiments only (results are wrong when non-zero): 1 = no activation pieces, 2 = no weight pieces,
-// 4 = no MFMAs, 8 = no fragment reads of the activations, 16 = no MFMAs in the weight-loading waves.  Built with -DPS_ABLATE=n by profiles/ablate_ps.sh.
+// 4 = no MFMAs, 8 = no fragment reads of the activations, 16 = no MFMAs in the weight-loading waves, 32 = no epilogue stores.  Built with -DPS_ABLATE=n by profiles/ablate_ps.sh.
 #ifndef PS_ABLATE
 #define PS_ABLATE 0
 #endif
@@ -306,7 +306,7 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
         }
         // pin that order: hipcc's scheduler otherwise sinks every fragment read to just before its MFMAs
         // (one register, lgkmcnt(0) in front of each group of four) and hoists all loads to the top
-        if (PS_ABLATE == 0) {
+        if ((PS_ABLATE & ~32) == 0) {
             __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);               // 8 weight + 2 activation fragment reads
             StepOrder<0, NSTEP, NP, FRONT>::pin();
             if (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);   // the LDS stores
@@ -352,20 +352,54 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
     __builtin_amdgcn_s_barrier();                 // every wave is done with the rings before the next tile refills them
 
     // ---- epilogue: acc[i][c][r] = out[token m_begin + (wm+2i)*16 + (lane&15)][col0(c) + 4*(lane>>4) + r] ----
+    // The C^T accumulators give a lane 4 consecutive columns of ONE token: stored directly, a wave instruction touches 16
+    // token rows x 64 B, rows tens of KB apart (r02).  For the K-split projections that is 40-70 MB of such stores per
+    // launch, and it is where the slow boxes of the pool lose their time: QKV 133 us with the stores, 57 us without
+    // (profiles/r03_proj_probe.txt; 70-80 us in all on a fast box).  So the tile goes through LDS (free after the K loop)
+    // and leaves row by row: one wave instruction = 1 KB of ONE output row (fp32) / 256 B of two rows (bf16 planes).
+    if (PS_ABLATE & 32) {                            // timing experiment: no output at all
+#pragma unroll
+        for (int i = 0; i < RTW; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(acc[i][c]));
+        return;
+    }
+    constexpr int NCOL = GLU ? 128 : 256;            // fp32 values per staged row
+    constexpr int ROWB = NCOL * 4 + 16;              // + 16 B: consecutive rows start 4 banks apart
+    constexpr int RC = GLU ? 192 : 96;               // rows per pass: 192 x 528 B = 99 KB / 96 x 1040 B = 97.5 KB
+    static_assert(RC * ROWB <= 2 * A_BUF + NSLOT * MG_SLOT || RTMAX * 16 * ROWB <= 2 * A_BUF + NSLOT * MG_SLOT, "staging fits the rings");
     const int jrow = lane & 15, jc = (lane >> 4) * 4;
+    const int tile_rows = t.m_end - t.m_begin;
+    for (int r0 = 0; r0 < t.rt * 16; r0 += RC) {     // block-uniform
 #pragma unroll
-    for (int i = 0; i < RTW; ++i) {
-        const int m = t.m_begin + (wm + 2 * i) * 16 + jrow;
-        if (m >= t.m_end) continue;
-        const long orow = p.c_rowidx ? p.c_rowidx[m] : m;
+        for (int i = 0; i < RTW; ++i) {
+            const int rl = (wm + 2 * i) * 16 - r0;   // first local row of this row tile (wave-uniform)
+            if (rl < 0 || rl + 16 > RC || rl + 16 > RTMAX * 16) continue;
+            unsigned char* rowp = lds + (size_t)(rl + jrow) * ROWB;
+            if (GLU) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[i][c][r]) * acc[i][c + 2][r];
+                    *reinterpret_cast<f32x4*>(rowp + (wn * 32 + c * 16 + jc) * 4) = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(rowp + (wn * 64 + c * 16 + jc) * 4) = acc[i][c];
+            }
+        }
+        __syncthreads();
+        const int nrows = min(RC, tile_rows - r0);
         if (GLU) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int n = t.n0 + wn * 32 + c * 16 + jc;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_f(acc[i][c][r]) * acc[i][c + 2][r];
+            // two rows per wave instruction: lane -> row (lane >> 5), columns 4 (lane & 31) ..
+            const int n = t.n0 + (lane & 31) * 4;
+            for (int rr = wid * 2; rr < nrows; rr += 16) {
+                const int row = rr + (lane >> 5);
+                if (row >= nrows || n >= p.N) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (size_t)row * ROWB + (lane & 31) * 16);
+                const int m = t.m_begin + r0 + row;
+                const long orow = p.c_rowidx ? p.c_rowidx[m] : m;
                 const bool full = n + 3 < p.N;
                 if (p.C) {
                     float* cp = p.C + orow * p.ldc + n;
@@ -388,14 +422,17 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
                 }
             }
         } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int n = t.n0 + wn * 64 + c * 16 + jc;
+            // one row per wave instruction: lane -> columns 4 lane ..
+            const int n = t.n0 + lane * 4;
+            for (int row = wid; row < nrows; row += 8) {
                 if (n >= p.N) continue;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(lds + (size_t)row * ROWB + lane * 16);
+                const int m = t.m_begin + r0 + row;
+                const long orow = p.c_rowidx ? p.c_rowidx[m] : m;
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float tv = acc[i][c][r];
+                    float tv = a[r];
                     if (n + r < p.N) {
                         if (p.bias) tv += p.bias[n + r];
                         tv = apply_act(tv, p.act);
@@ -427,6 +464,7 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
                 }
             }
         }
+        __syncthreads();                             // the staging rows are free again (next pass / next tile's rings)
     }
 }
 
