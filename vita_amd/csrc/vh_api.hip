@@ -53,6 +53,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
+    if (!strcmp(key, "prefill_fuse_rows")) { g_tuning.prefill_fuse_rows = value; return VH_OK; }
     if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
     if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
     if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
@@ -658,16 +659,32 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     if (qkv_slabs > 4) qkv_slabs = 4;
     const bool stream_attn = vh_tuning()->prefill_attn_gemm == 0 && qkv_slabs >= 1 && (H % 64) == 0 && ((nq * hd) % 64) == 0 &&
                              H <= 4096 && (m->nqkv % 4) == 0;
+    // (r03) K-split slabs are summed by the norm kernel that consumes the rows (VhRowUpdate) on the single-rank path;
+    // vh_tune("prefill_fuse_rows", 0) restores the separate slab-sum / combine launches
+    const bool fuse_rows = !tp && vh_tuning()->prefill_fuse_rows != 0 && stream_attn && vh_tuning()->prefill_moe_gemm == 0;
+    const bool attn_planes = stream_attn && vh_tuning()->attn_impl == 0 && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
+    bool combine_pending = false;
+    int pend_nslab = 1;
+    const int* pend_nslab_dev = nullptr;
+    const long pend_slab = (long)2 * m->c.max_prefill * H;
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        bool o_pending = false;
         if (stream_attn) {
             // weight-streaming projections (vh_gemm_ps.hip): the norm emits the bf16 hi/lo planes, the 35 row tiles of
             // S = 552 run as 3 m-tiles per 256 weight rows and the kernel picks a K split that fills the CUs
             // (72 QKV tiles x 3 slabs); the partial slabs are summed by the consumer (RoPE / KV write)
+            // (r03) the previous layer's expert outputs are still K-split slabs in py: this norm applies the routing-weighted
+            // sum to the residual rows first (VhRowUpdate), so no combine kernel runs between the layers
+            const VhRowUpdate cu{m->py, (long)H, pend_slab, pend_nslab_dev, pend_nslab, m->pwts};
             VH_TRY(vhk_rmsnorm_route(st, m->px, nullptr, m->pxn_hi, m->pxn_lo, w.attn_norm, Sn, H, m->c.rms_eps, nullptr, 0,
-                                     nullptr, nullptr), "rmsnorm");
+                                     nullptr, nullptr, combine_pending ? &cu : nullptr), "rmsnorm");
+            if (combine_pending && hidden_dbg)
+                hipMemcpyAsync(hidden_dbg + (size_t)(l - 1) * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
+                               hipMemcpyDeviceToDevice, st);
+            combine_pending = false;
             VhGemmPsArgs g{};
             g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; g.lda = H;
             g.W = w.wqkv; g.ldw = H; g.C = m->py; g.ldc = m->nqkv; g.M = Sn; g.N = m->nqkv; g.K = H;
@@ -693,13 +710,15 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             a.B = 1; a.Hq = nq; a.Hkv = nkv; a.Sq = Sn; a.Sk = pos0 + Sn; a.d = hd;
             a.causal = 1; a.q_off = pos0; a.klen = pos0 + Sn; a.chunk = 0; a.left = -1; a.scale = scale;
             a.ktable = m->table;
+            if (attn_planes) { a.O = nullptr; a.O_hi = m->ph_hi; a.O_lo = m->ph_lo; a.ldo_split = (long)nq * hd; }
             VH_TRY(vhk_attn(st, a), "attention");
         }
         if (stream_attn) {
-            // O projection on the streaming kernel: planes of the attention output, K-split slabs, slab sum fused with
-            // the residual add (or feeding the all-reduce under tensor parallelism)
+            // O projection on the streaming kernel: planes of the attention output (written by the attention kernel itself
+            // when it is the direct-operand one), K-split slabs, slab sum fused into the FFN norm (or feeding the all-reduce
+            // under tensor parallelism)
             const int KO = nq * hd;
-            VH_TRY(vhk_split_planes(st, m->pattn, KO, m->ph_hi, m->ph_lo, KO, Sn, KO), "split planes");
+            if (!attn_planes) VH_TRY(vhk_split_planes(st, m->pattn, KO, m->ph_hi, m->ph_lo, KO, Sn, KO), "split planes");
             VhGemmPsArgs g{};
             g.A_hi = m->ph_hi; g.A_lo = m->ph_lo; g.lda = KO;
             g.W = w.wo; g.ldw = KO; g.M = Sn; g.K = KO; g.ksplit = -8;
@@ -728,6 +747,8 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                     VH_TRY(vhk_sum_slabs(st, m->ptmp, H, m->py, H, Sn, H, m->pnslab + 2, 1, g.c_split_stride, 0), "slab sum");
                     if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
                     VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+                } else if (fuse_rows) {
+                    o_pending = true;                   // summed into px by the FFN norm below
                 } else {
                     VH_TRY(vhk_sum_slabs(st, m->px, H, m->py, H, Sn, H, m->pnslab + 2, 1, g.c_split_stride, 1), "slab sum");
                 }
@@ -771,8 +792,9 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             // weight-streaming path: the norm kernel emits the bf16 hi/lo planes directly, one tall m-tile per
             // expert (weights cross the fabric once), gate|up emits the planes of h, the down projection is
             // K-split into `nslab` partial slabs that the combine kernel adds
+            const VhRowUpdate ou{m->py, (long)H, (long)Sm * H, m->pnslab + 2, 1, nullptr};     // the O projection's slabs
             VH_TRY(vhk_rmsnorm_route(st, m->px, nullptr, m->pxn_hi, m->pxn_lo, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter,
-                                     E, m->pids, m->pwts), "rmsnorm + route");
+                                     E, m->pids, m->pwts, o_pending ? &ou : nullptr), "rmsnorm + route");
             VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
             VhGemmPsArgs g{};
             g.A_hi = m->pxn_hi; g.A_lo = m->pxn_lo; g.lda = H; g.a_rowidx = m->pstok;
@@ -846,13 +868,16 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             VH_TRY(vhk_moe_combine(st, m->ptmp, m->py, m->pwts, Sn, H, nslab, slab, nslab_dev), "combine");
             if (m->allreduce(m->ptmp, (long)Sn * H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
             VH_TRY(vhk_add(st, m->px, m->ptmp, (long)Sn * H), "add");
+        } else if (fuse_rows && l + 1 < m->c.n_layers) {
+            combine_pending = true;                     // applied by the next layer's attention norm
+            pend_nslab = nslab; pend_nslab_dev = nslab_dev;
         } else {
             VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H, nslab, slab, nslab_dev), "combine");
         }
         if (m->route_dbg)
             hipMemcpyAsync(m->route_dbg + (size_t)l * 2 * Sn, m->pids, (size_t)2 * Sn * sizeof(int),
                            hipMemcpyDeviceToDevice, st);
-        if (hidden_dbg)
+        if (hidden_dbg && !combine_pending)
             hipMemcpyAsync(hidden_dbg + (size_t)l * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
                            hipMemcpyDeviceToDevice, st);
     }

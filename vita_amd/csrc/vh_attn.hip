@@ -431,16 +431,25 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
     }
 
-    float* Ob = p.O + (size_t)b * p.bso + (size_t)h * D;
+    float* Ob = p.O ? p.O + (size_t)b * p.bso + (size_t)h * D : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int q = q0 + lg * 4 + r;
         if (q >= p.Sq) continue;
         const float inv = (l[r] > 0.f) ? 1.0f / l[r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < VQ; ++j)
-            *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) =
-                f32x4{o[4 * j][r] * inv, o[4 * j + 1][r] * inv, o[4 * j + 2][r] * inv, o[4 * j + 3][r] * inv};
+        for (int j = 0; j < VQ; ++j) {
+            const f32x4 v = f32x4{o[4 * j][r] * inv, o[4 * j + 1][r] * inv, o[4 * j + 2][r] * inv, o[4 * j + 3][r] * inv};
+            if (Ob) *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) = v;
+            if (p.O_hi) {   // (r03) the O projection streams bf16 hi/lo planes: emitted here instead of by a split pass
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) split_bf16(v[i], hi[i], lo[i]);
+                const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+        }
     }
 }
 
@@ -453,6 +462,8 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
     const int kl = a.klen < a.Sk ? a.klen : a.Sk;
     // direct-operand kernel (default): every operand row must allow 16-byte loads / stores
     auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    if (!a.O && !a.O_hi) return -1;
+    if (a.O_hi && (!a.O_lo || a.B != 1 || (a.ldo_split % 4) != 0 || !al16(a.O_hi) || !al16(a.O_lo))) return -1;
     const bool direct_ok = vh_tuning()->attn_impl == 0 && al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
                            (!rel || (al16(a.bias_u) && al16(a.bias_v) && (a.ldp % 4) == 0 && (a.hsp % 4) == 0)) &&
                            ((a.ldq | a.hsq | a.bsq | a.ldk | a.hsk | a.bsk | a.ldv | a.hsv | a.ldo | a.bso) % 4) == 0;
@@ -480,6 +491,7 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
 #undef AT_LAUNCH_W
         return 0;
     }
+    if (a.O_hi || !a.O) return -1;                    // plane output exists in the direct kernel only
     const dim3 grid((a.Sq + 63) / 64, a.Hq, a.B);
     // key groups per block: 4 (d = 64) / 2 (d = 64 rel-pos, d = 128) when the context is long enough to deal out (attn_ksplit = 1 keeps
     // the single-group kernel: tests compare the two)

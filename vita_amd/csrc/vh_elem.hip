@@ -72,15 +72,19 @@ __global__ __launch_bounds__(256) void k_norm_rows(const float* __restrict__ x, 
 // 2^-17), so no separate split pass runs.  (Round 1 used one WAVE per row with a serial 8-expert FMA chain:
 // 138 blocks, 75 us for a 9 MB read; this shape is 552 blocks x 128 FMAs per thread.)
 #define RR_MAXJ 4   // chunks per thread -> cols <= 4096
-__global__ __launch_bounds__(256) void k_rmsnorm_route(const float* __restrict__ x, float* __restrict__ y,
+// UPD (r03): the row first takes the update its producer left as K-split slabs (VhRowUpdate: the O projection's slabs
+// before the FFN norm, the previous layer's expert outputs before the attention norm) and is written back — the
+// arithmetic and its order are those of k_sum_slabs / k_moe_combine, which this replaces on the prefill path.
+template <int UPD>
+__global__ __launch_bounds__(256) void k_rmsnorm_route(float* __restrict__ x, float* __restrict__ y,
                                                        uint16_t* __restrict__ y_hi, uint16_t* __restrict__ y_lo,
                                                        const float* __restrict__ w, int rows, int cols, float eps,
                                                        const uint16_t* __restrict__ Wg, int E,
-                                                       int* __restrict__ ids, float* __restrict__ wts) {
+                                                       int* __restrict__ ids, float* __restrict__ wts, const VhRowUpdate u) {
     __shared__ float red[4 * 9];
     const int row = blockIdx.x;
     const int nv = cols >> 2;
-    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)row * cols);
+    f32x4* xp = reinterpret_cast<f32x4*>(x + (size_t)row * cols);
     f32x4 v[RR_MAXJ], g[RR_MAXJ];
 #pragma unroll
     for (int j = 0; j < RR_MAXJ; ++j) {
@@ -89,6 +93,38 @@ __global__ __launch_bounds__(256) void k_rmsnorm_route(const float* __restrict__
         v[j] = xp[cc];
         g[j] = reinterpret_cast<const f32x4*>(w)[cc];
         if (c >= nv) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (UPD != 0) {
+        const int ns = u.nslab_dev ? *u.nslab_dev : u.nslab;
+        if (UPD == 1) {
+            const f32x4* sp = reinterpret_cast<const f32x4*>(u.src + (size_t)row * u.ld);
+#pragma unroll
+            for (int j = 0; j < RR_MAXJ; ++j) {
+                const int c = threadIdx.x + j * 256;
+                if (c >= nv) continue;
+                f32x4 a = sp[c];
+                for (int k = 1; k < ns; ++k) a += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(sp + c) + (size_t)k * u.stride);
+                v[j] = a + v[j];
+                xp[c] = v[j];
+            }
+        } else {
+            const float w0 = u.wts[row * 2], w1 = u.wts[row * 2 + 1];
+            const f32x4* s0 = reinterpret_cast<const f32x4*>(u.src + (size_t)(2 * row) * u.ld);
+            const f32x4* s1 = reinterpret_cast<const f32x4*>(u.src + (size_t)(2 * row + 1) * u.ld);
+#pragma unroll
+            for (int j = 0; j < RR_MAXJ; ++j) {
+                const int c = threadIdx.x + j * 256;
+                if (c >= nv) continue;
+                f32x4 y0 = s0[c], y1 = s1[c];
+                for (int k = 1; k < ns; ++k) {
+                    y0 += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(s0 + c) + (size_t)k * u.stride);
+                    y1 += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(s1 + c) + (size_t)k * u.stride);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][i] += w0 * y0[i] + w1 * y1[i];
+                xp[c] = v[j];
+            }
+        }
     }
     float vals[9];
 #pragma unroll
@@ -530,13 +566,20 @@ int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, co
                        S, H);
     return 0;
 }
-int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
-                      int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts) {
+int vhk_rmsnorm_route(hipStream_t st, float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
+                      int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts, const VhRowUpdate* upd) {
     if (cols % 4 != 0 || cols > RR_MAXJ * 1024 || E == 1 || E < 0 || E > 8 || (y_hi && !y_lo) || (!y && !y_hi)) return -1;   // E = 0: norm only
     if (E > 0 && (!Wg || !ids || !wts)) return -1;
+    if (upd && (!upd->src || (upd->ld % 4) != 0 || (upd->stride % 4) != 0 || (!upd->nslab_dev && upd->nslab < 1))) return -1;
+    if (upd && upd->wts && upd->wts == wts && E > 0) return -1;   // the routing weights being applied must not be the ones being written
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(k_rmsnorm_route, dim3(rows), dim3(256), 0, st, x, y, y_hi, y_lo, w, rows, cols, eps, Wg, E, ids,
-                       wts);
+    const VhRowUpdate u = upd ? *upd : VhRowUpdate{};
+    if (!upd)
+        hipLaunchKernelGGL(k_rmsnorm_route<0>, dim3(rows), dim3(256), 0, st, x, y, y_hi, y_lo, w, rows, cols, eps, Wg, E, ids, wts, u);
+    else if (!u.wts)
+        hipLaunchKernelGGL(k_rmsnorm_route<1>, dim3(rows), dim3(256), 0, st, x, y, y_hi, y_lo, w, rows, cols, eps, Wg, E, ids, wts, u);
+    else
+        hipLaunchKernelGGL(k_rmsnorm_route<2>, dim3(rows), dim3(256), 0, st, x, y, y_hi, y_lo, w, rows, cols, eps, Wg, E, ids, wts, u);
     return 0;
 }
 // ---- the router alone (per-operator entry vh_router_top2; HF MixtralSparseMoeBlock: gate -> fp32 softmax -> top-2 ->

@@ -505,7 +505,9 @@ void k_gemm_ps(const VhGemmPsArgs p) {
             const int Tx = (MT * NT * ks + 7) >> 3;                   // tiles of the fullest XCD
             const int Rr = Tx / nb, rr = Tx - Rr * nb;
             const int rounds16 = 16 * Rr + (rr == 0 ? 0 : (2 * rr <= nb ? 9 : 16));   // M-split last round ~ 0.55
-            const int est = (rounds16 * 64) / ks + 4 * rounds16;      // + ~6 % of a full tile per round (prologue, epilogue)
+            // + ~6 % of a full tile per round (prologue, epilogue) + what a slab costs to store and to sum again, in the
+            // same units (a K = 4096 slab ~ 48; r03, profiles/r03_proj_variants.txt: O projection 5 slabs 57.5 us, 2 slabs 52.8)
+            const int est = (rounds16 * 64) / ks + 4 * rounds16 + ks * ((48 * 64) / nk_total);
             if (est < best) { best = est; KS = ks; }
         }
         if (p.nslab_out && blockIdx.x == 0 && threadIdx.x == 0) *p.nslab_out = KS;

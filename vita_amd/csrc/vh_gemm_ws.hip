@@ -431,7 +431,7 @@ void k_gemm_ws(const VhGemmPsArgs p) {
             const int Tx = (MT * NT_ * ks + 7) >> 3;
             const int Rr = Tx / nb, rr = Tx - Rr * nb;
             const int rounds16 = 16 * Rr + (rr == 0 ? 0 : (2 * rr <= nb ? 9 : 16));
-            const int est = (rounds16 * 64) / ks + 4 * rounds16;
+            const int est = (rounds16 * 64) / ks + 4 * rounds16 + ks * ((48 * 64) / nk_total);   // as vh_gemm_ps.hip
             if (est < best) { best = est; KS = ks; }
         }
         if (p.nslab_out && blockIdx.x == 0 && threadIdx.x == 0) *p.nslab_out = KS;

@@ -23,6 +23,7 @@ struct VhTuning {
     int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernel (16 rows per wave, no LDS tiles), 1 = LDS-tiled kernel
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
+    int prefill_fuse_rows = 1; // single-rank prefill: K-split slabs summed by the consuming norm kernel (VhRowUpdate); 0 = separate slab-sum / combine launches
     int prefill_moe_gemm = 0; // MoE prefill GEMMs: 0 = weight-streaming pre-split kernel (vh_gemm_ps, default), 1 = general kernel
     int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
     int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
@@ -172,6 +173,7 @@ struct VhAttnArgs {
     const float* P; long ldp; long hsp;   // rel-pos keys (audio), nullable
     const float* bias_u; const float* bias_v;  // [H][d], nullable (rel-pos)
     float* O; long ldo;                   // O[(b*Sq + q)*ldo + h*d + dd]
+    uint16_t* O_hi; uint16_t* O_lo; long ldo_split;   // optional bf16 hi/lo planes of O (same indexing, B = 1; direct kernel only); O may then be null
     long bsq, bsk, bso;                   // batch strides in elements for Q / K,V / O
     int B, Hq, Hkv, Sq, Sk, d;
     int causal; int q_off;                // causal: key <= q + q_off visible
@@ -202,8 +204,17 @@ int vhk_sum_slabs(hipStream_t st, float* dst, long ldd, const float* src, long l
                   const int* nslab_dev, int nslab, long stride, int accumulate);
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,
                      const float* img_feats, const float* aud_feats, float* out, int S, int H);
-int vhk_rmsnorm_route(hipStream_t st, const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
-                      int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts);
+// A pending update of the residual rows that the norm kernel applies (and writes back) before it norms them, so the
+// producer's K-split slabs are summed where they are consumed instead of in a launch of their own:
+//   wts == null:  x[r,:] += sum_k src[k*stride + r*ld + :]                                  (k_sum_slabs, accumulate)
+//   wts != null:  x[r,:] += wts[2r] * sum_k src[k*stride + 2r*ld + :] + wts[2r+1] * sum_k src[.. (2r+1)*ld ..]  (k_moe_combine)
+struct VhRowUpdate {
+    const float* src; long ld; long stride;
+    const int* nslab_dev; int nslab;        // the slab count is read on the device when nslab_dev != null
+    const float* wts;
+};
+int vhk_rmsnorm_route(hipStream_t st, float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, const float* w, int rows,
+                      int cols, float eps, const uint16_t* Wg, int E, int* ids, float* wts, const VhRowUpdate* upd = nullptr);
 int vhk_router_top2(hipStream_t st, const float* x, long ldx, const uint16_t* Wg, int E, int H, int rows, int* ids, float* wts,
                     float* probs);   // probs nullable: [rows][E] softmax
 int vhk_moe_sort(hipStream_t st, const int* ids, int S, int E, int* group_off, int* sorted_tok, int* sorted_slot);
