@@ -68,6 +68,14 @@ typedef struct {
     int ksplit;                   /* 0 = decided by the library when ws != NULL, 1 = never split, n = n-way */
 } vh_gemm_args;
 int vh_gemm(const vh_gemm_args* args, void* stream);
+/* vh_gemm_ln: vh_gemm followed by the LayerNorm that consumes its output, in one call:
+ *   C = epilogue(A W^T)  and  ln_out[m, :] = LayerNorm(C[m, :]; ln_eps) * ln_w + ln_b      (ln_b nullable)
+ * i.e. the encoders' `x = x + ls * proj(attn); h = norm2(x)` (InternVisionEncoderLayer.forward, modeling_intern_vit.py:245-253)
+ * and Whale's `x = residual + feed_forward(x); x = norm(x)` steps.  When the library splits K (small launches) the
+ * reducer holds whole rows and applies the norm itself; otherwise a norm launch follows.  Plain GEMMs only (no gate,
+ * groups or output row map); N % 4 == 0. */
+int vh_gemm_ln(const vh_gemm_args* args, const float* ln_w, const float* ln_b, float ln_eps, float* ln_out, long ld_ln,
+               void* stream);
 
 /* vh_gemm_ps: the same contraction as a WEIGHT STREAM for skinny M (Mixtral prefill, MoE grouped GEMMs: HF
  * MixtralExperts, modeling_mixtral.py:57-93) on activations already split into bf16 hi/lo planes (x = hi + lo
@@ -105,6 +113,31 @@ typedef struct {
     float scale;
 } vh_attn_args;
 int vh_attention(const vh_attn_args* args, void* stream);
+
+/* vh_encoder_layer: ONE pre-norm transformer block of the two encoders, all launches from a single call (the host loop of
+ * 24 layers x 8 operator calls was slower than the GPU at one tile / one clip):
+ *   qkv = h_in W_qkv^T + b;  a = attention(qkv);  x += ls1 * (a W_proj^T + b);  h = LN(x; n2);
+ *   x += ls2 * (act(h W_fc1^T + b) W_fc2^T + b);  h_out = LN(x; next)                     (ls1 / ls2 / next nullable)
+ * = InternVisionEncoderLayer.forward (internvit/modeling_intern_vit.py:245-253: layer scale, GELU) and Whale's
+ * TransformerEncoderLayer.forward (whale/module/encoder/transformer.py, rel-pos attention whale/module/layer/attention.py:358-419:
+ * P = linear_pos(pos_emb), pos_bias_u / pos_bias_v, pad / chunk mask; ReLU).  h_in is LN(x; this layer's norm1): from
+ * vh_layernorm for the first layer, from the previous call's h_out afterwards.  Attention runs inside each of the B
+ * sequences of M / B rows; keys >= klen are masked (klen < 0: none).  Scratch (caller-owned): qkv [M, 3C], attn [M, C], hmid [M, C], mid [M, F], ws (split-K slabs,
+ * >= 32 M max(C, F) bytes recommended; 0 disables the split). */
+typedef struct {
+    float* x; const float* h_in; float* h_out;
+    int M, C, F, heads, B;
+    const uint16_t* qkv_w; const float* qkv_b;
+    const uint16_t* proj_w; const float* proj_b; const float* ls1;
+    const float* n2_w; const float* n2_b;
+    const uint16_t* fc1_w; const float* fc1_b;
+    const uint16_t* fc2_w; const float* fc2_b; const float* ls2;
+    const float* next_w; const float* next_b;
+    int act; float eps;
+    const float* P; long ldp; const float* bias_u; const float* bias_v; int klen, chunk, left;
+    float* qkv; float* attn; float* hmid; float* mid; float* ws; size_t ws_bytes;
+} vh_encoder_layer_args;
+int vh_encoder_layer(const vh_encoder_layer_args* args, void* stream);
 
 /* nn.LayerNorm over the last dim (+ optional act, then * post_scale). */
 int vh_layernorm(const float* x, long ldx, float* y, long ldy, const float* w, const float* b, int rows, int cols,

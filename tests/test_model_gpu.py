@@ -146,12 +146,15 @@ def test_text_only_prompt_runs_dummy_encoders(tiny_model, dev):
 
 
 # ---- released-model layer geometry (2 layers each; oracle in fp64 numpy) -----------------------------
-def test_vit_real_geometry_two_layers(dev):
+@pytest.mark.parametrize("per_operator", [False, True])
+def test_vit_real_geometry_two_layers(dev, per_operator):
+    """per_operator: one C call per operator (vh_gemm[_ln] / vh_attention) instead of one per block (vh_encoder_layer)."""
     from vita_amd.model.encoders import InternViTVisionTower
     cfg = VitaConfig()
     cfg.vision = VisionConfig(num_hidden_layers=2)
     sd = synth_state_dict(cfg, seed=21, parts=("vision",))
     tower = InternViTVisionTower("InternViT-300M-448px", vcfg=cfg.vision)
+    tower.per_operator = per_operator
     tower.set_state_dict(sd, dev)
     rng = np.random.default_rng(22)
     pix = rng.standard_normal((1, 3, 448, 448)).astype(np.float32)
@@ -163,12 +166,14 @@ def test_vit_real_geometry_two_layers(dev):
     assert_close("vit real tower out", to_np(out), ref, atol=1e-3, rtol=1e-4)
 
 
-def test_whale_real_geometry_two_layers(dev):
+@pytest.mark.parametrize("per_operator", [False, True])
+def test_whale_real_geometry_two_layers(dev, per_operator):
     from vita_amd.model.encoders import WhaleAudioEncoder
     cfg = VitaConfig()
     cfg.audio = AudioConfig(num_hidden_layers=2)
     sd = synth_state_dict(cfg, seed=23, parts=("audio",))
     enc = WhaleAudioEncoder(sd, acfg=cfg.audio, device=dev, llm_dim=4096)
+    enc.per_operator = per_operator
     g = np.load(os.path.join(GOLD, "q1_audio.npz"))
     feats = g["fbank"]                                        # real fbank of asset/q1.wav: 352 frames -> 44 tokens
     out, mask, layers = enc.encode_one(torch.from_numpy(feats).to(dev), want_layers=True)

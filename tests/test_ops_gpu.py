@@ -89,6 +89,30 @@ def test_gemm_split_k(dev, ksplit):
     assert_close("ragged", got, a2.astype(np.float64) @ w2.T.astype(np.float64), atol=1e-4, rtol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,ksplit,with_bias", [(1025, 1024, 1024, 0, True), (249, 1024, 4096, 0, True), (249, 1024, 1024, 1, False),
+                                                   (5125, 1024, 1024, 0, True), (33, 256, 128, 0, False)])
+def test_gemm_with_layernorm(dev, M, N, K, ksplit, with_bias):
+    """vh_gemm_ln: the Linear (+ bias, layer scale, in-place residual) and the LayerNorm of its output in one call — through
+    the split-K reducer that norms whole rows (one tile / one clip), and through the norm launch that follows an unsplit
+    GEMM (5 tiles; ksplit = 1; tiny K) — against the fp64 composition (modeling_intern_vit.py:245-253)."""
+    from vita_amd import ops
+    rng = np.random.default_rng(M + N)
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = _w(rng, N, K)
+    bias, scale = _w(rng, N, std=0.5), _w(rng, N, std=1.0)
+    lw, lb = 1.0 + _w(rng, N, std=0.2), _w(rng, N, std=0.3)
+    x = rng.standard_normal((M, N), dtype=np.float32)
+    xd = _dev(x, dev)
+    out, h = ops.gemm(_dev(a, dev), _dev(w, dev, torch.bfloat16), bias=_dev(bias, dev), scale=_dev(scale, dev), resid=xd, out=xd,
+                      ksplit=ksplit, ln=(_dev(lw, dev), _dev(lb, dev) if with_bias else None, 1e-6))
+    assert out.data_ptr() == xd.data_ptr()
+    ref = (a.astype(np.float64) @ w.T + bias) * scale + x
+    mu, var = ref.mean(-1, keepdims=True), ref.var(-1, keepdims=True)
+    ref_h = (ref - mu) / np.sqrt(var + 1e-6) * lw + (lb if with_bias else 0.0)
+    assert_close("gemm_ln: C", to_np(xd), ref, atol=2e-5 * np.sqrt(K), rtol=2e-5)
+    assert_close("gemm_ln: LayerNorm(C)", to_np(h), ref_h, atol=5e-5 * np.sqrt(K), rtol=2e-5)
+
+
 def test_gemm_inplace_residual(dev):
     """out aliases resid (the x += proj(...) pattern)."""
     from vita_amd import ops

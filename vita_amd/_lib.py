@@ -55,6 +55,22 @@ class AttnArgs(C.Structure):
     ]
 
 
+class EncoderLayerArgs(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("h_in", c_void_p), ("h_out", c_void_p),
+        ("M", c_int), ("C", c_int), ("F", c_int), ("heads", c_int), ("B", c_int),
+        ("qkv_w", c_void_p), ("qkv_b", c_void_p),
+        ("proj_w", c_void_p), ("proj_b", c_void_p), ("ls1", c_void_p),
+        ("n2_w", c_void_p), ("n2_b", c_void_p),
+        ("fc1_w", c_void_p), ("fc1_b", c_void_p),
+        ("fc2_w", c_void_p), ("fc2_b", c_void_p), ("ls2", c_void_p),
+        ("next_w", c_void_p), ("next_b", c_void_p),
+        ("act", c_int), ("eps", c_float),
+        ("P", c_void_p), ("ldp", c_long), ("bias_u", c_void_p), ("bias_v", c_void_p), ("klen", c_int), ("chunk", c_int), ("left", c_int),
+        ("qkv", c_void_p), ("attn", c_void_p), ("hmid", c_void_p), ("mid", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t),
+    ]
+
+
 class MixtralCfg(C.Structure):
     _fields_ = [
         ("hidden", c_int), ("n_layers", c_int), ("n_q_heads", c_int), ("n_kv_heads", c_int),
@@ -80,9 +96,11 @@ SIGNATURES = {
     "vh_last_error": (C.c_char_p, []),
     "vh_tune": (c_int, [C.c_char_p, c_int]),
     "vh_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "vh_gemm_ln": (c_int, [C.POINTER(GemmArgs), c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p]),
     "vh_gemm_ps": (c_int, [C.POINTER(GemmPsArgs), c_void_p]),
     "vh_split_planes": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "vh_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "vh_encoder_layer": (c_int, [C.POINTER(EncoderLayerArgs), c_void_p]),
     "vh_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                              c_float, c_void_p]),
     "vh_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -70,9 +70,18 @@ int vh_tune(const char* key, int value) {
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
-int vh_gemm(const vh_gemm_args* a, void* stream) {
-    if (!a || !a->A || !a->W || !a->C) return fail(VH_E_ARG, "vh_gemm: null pointer");
+static int gemm_entry(const char* name, const vh_gemm_args* a, const float* ln_w, const float* ln_b, float ln_eps, float* ln_out,
+                      long ld_ln, void* stream);
+int vh_gemm(const vh_gemm_args* a, void* stream) { return gemm_entry("vh_gemm", a, nullptr, nullptr, 0.f, nullptr, 0, stream); }
+int vh_gemm_ln(const vh_gemm_args* a, const float* ln_w, const float* ln_b, float ln_eps, float* ln_out, long ld_ln, void* stream) {
+    if (!ln_w || !ln_out) return fail(VH_E_ARG, "vh_gemm_ln: null pointer");
+    return gemm_entry("vh_gemm_ln", a, ln_w, ln_b, ln_eps, ln_out, ld_ln, stream);
+}
+static int gemm_entry(const char* name, const vh_gemm_args* a, const float* ln_w, const float* ln_b, float ln_eps, float* ln_out,
+                      long ld_ln, void* stream) {
+    if (!a || !a->A || !a->W || !a->C) return fail(VH_E_ARG, "%s: null pointer", name);
     VhGemmArgs g{};
+    g.ln_w = ln_w; g.ln_b = ln_b; g.ln_eps = ln_eps; g.ln_out = ln_out; g.ld_ln = ld_ln;
     g.A = a->A; g.lda = a->lda; g.a_rows = a->a_rows; g.a_rowidx = a->a_rowidx;
     g.nseg = a->nseg; g.seglen = a->seglen;
     for (int i = 0; i < 16; ++i) g.segrow[i] = a->segrow[i];
@@ -82,8 +91,8 @@ int vh_gemm(const vh_gemm_args* a, void* stream) {
     g.bias = a->bias; g.scale = a->scale; g.resid = a->resid; g.ldr = a->ldr;
     g.M = a->M; g.N = a->N; g.K = a->K; g.act = a->act;
     g.ws = a->ws; g.ws_bytes = a->ws_bytes; g.ksplit = a->ksplit;
-    if ((a->lda % 4) != 0 || (a->ldw % 8) != 0) return fail(VH_E_SHAPE, "vh_gemm: lda%%4 / ldw%%8 alignment");
-    return check_launch("vh_gemm", vhk_gemm(S(stream), g));
+    if ((a->lda % 4) != 0 || (a->ldw % 8) != 0) return fail(VH_E_SHAPE, "%s: lda%%4 / ldw%%8 alignment", name);
+    return check_launch(name, vhk_gemm(S(stream), g));
 }
 
 int vh_gemm_ps(const vh_gemm_ps_args* a, void* stream) {
@@ -892,6 +901,50 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
         hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VH_E_HIP, "prefill: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
+int vh_encoder_layer(const vh_encoder_layer_args* a, void* stream) {
+    if (!a || !a->x || !a->h_in || !a->qkv_w || !a->proj_w || !a->n2_w || !a->fc1_w || !a->fc2_w || !a->qkv || !a->attn ||
+        !a->hmid || !a->mid)
+        return fail(VH_E_ARG, "vh_encoder_layer: null pointer");
+    const int M = a->M, Cw = a->C, F = a->F;
+    if (M < 1 || a->B < 1 || M % a->B != 0 || a->heads < 1 || Cw % a->heads != 0 || Cw % 64 != 0 || F % 64 != 0)
+        return fail(VH_E_SHAPE, "vh_encoder_layer: M %d B %d C %d F %d heads %d", M, a->B, Cw, F, a->heads);
+    const int d = Cw / a->heads, Sq = M / a->B;
+    if (d != 64 && d != 128) return fail(VH_E_SHAPE, "vh_encoder_layer: head_dim %d (64 or 128)", d);
+    if (a->P && (!a->bias_u || !a->bias_v || a->B != 1)) return fail(VH_E_ARG, "vh_encoder_layer: rel-pos needs bias_u / bias_v and B = 1");
+    if (a->h_out && !a->next_w) return fail(VH_E_ARG, "vh_encoder_layer: h_out without next_w");
+    hipStream_t st = S(stream);
+    auto lin = [&](const float* A, int K, const uint16_t* W, int N, const float* bias, int act, const float* scale, const float* resid,
+                   float* Cout, const float* lw, const float* lb, float* lout) {
+        VhGemmArgs g{};
+        g.A = A; g.lda = K; g.a_rows = M; g.nseg = 1; g.seglen = K;
+        g.W = W; g.ldw = K; g.C = Cout; g.ldc = N; g.M = M; g.N = N; g.K = K; g.act = act;
+        g.bias = bias; g.scale = scale; g.resid = resid; g.ldr = N;
+        g.ws = a->ws; g.ws_bytes = a->ws_bytes; g.ksplit = a->ws ? 0 : 1;
+        g.ln_w = lw; g.ln_b = lb; g.ln_eps = a->eps; g.ln_out = lout; g.ld_ln = N;
+        return vhk_gemm(st, g);
+    };
+    VH_TRY(lin(a->h_in, Cw, a->qkv_w, 3 * Cw, a->qkv_b, VH_ACT_NONE, nullptr, nullptr, a->qkv, nullptr, nullptr, nullptr), "encoder qkv");
+    {
+        VhAttnArgs g{};
+        g.Q = a->qkv; g.K = a->qkv + Cw; g.V = a->qkv + 2 * Cw;
+        g.ldq = g.ldk = g.ldv = 3L * Cw; g.hsq = g.hsk = g.hsv = d;
+        g.bsq = g.bsk = (long)Sq * 3 * Cw; g.bso = (long)Sq * Cw;
+        g.O = a->attn; g.ldo = Cw;
+        g.B = a->B; g.Hq = g.Hkv = a->heads; g.Sq = g.Sk = Sq; g.d = d;
+        g.klen = (a->klen >= 0 && a->klen < Sq) ? a->klen : Sq; g.chunk = a->chunk; g.left = a->left;
+        g.scale = 1.0f / sqrtf((float)d);
+        g.P = a->P; g.ldp = a->ldp; g.hsp = d; g.bias_u = a->bias_u; g.bias_v = a->bias_v;
+        VH_TRY(vhk_attn(st, g), "encoder attention");
+    }
+    VH_TRY(lin(a->attn, Cw, a->proj_w, Cw, a->proj_b, VH_ACT_NONE, a->ls1, a->x, a->x, a->n2_w, a->n2_b, a->hmid), "encoder proj");
+    VH_TRY(lin(a->hmid, Cw, a->fc1_w, F, a->fc1_b, a->act, nullptr, nullptr, a->mid, nullptr, nullptr, nullptr), "encoder fc1");
+    VH_TRY(lin(a->mid, F, a->fc2_w, Cw, a->fc2_b, VH_ACT_NONE, a->ls2, a->x, a->x, a->h_out ? a->next_w : nullptr, a->next_b,
+               a->h_out), "encoder fc2");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(VH_E_HIP, "vh_encoder_layer: %s", hipGetErrorString(e));
     return VH_OK;
 }
 

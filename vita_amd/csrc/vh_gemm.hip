@@ -272,12 +272,81 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const VhGemmArgs p, int ksp
     }
 }
 
+// The same reduction with one BLOCK per output row (N <= 4096), followed by the LayerNorm of that row (VhGemmArgs::ln_*):
+// the encoders' Linear -> (+ bias, layer scale, residual) -> LayerNorm chains (InternViT: modeling_intern_vit.py:245-253,
+// Whale: transformer.py encoder layer) cost one launch instead of reducer + norm.  Thread t owns the 16-byte chunks
+// t + 256 j; all slab loads of a chunk are issued before they are added (a first version with one wave per row and a
+// serial slab loop took 14-27 us against 5 + 7 for the two kernels it replaces: profiles/r03_encoder_pass_trace.txt).
+#define GR_MAXJ 4
+template <int KSP>
+__global__ __launch_bounds__(256) void k_gemm_reduce_ln(const VhGemmArgs p, int ksp_rt) {
+    __shared__ float red[4];
+    const long m = blockIdx.x;
+    const int nv = p.N >> 2;
+    const int ksp = KSP > 0 ? KSP : ksp_rt;
+    const size_t slab = (size_t)p.M * p.N;
+    f32x4 v[GR_MAXJ];
+    float s[1] = {0.f};
+#pragma unroll
+    for (int j = 0; j < GR_MAXJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c >= nv) continue;
+        const int n = c * 4;
+        const float* src = p.ws + (size_t)m * p.N + n;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        if (KSP > 0) {
+            f32x4 part[KSP > 1 ? KSP - 1 : 1];
+#pragma unroll
+            for (int k = 1; k < KSP; ++k) part[k - 1] = *reinterpret_cast<const f32x4*>(src + k * slab);
+#pragma unroll
+            for (int k = 1; k < KSP; ++k) a += part[k - 1];
+        } else {
+            for (int k = 1; k < ksp; ++k) a += *reinterpret_cast<const f32x4*>(src + k * slab);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = a[i];
+            if (p.bias) x += p.bias[n + i];
+            x = apply_act(x, p.act);
+            if (p.scale) x *= p.scale[n + i];
+            if (p.resid) x += p.resid[m * p.ldr + n + i];
+            a[i] = x;
+        }
+        *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = a;
+        v[j] = a;
+        s[0] += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    block256_sum<1>(s, red);
+    const float mean = s[0] / (float)p.N;
+    float q[1] = {0.f};
+#pragma unroll
+    for (int j = 0; j < GR_MAXJ; ++j) {
+        if (threadIdx.x + j * 256 < nv) {
+            const f32x4 d = v[j] - mean;
+            q[0] += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    block256_sum<1>(q, red);
+    const float inv = rsqrtf(q[0] / (float)p.N + p.ln_eps);
+#pragma unroll
+    for (int j = 0; j < GR_MAXJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c >= nv) continue;
+        const f32x4 ww = reinterpret_cast<const f32x4*>(p.ln_w)[c];
+        f32x4 r = (v[j] - mean) * inv * ww;
+        if (p.ln_b) r += reinterpret_cast<const f32x4*>(p.ln_b)[c];
+        *reinterpret_cast<f32x4*>(p.ln_out + m * p.ld_ln + c * 4) = r;
+    }
+}
+
 }  // namespace
 
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.K <= 0 || a.K % GM_BK != 0 || a.nseg < 1 || a.nseg > 16 || a.seglen % GM_BK != 0 ||
         a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0 || a.A == nullptr)
         return -1;
+    if (a.ln_out && (!a.ln_w || a.W_up || a.c_rowidx || a.group_off || (a.N % 4) != 0 || (a.ldc % 4) != 0 || (a.ld_ln % 4) != 0)) return -1;
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
     g.mt_slots = a.group_off ? (a.M / GM_BM + a.ngroups) : (a.M + GM_BM - 1) / GM_BM;  // grouped: upper bound
@@ -306,11 +375,24 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     } else {
         if (pf2) hipLaunchKernelGGL((k_gemm<false, 2, 3>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_gemm<false, 1, 4>), grid, dim3(256), 0, st, g);
+        const bool ln_fused = a.ln_out && ksp > 1 && a.N <= GR_MAXJ * 1024 && (a.ldc % 4) == 0 && (a.ld_ln % 4) == 0;
+        if (ksp > 1 && ln_fused) {
+            switch (ksp) {
+                case 2: hipLaunchKernelGGL(k_gemm_reduce_ln<2>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
+                case 3: hipLaunchKernelGGL(k_gemm_reduce_ln<3>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
+                case 4: hipLaunchKernelGGL(k_gemm_reduce_ln<4>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
+                case 6: hipLaunchKernelGGL(k_gemm_reduce_ln<6>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
+                case 8: hipLaunchKernelGGL(k_gemm_reduce_ln<8>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
+                default: hipLaunchKernelGGL(k_gemm_reduce_ln<0>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
+            }
+            return 0;
+        }
         if (ksp > 1) {
             long rg = ((long)a.M * (a.N / 4) + 255) / 256;
             if (rg > 2048) rg = 2048;
             hipLaunchKernelGGL(k_gemm_reduce, dim3((int)rg), dim3(256), 0, st, g, ksp);
         }
     }
+    if (a.ln_out) return vhk_layernorm(st, a.C, a.ldc, a.ln_out, a.ld_ln, a.ln_w, a.ln_b, a.M, a.N, a.ln_eps, VH_ACT_NONE, 1.0f);
     return 0;
 }

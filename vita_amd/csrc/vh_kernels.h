@@ -141,6 +141,9 @@ struct VhGemmArgs {
     // scratch for ksplit * M * N partial sums; a second kernel adds them and applies the epilogue.  ksplit 0 = the
     // launcher decides (only when ws is given), 1 = off.  Plain (ungrouped, non-gated, no row maps) GEMMs only.
     float* ws; size_t ws_bytes; int ksplit;
+    // (r03) the LayerNorm that consumes C, in the same call: ln_out[m, :] = LN(C[m, :]) * ln_w + ln_b (nullable ln_b).  With
+    // split-K the reducer already holds whole rows, so the norm costs no launch of its own; otherwise a norm launch follows.
+    const float* ln_w; const float* ln_b; float ln_eps; float* ln_out; long ld_ln;
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
 

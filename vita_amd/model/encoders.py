@@ -8,6 +8,7 @@ Same constructor-time names, forward signatures and return shapes; the arithmeti
 of libvita_hip.so kernels (vita_amd.ops), activations fp32, weights bf16.  nn.Module is used only
 as the container type the reference's callers expect (.to(), .eval(), attribute access)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -72,6 +73,8 @@ class InternViTVisionTower(_HipModule):
         self.image_processor = None
         self._sd = None
         self.w = None
+        # True: one library call per operator (vh_gemm / vh_attention / ...) instead of per block (debugging, A/B timing)
+        self.per_operator = os.environ.get("VITA_AMD_PER_OPERATOR", "0") == "1"
 
     # -- loading ------------------------------------------------------------------------------
     def set_state_dict(self, sd, device):
@@ -135,16 +138,35 @@ class InternViTVisionTower(_HipModule):
         x = ops.vit_assemble(pe, w["cls"], w["pos"], n, N, C)                    # [n*N, C]
         attn = torch.empty((n * N, C), dtype=torch.float32, device=self._device)
         layers = []
-        for L in w["layers"]:
-            h = ops.layernorm(x, L["n1w"], L["n1b"], v.layer_norm_eps)
+        # every LayerNorm after the first rides on the Linear that produces its input (ops.gemm(ln=...): the split-K reducer
+        # holds whole rows, so the norm costs no launch of its own at one tile)
+        h = ops.layernorm(x, w["layers"][0]["n1w"], w["layers"][0]["n1b"], v.layer_norm_eps) if w["layers"] else None
+        if not self.per_operator and w["layers"]:
+            # one library call per block (vh_encoder_layer): 24 host calls per pass instead of ~170
+            sc = ops.EncoderScratch(n * N, C, w["layers"][0]["fc1_w"].shape[0], self._device)
+            for li, L in enumerate(w["layers"]):
+                nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
+                ops.encoder_layer(x, h, sc.h[li & 1], L, sc, heads=nh, B=n, act="gelu", eps=v.layer_norm_eps,
+                                  next_norm=(nxt["n1w"], nxt["n1b"]) if nxt is not None else None)
+                h = sc.h[li & 1]
+                if want_layers:
+                    layers.append(x.clone().view(n, N, C))
+            out = ops.vit_pixel_shuffle(x, n, g, C, self.scale_pix_shuffle)
+            return (out, layers) if want_layers else out
+        for li, L in enumerate(w["layers"]):
             qkv = ops.gemm(h, L["qkv_w"], bias=L["qkv_b"])                        # [n*N, 3C] = (three, head, d)
             ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B=n, Hq=nh, Hkv=nh, Sq=N, Sk=N, d=d, ldq=3 * C,
                           hsq=d, ldk=3 * C, hsk=d, ldv=3 * C, hsv=d, ldo=C, bsq=N * 3 * C, bsk=N * 3 * C, bso=N * C,
                           scale=d ** -0.5)
-            ops.gemm(attn, L["proj_w"], bias=L["proj_b"], scale=L["ls1"], resid=x, out=x)
-            h = ops.layernorm(x, L["n2w"], L["n2b"], v.layer_norm_eps)
+            _, h = ops.gemm(attn, L["proj_w"], bias=L["proj_b"], scale=L["ls1"], resid=x, out=x,
+                            ln=(L["n2w"], L["n2b"], v.layer_norm_eps))
             m = ops.gemm(h, L["fc1_w"], bias=L["fc1_b"], act="gelu")
-            ops.gemm(m, L["fc2_w"], bias=L["fc2_b"], scale=L["ls2"], resid=x, out=x)
+            nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
+            if nxt is not None:
+                _, h = ops.gemm(m, L["fc2_w"], bias=L["fc2_b"], scale=L["ls2"], resid=x, out=x,
+                                ln=(nxt["n1w"], nxt["n1b"], v.layer_norm_eps))
+            else:
+                ops.gemm(m, L["fc2_w"], bias=L["fc2_b"], scale=L["ls2"], resid=x, out=x)
             if want_layers:
                 layers.append(x.clone().view(n, N, C))
         out = ops.vit_pixel_shuffle(x, n, g, C, self.scale_pix_shuffle)
@@ -219,6 +241,7 @@ class WhaleAudioEncoder(_HipModule):
         self.audio_processor = AudioEncoderProcessor()
         self.chunk, self.left = 0, -1
         self.normalized_input = False   # True: features already CMVN-normalised (vLLM-flavour extractor)
+        self.per_operator = os.environ.get("VITA_AMD_PER_OPERATOR", "0") == "1"   # one library call per operator, not per block
         self.w = None
         if sd is not None:
             self.load(sd, device)
@@ -266,6 +289,8 @@ class WhaleAudioEncoder(_HipModule):
                 "n2w": _f32(q("norm2.weight"), dev), "n2b": _f32(q("norm2.bias"), dev),
                 "w1": _bf(q("feed_forward.w_1.weight"), dev), "b1": _f32(q("feed_forward.w_1.bias"), dev),
                 "w2": _bf(q("feed_forward.w_2.weight"), dev), "b2": _f32(q("feed_forward.w_2.bias"), dev)})
+            Ld = w["layers"][-1]    # the block entry's names (ops.encoder_layer)
+            Ld.update(proj_w=Ld["out_w"], proj_b=Ld["out_b"], fc1_w=Ld["w1"], fc1_b=Ld["b1"], fc2_w=Ld["w2"], fc2_b=Ld["b2"])
         ad = "adpter."
         k = a.adapter_kernel
         w.update({"ad_w": _bf(g(ad + "conv1d2.weight").permute(0, 2, 1).reshape(2 * C, k * C), dev),
@@ -275,6 +300,21 @@ class WhaleAudioEncoder(_HipModule):
         self.pe = torch.from_numpy(sinusoid_table(a.max_pe_len, C)).to(dev)
         self.w = w
         self._idx_cache = {}
+        self._pos_proj = None       # [layers][cap, C]: linear_pos(pos_emb) of every layer for the first `cap` positions
+
+    def _pos_projections(self, T2):
+        """linear_pos(pos_emb[:T2]) of all layers.  The operand is the fixed sinusoid table (attention.py:26-37, :358-369: `p =
+        self.linear_pos(pos_emb)`), not the audio, so it is a function of the weights alone — folded once per table length
+        (grown in powers of two, rows [0, T2) of a longer fold are the fold of pos_emb[:T2]) like a RoPE table, instead of 24
+        GEMMs per clip.  100 MB at 1024 positions (40 s of audio)."""
+        cap = 0 if self._pos_proj is None else self._pos_proj[0].shape[0]
+        if T2 > cap:
+            cap = min(max(256, 1 << (T2 - 1).bit_length()), self.acfg.max_pe_len)
+            if T2 > cap:
+                raise ValueError(f"audio clip needs {T2} positions, the table holds {self.acfg.max_pe_len}")
+            pos = self.pe[:cap]
+            self._pos_proj = [ops.gemm(pos, L["pos_w"]) for L in self.w["layers"]]
+        return self._pos_proj
 
     def _conv2_rows(self, T1, F1):
         key = ("c2", T1, F1)
@@ -320,23 +360,37 @@ class WhaleAudioEncoder(_HipModule):
         y = ops.layernorm(y, w["emb_nw"], w["emb_nb"], 1e-5, act="relu", post_scale=math.sqrt(C))
         if dbg is not None:
             dbg["embed"] = y.clone()
-        pos = self.pe[:T2]
+        pos_proj = self._pos_projections(T2)
         o = torch.empty((T2, C), dtype=torch.float32, device=self._device)
         layers = []
-        for L in w["layers"]:
-            h = ops.layernorm(y, L["n1w"], L["n1b"], a.layer_norm_eps)
+        h = ops.layernorm(y, w["layers"][0]["n1w"], w["layers"][0]["n1b"], a.layer_norm_eps) if w["layers"] else None
+        block_calls = not self.per_operator and bool(w["layers"])
+        if block_calls:
+            sc = ops.EncoderScratch(T2, C, w["layers"][0]["fc1_w"].shape[0], self._device)
+            for li, L in enumerate(w["layers"]):
+                nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
+                nn_ = (nxt["n1w"], nxt["n1b"]) if nxt is not None else (w["an_w"], w["an_b"])
+                ops.encoder_layer(y, h, sc.h[li & 1], L, sc, heads=nh, B=1, act="relu", eps=a.layer_norm_eps,
+                                  next_norm=nn_, p=pos_proj[li], bias_u=L["u"], bias_v=L["v"], klen=klen, chunk=self.chunk,
+                                  left=self.left)
+                h = sc.h[li & 1]
+                if want_layers:
+                    layers.append(y.clone())
+        for li, L in enumerate(w["layers"] if not block_calls else []):
             qkv = ops.gemm(h, L["qkv_w"], bias=L["qkv_b"])
-            pp = ops.gemm(pos, L["pos_w"])
+            pp = pos_proj[li]
             ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], o, B=1, Hq=nh, Hkv=nh, Sq=T2, Sk=T2, d=dk, ldq=3 * C, hsq=dk,
                           ldk=3 * C, hsk=dk, ldv=3 * C, hsv=dk, ldo=C, scale=1.0 / math.sqrt(dk), klen=klen,
                           chunk=self.chunk, left=self.left, p=pp, ldp=C, hsp=dk, bias_u=L["u"], bias_v=L["v"])
-            ops.gemm(o, L["out_w"], bias=L["out_b"], resid=y, out=y)
-            h = ops.layernorm(y, L["n2w"], L["n2b"], a.layer_norm_eps)
+            _, h = ops.gemm(o, L["out_w"], bias=L["out_b"], resid=y, out=y, ln=(L["n2w"], L["n2b"], a.layer_norm_eps))
             f = ops.gemm(h, L["w1"], bias=L["b1"], act="relu")
-            ops.gemm(f, L["w2"], bias=L["b2"], resid=y, out=y)
+            # the norm after this layer: the next layer's norm1, or the encoder's after_norm
+            nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
+            nw, nb = (nxt["n1w"], nxt["n1b"]) if nxt is not None else (w["an_w"], w["an_b"])
+            _, h = ops.gemm(f, L["w2"], bias=L["b2"], resid=y, out=y, ln=(nw, nb, a.layer_norm_eps))
             if want_layers:
                 layers.append(y.clone())
-        y = ops.layernorm(y, w["an_w"], w["an_b"], a.layer_norm_eps)
+        y = h if w["layers"] else ops.layernorm(y, w["an_w"], w["an_b"], a.layer_norm_eps)
         if klen < T2:
             y[klen:].zero_()                                                                    # masked_fill_(~mask_pad, 0)
         rows3, T3 = self._adapter_rows(T2)

@@ -63,9 +63,10 @@ def _scratch(device, nbytes):
 
 def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=None, a_rowidx=None, a_rows=None,
          segrow=None, seglen=None, m=None, c_rowidx=None, group_off=None, ngroups=0, w_group_stride=0, lda=None,
-         ldc=None, ksplit=0):
+         ldc=None, ksplit=0, ln=None):
     """out[orow(m), :] = epilogue(A[arow(m, k)] @ w.T).  a: fp32 [rows, lda]; w: bf16 [N, K] (or [E, N, K] grouped).
-    ksplit: 0 = the library may split K over more blocks for small launches (plain GEMMs), 1 = never, n = n-way."""
+    ksplit: 0 = the library may split K over more blocks for small launches (plain GEMMs), 1 = never, n = n-way.
+    ln = (weight, bias or None, eps): also returns LayerNorm(out) — (out, ln_out) — from the same call (vh_gemm_ln)."""
     _dev(a, w, out)
     _f32(_c(a, "a"), "a"); _bf16(w, "w")
     if not w.is_contiguous():
@@ -102,6 +103,12 @@ def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=No
         # room for up to 8 partial-sum slabs, capped at 96 MB (the library lowers the split to what fits)
         ws = _scratch(a.device, min(8 * 4 * M * N, 96 << 20))
         g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
+    if ln is not None:
+        lw, lb, eps = ln
+        _dev(lw); _f32(_c(lw, "ln weight"), "ln weight")
+        ln_out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        check(lib.vh_gemm_ln(C.byref(g), _p(lw), _p(lb), float(eps), _p(ln_out), int(ln_out.stride(0)), _stream()), "vh_gemm_ln")
+        return out, ln_out
     check(lib.vh_gemm(C.byref(g), _stream()), "vh_gemm")
     return out
 
@@ -128,6 +135,44 @@ def attention(q, k, v, out, *, B, Hq, Hkv, Sq, Sk, d, ldq, hsq, ldk, hsk, ldv, h
     a.scale = float(scale)
     check(lib.vh_attention(C.byref(a), _stream()), "vh_attention")
     return out
+
+
+class EncoderScratch:
+    """Caller-owned scratch of vh_encoder_layer for [M, C] rows and an MLP of width F (reused by every layer of a pass)."""
+
+    def __init__(self, M, Cw, F, device):
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        self.M, self.C, self.F = M, Cw, F
+        self.qkv, self.attn, self.hmid, self.mid = f(M, 3 * Cw), f(M, Cw), f(M, Cw), f(M, F)
+        self.h = [f(M, Cw), f(M, Cw)]                       # LayerNorm outputs, ping-pong between layers
+        self.ws = _scratch(device, min(8 * 4 * M * max(3 * Cw, F), 96 << 20))
+
+
+def encoder_layer(x, h_in, h_out, L, sc, *, heads, B, act, eps, next_norm=None, p=None, bias_u=None, bias_v=None, klen=-1, chunk=0,
+                  left=-1):
+    """One pre-norm transformer block in ONE library call (vh_encoder_layer): x [M, C] updated in place, h_in = LN(x; norm1),
+    h_out = LN(x_out; next_norm) when next_norm = (w, b) is given.  L: dict of this layer's weights (qkv_w, qkv_b, proj_w,
+    proj_b, ls1?, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, ls2?)."""
+    _dev(x, h_in)
+    a = _lib.EncoderLayerArgs()
+    a.x, a.h_in, a.h_out = x.data_ptr(), h_in.data_ptr(), (h_out.data_ptr() if next_norm is not None else None)
+    a.M, a.C, a.F, a.heads, a.B = sc.M, sc.C, sc.F, int(heads), int(B)
+    if tuple(x.shape) != (sc.M, sc.C) or not x.is_contiguous() or not h_in.is_contiguous():
+        raise ValueError("encoder_layer: x / h_in must be contiguous [M, C] rows matching the scratch")
+    a.qkv_w, a.qkv_b = L["qkv_w"].data_ptr(), L["qkv_b"].data_ptr()
+    a.proj_w, a.proj_b, a.ls1 = L["proj_w"].data_ptr(), L["proj_b"].data_ptr(), _p(L.get("ls1"))
+    a.n2_w, a.n2_b = L["n2w"].data_ptr(), L["n2b"].data_ptr()
+    a.fc1_w, a.fc1_b = L["fc1_w"].data_ptr(), L["fc1_b"].data_ptr()
+    a.fc2_w, a.fc2_b, a.ls2 = L["fc2_w"].data_ptr(), L["fc2_b"].data_ptr(), _p(L.get("ls2"))
+    if next_norm is not None:
+        a.next_w, a.next_b = next_norm[0].data_ptr(), _p(next_norm[1])
+    a.act, a.eps = ACT[act], float(eps)
+    if p is not None:
+        a.P, a.ldp, a.bias_u, a.bias_v = p.data_ptr(), int(p.stride(0)), bias_u.data_ptr(), bias_v.data_ptr()
+    a.klen, a.chunk, a.left = int(klen), int(chunk), int(left)
+    a.qkv, a.attn, a.hmid, a.mid = sc.qkv.data_ptr(), sc.attn.data_ptr(), sc.hmid.data_ptr(), sc.mid.data_ptr()
+    a.ws, a.ws_bytes = sc.ws.data_ptr(), sc.ws.numel()
+    check(_lib.load().vh_encoder_layer(C.byref(a), _stream()), "vh_encoder_layer")
 
 
 def layernorm(x, w, b, eps, *, act=None, post_scale=1.0, out=None):
