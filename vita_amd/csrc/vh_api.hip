@@ -50,6 +50,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
     if (!strcmp(key, "attn_wpe")) { g_tuning.attn_wpe = value; return VH_OK; }
+    if (!strcmp(key, "attn_rows")) { g_tuning.attn_rows = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
@@ -671,7 +672,7 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     // (r03) K-split slabs are summed by the norm kernel that consumes the rows (VhRowUpdate) on the single-rank path;
     // vh_tune("prefill_fuse_rows", 0) restores the separate slab-sum / combine launches
     const bool fuse_rows = !tp && vh_tuning()->prefill_fuse_rows != 0 && stream_attn && vh_tuning()->prefill_moe_gemm == 0;
-    const bool attn_planes = stream_attn && vh_tuning()->attn_impl == 0 && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
+    const bool attn_planes = stream_attn && vh_tuning()->attn_impl != 1 && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
     bool combine_pending = false;
     int pend_nslab = 1;
     const int* pend_nslab_dev = nullptr;

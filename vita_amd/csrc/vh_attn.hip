@@ -453,6 +453,269 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 }
 
+
+// ---- bf16 x 3 variant of the direct-operand kernel (r03; default for the plain and causal call sites) -----------------
+// Same wave = 16 query rows x a share of the keys, same online softmax in the D layout, same merge — but the two matrix
+// products run on v_mfma_f32_16x16x32_bf16 with BOTH operands split into bf16 hi + lo (x = hi + lo to 2^-17, hardware
+// v_cvt_pk_bf16_f32) and three products per fragment pair (lo*hi + hi*lo + hi*hi; lo*lo is below 2^-17 of the term): the
+// precision class of the exact-mode GEMMs (vh_gemm.hip) at 3/16 of the matrix-pipe time of the fp32 MFMA
+// (16x16x4 f32: 2048 FLOP in 32 cycles; 16x16x32 bf16: 16384 FLOP in 16).  The 32-deep reduction changes the operand
+// shapes, not the loads:
+//   S = Q K^T : lane (lr, lg) holds Q[row lr][32c + 8lg ..+8] and K[key lr][32c + 8lg ..+8] — two float4 each per chunk c;
+//   O += P V  : A = P[row lr][keys 8lg ..+8] (8 consecutive floats of the wave-private LDS patch, one ds_read_b128 pair),
+//               B_t = V[keys 8lg + u][lr*(D/16) + t], u = 0..7: the lane loads V[key][lr*(D/16) ..] for its 8 keys (as the
+//               fp32 kernel does for 4) and pairs the values ALONG THE KEYS when it converts them (v_cvt_pk takes two
+//               registers), so the transposition costs nothing.
+// Rel-pos attention (Whale, 12 us) stays on the fp32 kernel.
+typedef __attribute__((ext_vector_type(2))) float at_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 at_bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int at_u32x4;
+__device__ __forceinline__ void at_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const at_f32x2 v = {a, b};
+    const at_bf16x2 h = __builtin_convertvector(v, at_bf16x2);
+    const at_f32x2 r = v - __builtin_convertvector(h, at_f32x2);
+    const at_bf16x2 l = __builtin_convertvector(r, at_bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void at_split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    uint32_t h[4], l[4];
+    at_split2(a[0], a[1], h[0], l[0]);
+    at_split2(a[2], a[3], h[1], l[1]);
+    at_split2(b[0], b[1], h[2], l[2]);
+    at_split2(b[2], b[3], h[3], l[3]);
+    hi = __builtin_bit_cast(bf16x8, at_u32x4{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(bf16x8, at_u32x4{l[0], l[1], l[2], l[3]});
+}
+#define AT_PSTR3 36     // patch row stride (floats): 16-byte aligned 8-float reads at 8 lg, rows 4 banks apart mod 64
+
+// RT = 16-row tiles per wave.  With one tile the launch is bound by operand traffic, not by either pipe: every wave pulls
+// the whole K and V of its head through L2 -> registers (ViT: 4160 waves x 128 KB = 532 MB per launch, 8.7 TB/s at 61 us;
+// the fp32 kernel moved the same bytes in 78 us).  Two tiles per wave (d = 64) halve the bytes and the conversions per row.
+// MODE fixes the mask flavour at compile time (0 = pad mask only, 1 = causal, 2 = causal + KV page table): with the flavours
+// as run-time branches the loop body held 34 branches / 20 exec-mask regions, each a scheduling barrier between the loads,
+// conversions and MFMAs it should interleave.
+template <int D, int KS, int WPE, int RT, int MODE>
+__global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_attn_x3(const VhAttnArgs p) {
+    constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
+    constexpr int NC = D / 16;          // output column tiles = floats of a V row per lane
+    constexpr int VQ = NC / 4;          // float4s of V per lane per key
+    constexpr int C32 = D / 32;         // 32-deep chunks of the head dimension
+    constexpr int MGW = RT * (8 + NC * 4);
+    __shared__ __attribute__((aligned(16))) float Ps[KS][RT][16 * AT_PSTR3];
+    __shared__ __attribute__((aligned(16))) float Mg[(KS > 1 ? KS - 1 : 1) * 64 * MGW];
+
+    const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (p.Hq / p.Hkv);
+    const int q0 = blockIdx.x * 16 * RT;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
+    const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
+    const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
+
+    bf16x8 qh[RT][C32], ql[RT][C32];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int q = min(q0 + 16 * rt + lr, p.Sq - 1);     // rows past Sq compute on a copy of the last row, never stored
+#pragma unroll
+        for (int c = 0; c < C32; ++c) {
+            const float* src = Qb + (size_t)q * p.ldq + 32 * c + 8 * lg;
+            at_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), qh[rt][c], ql[rt][c]);
+        }
+    }
+
+    const int kend = min(p.Sk, p.klen);
+    int kloop = kend;
+    if (CAUSAL) kloop = min(kloop, min(q0 + 16 * RT - 1, p.Sq - 1) + p.q_off + 1);
+
+    float m[RT][4], l[RT][4];
+    f32x4 o[RT][NC];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m[rt][r] = -INFINITY; l[rt][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NC; ++t) o[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    f32x4 kf[2][C32][2], vf[8][VQ];
+    auto phys = [&](int key) __attribute__((always_inline)) {
+        key = min(key, p.Sk - 1);
+        return PAGED ? p.ktable[key >> 6] * 64 + (key & 63) : key;
+    };
+    auto load_k = [&](int kt0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const float* row = Kb + (size_t)phys(kt0 + 16 * jt + lr) * p.ldk + 8 * lg;
+#pragma unroll
+            for (int c = 0; c < C32; ++c) {
+                kf[jt][c][0] = *reinterpret_cast<const f32x4*>(row + 32 * c);
+                kf[jt][c][1] = *reinterpret_cast<const f32x4*>(row + 32 * c + 4);
+            }
+        }
+    };
+    auto load_v = [&](int kt0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* row = Vb + (size_t)phys(kt0 + 8 * lg + u) * p.ldv + lr * NC;
+#pragma unroll
+            for (int j = 0; j < VQ; ++j) vf[u][j] = *reinterpret_cast<const f32x4*>(row + 4 * j);
+        }
+    };
+
+    constexpr int STEP = KS * AT_KT;
+    int kt0 = kg * AT_KT;
+    load_k(kt0);
+    load_v(kt0);
+    for (; kt0 < kloop; kt0 += STEP) {
+        // ---- S = Q K^T for the two 16-key sub-tiles: 3 bf16 products per 32-deep chunk, K converted once for all row tiles
+        f32x4 sacc[RT][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) sacc[rt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < C32; ++c) {
+                bf16x8 kh, kl;
+                at_split8(kf[jt][c][0], kf[jt][c][1], kh, kl);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 a = sacc[rt][jt];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[rt][c], kh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kh, a, 0, 0, 0);
+                    sacc[rt][jt] = a;
+                }
+            }
+        }
+        load_k(kt0 + STEP);                                  // (clamped) K of this wave's next tile: lands under softmax + PV
+
+        // ---- online softmax in D layout: lane holds S[q0 + 16rt + 4lg + r][kt0 + 16jt + lr] ---------------------------
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float* ps = Ps[kg][rt];
+            float alpha[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + 16 * rt + lg * 4 + r;
+                float s0 = sacc[rt][0][r] * p.scale, s1 = sacc[rt][1][r] * p.scale;
+                const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;      // keys < klim are visible
+                s0 = (kt0 + lr < klim) ? s0 : -INFINITY;
+                s1 = (kt0 + 16 + lr < klim) ? s1 : -INFINITY;
+                const float mx = grp16_max(fmaxf(s0, s1));
+                const float mn = fmaxf(m[rt][r], mx);
+                const bool none = mn == -INFINITY;                                // nothing visible yet: exp(-inf + inf) is discarded
+                alpha[r] = none ? 1.f : __expf(m[rt][r] - mn);
+                const float p0 = none ? 0.f : __expf(s0 - mn);
+                const float p1 = none ? 0.f : __expf(s1 - mn);
+                l[rt][r] = l[rt][r] * alpha[r] + grp16_sum(p0 + p1);
+                m[rt][r] = mn;
+                ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
+                ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
+            }
+#pragma unroll
+            for (int t = 0; t < NC; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[rt][t][r] *= alpha[r];
+        }
+        // the patches are private to this wave: its LDS operations execute in order, only the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- O += P V: one 32-key step, 3 products per output column tile, V converted once for all row tiles ----------
+        bf16x8 ph[RT], pl[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float* ps = Ps[kg][rt];
+            at_split8(*reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg),
+                      *reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg + 4), ph[rt], pl[rt]);
+        }
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            uint32_t vh[4], vl[4];
+#pragma unroll
+            for (int u2 = 0; u2 < 4; ++u2)
+                at_split2(vf[2 * u2][t >> 2][t & 3], vf[2 * u2 + 1][t >> 2][t & 3], vh[u2], vl[u2]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, at_u32x4{vh[0], vh[1], vh[2], vh[3]});
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, at_u32x4{vl[0], vl[1], vl[2], vl[3]});
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                o[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rt], bh, o[rt][t], 0, 0, 0);
+                o[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bl, o[rt][t], 0, 0, 0);
+                o[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bh, o[rt][t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // patch reads are done before the next tile rewrites them
+        load_v(kt0 + STEP);                                  // lands under the next S and softmax
+    }
+
+    // ---- merge the key shares into wave 0, in wave order (deterministic) ---------------------------------------------
+    if (KS > 1) {
+        if (kg > 0) {
+            float* mg = Mg + ((kg - 1) * 64 + lane) * MGW;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float* mr = mg + rt * (8 + NC * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mr[r] = m[rt][r]; mr[4 + r] = l[rt][r]; }
+#pragma unroll
+                for (int t = 0; t < NC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mr[8 + t * 4 + r] = o[rt][t][r];
+            }
+        }
+        __syncthreads();
+        if (kg > 0) return;
+        for (int g = 1; g < KS; ++g) {
+            const float* mg = Mg + ((g - 1) * 64 + lane) * MGW;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* mr = mg + rt * (8 + NC * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m2 = mr[r], l2 = mr[4 + r];
+                    const float mn = fmaxf(m[rt][r], m2);
+                    const float a1 = (mn == -INFINITY) ? 1.f : __expf(m[rt][r] - mn);
+                    const float a2 = (mn == -INFINITY) ? 0.f : __expf(m2 - mn);
+                    l[rt][r] = l[rt][r] * a1 + l2 * a2;
+                    m[rt][r] = mn;
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[rt][t][r] = o[rt][t][r] * a1 + mr[8 + t * 4 + r] * a2;
+                }
+            }
+        }
+    }
+
+    float* Ob = p.O ? p.O + (size_t)b * p.bso + (size_t)h * D : nullptr;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + 16 * rt + lg * 4 + r;
+            if (q >= p.Sq) continue;
+            const float inv = (l[rt][r] > 0.f) ? 1.0f / l[rt][r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < VQ; ++j) {
+                const f32x4 v = f32x4{o[rt][4 * j][r] * inv, o[rt][4 * j + 1][r] * inv, o[rt][4 * j + 2][r] * inv, o[rt][4 * j + 3][r] * inv};
+                if (Ob) *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) = v;
+                if (p.O_hi) {
+                    uint32_t hi[2], lo[2];
+                    at_split2(v[0], v[1], hi[0], lo[0]);
+                    at_split2(v[2], v[3], hi[1], lo[1]);
+                    const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                    *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0], hi[1]);
+                    *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0], lo[1]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
@@ -464,7 +727,7 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
     auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     if (!a.O && !a.O_hi) return -1;
     if (a.O_hi && (!a.O_lo || a.B != 1 || (a.ldo_split % 4) != 0 || !al16(a.O_hi) || !al16(a.O_lo))) return -1;
-    const bool direct_ok = vh_tuning()->attn_impl == 0 && al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
+    const bool direct_ok = vh_tuning()->attn_impl != 1 && al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
                            (!rel || (al16(a.bias_u) && al16(a.bias_v) && (a.ldp % 4) == 0 && (a.hsp % 4) == 0)) &&
                            ((a.ldq | a.hsq | a.bsq | a.ldk | a.hsk | a.bsk | a.ldv | a.hsv | a.ldo | a.bso) % 4) == 0;
     if (direct_ok && (a.d == 64 || (a.d == 128 && !rel))) {
@@ -478,6 +741,25 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
 #define AT_LAUNCH(DD, RR, KK) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, 2>), g16, dim3(64 * KK), 0, st, a)
 #define AT_LAUNCH_W(DD, RR, KK, WW) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, WW>), g16, dim3(64 * KK), 0, st, a)
         const int wpe = vh_tuning()->attn_wpe;
+        // bf16 x 3 products (attn_impl 2: the fp32-MFMA kernel below).  Mask flavours are compile-time: pad mask only, causal,
+        // causal + page table; anything else (chunk masks, a page table without causal) takes the fp32 kernel.
+        const int mode = a.chunk > 0 ? -1 : (!a.causal ? (a.ktable ? -1 : 0) : (a.ktable ? 2 : 1));
+        if (!rel && vh_tuning()->attn_impl == 0 && mode >= 0) {
+            const dim3 g32((a.Sq + 31) / 32, a.Hq, a.B);
+            const bool two = a.d == 64 && mode == 0 && vh_tuning()->attn_rows == 32;   // 32 rows per wave: measured slower, kept as a tested option
+#define X3(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM>), G, dim3(64 * KK), 0, st, a)
+#define X3_MODES(DD, KK, WW) do { if (mode == 0) X3(DD, KK, WW, 1, 0, g16); else if (mode == 1) X3(DD, KK, 2, 1, 1, g16); else X3(DD, KK, 2, 1, 2, g16); } while (0)
+            if (two) {
+                if (ks == 1) X3(64, 1, 2, 2, 0, g32); else if (ks == 2) X3(64, 2, 2, 2, 0, g32); else X3(64, 4, 2, 2, 0, g32);
+            } else if (a.d == 64) {
+                if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else if (wpe == 2) X3_MODES(64, 4, 2); else X3_MODES(64, 4, 3);
+            } else {
+                if (ks == 1) X3_MODES(128, 1, 2); else X3_MODES(128, 2, 2);
+            }
+#undef X3_MODES
+#undef X3
+            return 0;
+        }
         if (a.d == 64 && !rel) {
             if (ks == 1) AT_LAUNCH(64, false, 1);
             else if (ks == 2) AT_LAUNCH(64, false, 2);

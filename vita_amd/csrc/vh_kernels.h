@@ -20,7 +20,8 @@ struct VhTuning {
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
     int attn_wpe = 3;          // plain d = 64 attention (ViT): waves per SIMD the register allocation aims at (2: 182 VGPRs, 3: 145, 4: 128 + spills)
-    int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernel (16 rows per wave, no LDS tiles), 1 = LDS-tiled kernel
+    int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernels (16 rows per wave, no LDS tiles; plain / causal on bf16 x 3 MFMAs), 1 = LDS-tiled fp32 kernel, 2 = direct-operand fp32-MFMA kernel everywhere
+    int attn_rows = 0;         // bf16 x 3 attention at d = 64: query rows per wave, 0 = auto (32 when the launch still fills the chip), 16, 32
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
     int prefill_fuse_rows = 1; // single-rank prefill: K-split slabs summed by the consuming norm kernel (VhRowUpdate); 0 = separate slab-sum / combine launches
