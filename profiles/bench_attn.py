@@ -40,8 +40,8 @@ vc = torch.randn((nkv, ctx, d2), device=dev, generator=g)
 out2 = torch.empty((S, nq * d2), device=dev)
 pre = lambda: ops.attention(q2, kc, vc, out2, B=1, Hq=nq, Hkv=nkv, Sq=S, Sk=S, d=d2, ldq=nq * d2, hsq=d2, ldk=d2, hsk=ctx * d2,
                             ldv=d2, hsv=ctx * d2, ldo=nq * d2, scale=d2 ** -0.5, causal=True, q_off=0)
-DEFAULTS = {"attn_impl": 0, "attn_ksplit": 0, "attn_wpe": 3, "attn_rows": 0}
-VARIANTS = [{}, {"attn_impl": 2}, {"attn_ksplit": 1}, {"attn_ksplit": 2}, {"attn_wpe": 2}, {"attn_ksplit": 2, "attn_wpe": 2},
+DEFAULTS = {"attn_impl": 0, "attn_ksplit": 0, "attn_wpe": 0, "attn_rows": 0}
+VARIANTS = [{}, {"attn_impl": 2}, {"attn_ksplit": 1}, {"attn_ksplit": 2}, {"attn_wpe": 3}, {"attn_ksplit": 2, "attn_wpe": 3},
             {"attn_rows": 32}, {"attn_rows": 32, "attn_ksplit": 2}, {"attn_rows": 32, "attn_ksplit": 1}]
 for v in VARIANTS:
     for k, val in {**DEFAULTS, **v}.items():

@@ -719,7 +719,7 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             a.O = m->pattn; a.ldo = (long)nq * hd;
             a.B = 1; a.Hq = nq; a.Hkv = nkv; a.Sq = Sn; a.Sk = pos0 + Sn; a.d = hd;
             a.causal = 1; a.q_off = pos0; a.klen = pos0 + Sn; a.chunk = 0; a.left = -1; a.scale = scale;
-            a.ktable = m->table;
+            a.ktable = m->table; a.kv_rows = m->c.max_ctx;
             if (attn_planes) { a.O = nullptr; a.O_hi = m->ph_hi; a.O_lo = m->ph_lo; a.ldo_split = (long)nq * hd; }
             VH_TRY(vhk_attn(st, a), "attention");
         }

@@ -541,27 +541,33 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 
     f32x4 kf[2][C32][2], vf[8][VQ];
-    auto phys = [&](int key) __attribute__((always_inline)) {
-        key = min(key, p.Sk - 1);
-        return PAGED ? p.ktable[key >> 6] * 64 + (key & 63) : key;
+    // Row addresses are a uniform base + a 32-bit byte offset from a 24-bit multiply (the launcher checks that rows x stride
+    // fits): the first version spent 63 quarter-rate 32/64-bit multiplies and ~100 more VALU per tile on 64-bit row pointers,
+    // a third of the loop's issue cycles in a kernel that is VALU-bound.
+    const unsigned ldk = (unsigned)p.ldk, ldv = (unsigned)p.ldv;
+    const int klast = p.Sk - 1;
+    auto row_bytes = [&](int key, unsigned ld, unsigned col) __attribute__((always_inline)) {
+        key = min(key, klast);
+        if (PAGED) key = p.ktable[key >> 6] * 64 + (key & 63);
+        return (__umul24((unsigned)key, ld) + col) * 4u;
     };
     auto load_k = [&](int kt0) __attribute__((always_inline)) {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            const float* row = Kb + (size_t)phys(kt0 + 16 * jt + lr) * p.ldk + 8 * lg;
+            const char* row = reinterpret_cast<const char*>(Kb) + row_bytes(kt0 + 16 * jt + lr, ldk, 8 * lg);
 #pragma unroll
             for (int c = 0; c < C32; ++c) {
-                kf[jt][c][0] = *reinterpret_cast<const f32x4*>(row + 32 * c);
-                kf[jt][c][1] = *reinterpret_cast<const f32x4*>(row + 32 * c + 4);
+                kf[jt][c][0] = *reinterpret_cast<const f32x4*>(row + 128 * c);
+                kf[jt][c][1] = *reinterpret_cast<const f32x4*>(row + 128 * c + 16);
             }
         }
     };
     auto load_v = [&](int kt0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float* row = Vb + (size_t)phys(kt0 + 8 * lg + u) * p.ldv + lr * NC;
+            const char* row = reinterpret_cast<const char*>(Vb) + row_bytes(kt0 + 8 * lg + u, ldv, lr * NC);
 #pragma unroll
-            for (int j = 0; j < VQ; ++j) vf[u][j] = *reinterpret_cast<const f32x4*>(row + 4 * j);
+            for (int j = 0; j < VQ; ++j) vf[u][j] = *reinterpret_cast<const f32x4*>(row + 16 * j);
         }
     };
 
@@ -740,19 +746,28 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
         // blocks for the ViT's 1040 instead of 512), 2 elsewhere (rel-pos and d = 128 need > 200 registers)
 #define AT_LAUNCH(DD, RR, KK) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, 2>), g16, dim3(64 * KK), 0, st, a)
 #define AT_LAUNCH_W(DD, RR, KK, WW) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, WW>), g16, dim3(64 * KK), 0, st, a)
-        const int wpe = vh_tuning()->attn_wpe;
+        const int wpe_raw = vh_tuning()->attn_wpe;          // 0 = auto: 3 for the fp32 kernel, 2 for bf16 x 3 (3 spills inside its loop)
+        const int wpe = wpe_raw == 0 ? 3 : wpe_raw;
         // bf16 x 3 products (attn_impl 2: the fp32-MFMA kernel below).  Mask flavours are compile-time: pad mask only, causal,
         // causal + page table; anything else (chunk masks, a page table without causal) takes the fp32 kernel.
-        const int mode = a.chunk > 0 ? -1 : (!a.causal ? (a.ktable ? -1 : 0) : (a.ktable ? 2 : 1));
+        int mode = a.chunk > 0 ? -1 : (!a.causal ? (a.ktable ? -1 : 0) : (a.ktable ? 2 : 1));
+        {   // 32-bit byte offsets inside one head's K / V: rows (24-bit) x stride (24-bit) + a row, in bytes, below 2^32
+            const long rows = a.ktable ? (a.kv_rows > 0 ? a.kv_rows : (1L << 24)) : a.Sk;
+            const long ldmax = a.ldk > a.ldv ? a.ldk : a.ldv;
+            if (rows >= (1L << 24) || ldmax >= (1L << 24) || ldmax < 0 || (rows * ldmax + a.d) * 4 >= (1L << 32)) mode = -1;
+        }
         if (!rel && vh_tuning()->attn_impl == 0 && mode >= 0) {
             const dim3 g32((a.Sq + 31) / 32, a.Hq, a.B);
-            const bool two = a.d == 64 && mode == 0 && vh_tuning()->attn_rows == 32;   // 32 rows per wave: measured slower, kept as a tested option
+            // 32 rows per wave (K / V loaded and converted once for two row tiles): 57 against 63 us on the ViT once the loop
+            // was VALU-lean; only when the launch still gives every SIMD two waves
+            const int rows = vh_tuning()->attn_rows;
+            const bool two = a.d == 64 && mode == 0 && (rows == 32 || (rows == 0 && (long)g32.x * g32.y * g32.z * ks >= 8L * vh_num_cus()));
 #define X3(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM>), G, dim3(64 * KK), 0, st, a)
 #define X3_MODES(DD, KK, WW) do { if (mode == 0) X3(DD, KK, WW, 1, 0, g16); else if (mode == 1) X3(DD, KK, 2, 1, 1, g16); else X3(DD, KK, 2, 1, 2, g16); } while (0)
             if (two) {
                 if (ks == 1) X3(64, 1, 2, 2, 0, g32); else if (ks == 2) X3(64, 2, 2, 2, 0, g32); else X3(64, 4, 2, 2, 0, g32);
             } else if (a.d == 64) {
-                if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else if (wpe == 2) X3_MODES(64, 4, 2); else X3_MODES(64, 4, 3);
+                if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else if (wpe_raw != 3) X3_MODES(64, 4, 2); else X3_MODES(64, 4, 3);
             } else {
                 if (ks == 1) X3_MODES(128, 1, 2); else X3_MODES(128, 2, 2);
             }

@@ -19,7 +19,7 @@ struct VhTuning {
                                // (S = n rows sorted by expert, every touched expert streamed once); 0 = never
     int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
-    int attn_wpe = 3;          // plain d = 64 attention (ViT): waves per SIMD the register allocation aims at (2: 182 VGPRs, 3: 145, 4: 128 + spills)
+    int attn_wpe = 0;          // d = 64 attention: waves per SIMD the register allocation aims at; 0 = auto (fp32 kernel 3: 145 VGPRs; bf16 x 3 kernel 2: 216, no spills)
     int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernels (16 rows per wave, no LDS tiles; plain / causal on bf16 x 3 MFMAs), 1 = LDS-tiled fp32 kernel, 2 = direct-operand fp32-MFMA kernel everywhere
     int attn_rows = 0;         // bf16 x 3 attention at d = 64: query rows per wave, 0 = auto (32 when the launch still fills the chip), 16, 32
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
@@ -185,6 +185,7 @@ struct VhAttnArgs {
     int chunk, left;                      // chunk>0: whale chunk mask (utils.py:88-103); left<0 = all left chunks
     float scale;
     const int* ktable;                    // nullable: keys / values live in 64-row pages, logical block j>>6 -> page ktable[j>>6]
+    long kv_rows;                         // rows a page-table entry may address (the pool); 0 = Sk.  Bounds the 32-bit offsets of k_attn_x3
 };
 int vhk_attn(hipStream_t st, const VhAttnArgs& a);
 
