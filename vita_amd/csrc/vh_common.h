@@ -24,11 +24,14 @@ __device__ __forceinline__ float bf16_lo_to_f32(uint32_t packed) { return __uint
 __device__ __forceinline__ float bf16_hi_to_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
-// round-to-nearest-even f32 -> bf16 bit pattern (inputs are finite here).
+// round-to-nearest-even f32 -> bf16 bit pattern: gfx950's converter (v_cvt_pk_bf16_f32).  (r01-r02 did this in integer
+// arithmetic: ~5 VALU per conversion, 14 per hi/lo split — which made the general GEMM's operand staging, 16 values per thread
+// and K-tile, cost more issue cycles than its 32 MFMAs.)
+typedef __attribute__((ext_vector_type(2))) float vh_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vh_bf16x2;
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    const __bf16 b = (__bf16)f;
+    return (uint32_t)__builtin_bit_cast(unsigned short, b);
 }
 
 // x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi); |x - hi - lo| <= 2^-17 |x|.
@@ -36,6 +39,15 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) 
     hi = f32_to_bf16_rne(x);
     float r = x - __uint_as_float(hi << 16);
     lo = f32_to_bf16_rne(r);
+}
+// The same for two values at once, results PACKED (a in the low half): 5 VALU per pair (cvt_pk, and, lshl, pk_add, cvt_pk).
+__device__ __forceinline__ void split_bf16_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const vh_f32x2 v = {a, b};
+    const vh_bf16x2 h = __builtin_convertvector(v, vh_bf16x2);
+    const vh_f32x2 r = v - __builtin_convertvector(h, vh_f32x2);
+    const vh_bf16x2 l = __builtin_convertvector(r, vh_bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
 }
 
 // 8 bf16 (one 16-byte chunk) dotted with 8 fp32 activations.

@@ -159,11 +159,11 @@ __global__ __launch_bounds__(256) void k_rmsnorm_route(float* __restrict__ x, fl
             const f32x4 r = v[j] * inv;
             if (y) reinterpret_cast<f32x4*>(y + (size_t)row * cols)[c] = r;
             if (y_hi) {
-                uint32_t hi[4], lo[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) split_bf16(r[i], hi[i], lo[i]);
-                reinterpret_cast<uint2*>(y_hi + (size_t)row * cols)[c] = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-                reinterpret_cast<uint2*>(y_lo + (size_t)row * cols)[c] = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                uint32_t hi[2], lo[2];
+                split_bf16_pair(r[0], r[1], hi[0], lo[0]);
+                split_bf16_pair(r[2], r[3], hi[1], lo[1]);
+                reinterpret_cast<uint2*>(y_hi + (size_t)row * cols)[c] = make_uint2(hi[0], hi[1]);
+                reinterpret_cast<uint2*>(y_lo + (size_t)row * cols)[c] = make_uint2(lo[0], lo[1]);
             }
         }
     }

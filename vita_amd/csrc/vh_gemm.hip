@@ -134,13 +134,11 @@ void k_gemm(const VhGemmArgs p) {
             const uint4 f0 = ra[c * 2], f1 = ra[c * 2 + 1];
             const uint32_t v[8] = {f0.x & keep, f0.y & keep, f0.z & keep, f0.w & keep,
                                    f1.x & keep, f1.y & keep, f1.z & keep, f1.w & keep};
-            uint32_t hi[8], lo[8];
+            uint32_t hi[4], lo[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) split_bf16(__uint_as_float(v[i]), hi[i], lo[i]);
-            const uint4 ph = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16),
-                                        hi[6] | (hi[7] << 16));
-            const uint4 pl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16),
-                                        lo[6] | (lo[7] << 16));
+            for (int i = 0; i < 4; ++i) split_bf16_pair(__uint_as_float(v[2 * i]), __uint_as_float(v[2 * i + 1]), hi[i], lo[i]);
+            const uint4 ph = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            const uint4 pl = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             const int off = lds_off(arow, achunk0 + c);
             *reinterpret_cast<uint4*>(lds_ahi + off) = ph;
             *reinterpret_cast<uint4*>(lds_alo + off) = pl;

@@ -408,16 +408,16 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = v[r];
                 }
                 if (p.C_hi) {
-                    uint32_t hi[4], lo[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) split_bf16(v[r], hi[r], lo[r]);
+                    uint32_t hi[2], lo[2];
+                    split_bf16_pair(v[0], v[1], hi[0], lo[0]);
+                    split_bf16_pair(v[2], v[3], hi[1], lo[1]);
                     uint16_t* hp = p.C_hi + orow * p.ldc_split + n;
                     uint16_t* lp = p.C_lo + orow * p.ldc_split + n;
                     if (full && ((p.ldc_split & 3) == 0)) {
-                        *reinterpret_cast<uint2*>(hp) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-                        *reinterpret_cast<uint2*>(lp) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                        *reinterpret_cast<uint2*>(hp) = make_uint2(hi[0], hi[1]);
+                        *reinterpret_cast<uint2*>(lp) = make_uint2(lo[0], lo[1]);
                     } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) { hp[r] = (uint16_t)hi[r]; lp[r] = (uint16_t)lo[r]; }
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) { hp[r] = (uint16_t)(hi[r >> 1] >> (16 * (r & 1))); lp[r] = (uint16_t)(lo[r >> 1] >> (16 * (r & 1))); }
                     }
                 }
             }
@@ -450,16 +450,16 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) cp[r] = v[r];
                 }
                 if (p.C_hi) {
-                    uint32_t hi[4], lo[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) split_bf16(v[r], hi[r], lo[r]);
+                    uint32_t hi[2], lo[2];
+                    split_bf16_pair(v[0], v[1], hi[0], lo[0]);
+                    split_bf16_pair(v[2], v[3], hi[1], lo[1]);
                     uint16_t* hp = p.C_hi + orow * p.ldc_split + n;
                     uint16_t* lp = p.C_lo + orow * p.ldc_split + n;
                     if (full && ((p.ldc_split & 3) == 0)) {
-                        *reinterpret_cast<uint2*>(hp) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-                        *reinterpret_cast<uint2*>(lp) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                        *reinterpret_cast<uint2*>(hp) = make_uint2(hi[0], hi[1]);
+                        *reinterpret_cast<uint2*>(lp) = make_uint2(lo[0], lo[1]);
                     } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) { hp[r] = (uint16_t)hi[r]; lp[r] = (uint16_t)lo[r]; }
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) { hp[r] = (uint16_t)(hi[r >> 1] >> (16 * (r & 1))); lp[r] = (uint16_t)(lo[r >> 1] >> (16 * (r & 1))); }
                     }
                 }
             }
@@ -593,13 +593,11 @@ __global__ void k_split_planes(const float* __restrict__ x, long ldx, uint16_t* 
         const float4 a = reinterpret_cast<const float4*>(x + r * ldx)[c * 2];
         const float4 b = reinterpret_cast<const float4*>(x + r * ldx)[c * 2 + 1];
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint32_t h[8], l[8];
+        uint32_t h[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split_bf16(v[j], h[j], l[j]);
-        reinterpret_cast<uint4*>(hi + r * ldo)[c] =
-            make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        reinterpret_cast<uint4*>(lo + r * ldo)[c] =
-            make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        for (int j = 0; j < 4; ++j) split_bf16_pair(v[2 * j], v[2 * j + 1], h[j], l[j]);
+        reinterpret_cast<uint4*>(hi + r * ldo)[c] = make_uint4(h[0], h[1], h[2], h[3]);
+        reinterpret_cast<uint4*>(lo + r * ldo)[c] = make_uint4(l[0], l[1], l[2], l[3]);
     }
 }
 
