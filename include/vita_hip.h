@@ -111,6 +111,8 @@ typedef struct {
     int B, Hq, Hkv, Sq, Sk, d;
     int causal, q_off, klen, chunk, left;
     float scale;
+    void* ws; size_t ws_bytes;   /* optional scratch (16-byte aligned, B * Hkv * roundup(Sk, 32) * d * 8 bytes): the plain / causal
+                                  * kernels then convert K and V to bf16 hi/lo planes ONCE per call instead of in every wave */
 } vh_attn_args;
 int vh_attention(const vh_attn_args* args, void* stream);
 
@@ -136,6 +138,7 @@ typedef struct {
     int act; float eps;
     const float* P; long ldp; const float* bias_u; const float* bias_v; int klen, chunk, left;
     float* qkv; float* attn; float* hmid; float* mid; float* ws; size_t ws_bytes;
+    void* attn_ws; size_t attn_ws_bytes;   /* optional: vh_attn_args.ws for the block's attention */
 } vh_encoder_layer_args;
 int vh_encoder_layer(const vh_encoder_layer_args* args, void* stream);
 

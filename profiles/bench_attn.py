@@ -31,17 +31,19 @@ H, N, d = 16, 1025, 64
 C = H * d
 qkv = torch.randn((N, 3 * C), device=dev, generator=g)
 out = torch.empty((N, C), device=dev)
+ws1 = torch.empty(ops.attention_ws_bytes(1, H, N, d), dtype=torch.uint8, device=dev)
 vit = lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], out, B=1, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=3 * C, hsq=d, ldk=3 * C,
-                            hsk=d, ldv=3 * C, hsv=d, ldo=C, scale=d ** -0.5)
+                            hsk=d, ldv=3 * C, hsv=d, ldo=C, scale=d ** -0.5, ws=ws1)
 nq, nkv, d2, S, ctx = 32, 8, 128, 552, 640
 q2 = torch.randn((S, nq * d2), device=dev, generator=g)
 kc = torch.randn((nkv, ctx, d2), device=dev, generator=g)
 vc = torch.randn((nkv, ctx, d2), device=dev, generator=g)
 out2 = torch.empty((S, nq * d2), device=dev)
+ws2 = torch.empty(ops.attention_ws_bytes(1, nkv, S, d2), dtype=torch.uint8, device=dev)
 pre = lambda: ops.attention(q2, kc, vc, out2, B=1, Hq=nq, Hkv=nkv, Sq=S, Sk=S, d=d2, ldq=nq * d2, hsq=d2, ldk=d2, hsk=ctx * d2,
-                            ldv=d2, hsv=ctx * d2, ldo=nq * d2, scale=d2 ** -0.5, causal=True, q_off=0)
-DEFAULTS = {"attn_impl": 0, "attn_ksplit": 0, "attn_wpe": 0, "attn_rows": 0}
-VARIANTS = [{}, {"attn_impl": 2}, {"attn_ksplit": 1}, {"attn_ksplit": 2}, {"attn_wpe": 3}, {"attn_ksplit": 2, "attn_wpe": 3},
+                            ldv=d2, hsv=ctx * d2, ldo=nq * d2, scale=d2 ** -0.5, causal=True, q_off=0, ws=ws2)
+DEFAULTS = {"attn_impl": 0, "attn_ksplit": 0, "attn_wpe": 0, "attn_rows": 0, "attn_presplit": 0}
+VARIANTS = [{}, {"attn_presplit": 1}, {"attn_rows": 16}, {"attn_rows": 16, "attn_presplit": 1}, {"attn_impl": 2}, {"attn_ksplit": 1}, {"attn_ksplit": 2}, {"attn_wpe": 3}, {"attn_ksplit": 2, "attn_wpe": 3},
             {"attn_rows": 32}, {"attn_rows": 32, "attn_ksplit": 2}, {"attn_rows": 32, "attn_ksplit": 1}]
 for v in VARIANTS:
     for k, val in {**DEFAULTS, **v}.items():

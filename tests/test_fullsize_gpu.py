@@ -56,17 +56,36 @@ def test_decode_step_equals_prefill_row(full, dev):
 
 
 def test_chunked_prefill_equals_one_shot(full, dev):
+    """pos0 > 0 with KV-cache append against the one-shot prefill of the same 150 tokens.  The two schedules are not the same
+    arithmetic: the K split of the projections / expert GEMMs is chosen on the device from the row count, so slabs are summed in
+    a different order (1e-5 per layer), and a 32-layer top-2 router is discontinuous — ONE near-tied decision that flips moves
+    the logits by 1e-2 (seen in r03: 9.2e-3 from this prompt once the attention rounding changed).  So the routing decisions of
+    both runs are compared: every layer up to the first differing decision must agree tightly (that is the chunking logic:
+    positions, KV append, causal offset), flips must be rare, and the logits bar applies whenever no decision flipped."""
     cfg, packed, eng = full
+    L = cfg.text.num_hidden_layers
     rng = np.random.default_rng(1)
     ids = rng.integers(3, cfg.text.vocab_size, size=150).tolist()
-    one, _ = eng.prefill(_emb(packed, ids, dev))
-    one = one.clone()
+    one, h1 = eng.prefill(_emb(packed, ids, dev), want_hidden=True, want_route=True)
+    one, h1, r1 = one.clone(), h1[:, 83:].clone(), eng.route_ids[:, 83:].clone()
     eng.prefill(_emb(packed, ids[:83], dev))
-    two, _ = eng.prefill(_emb(packed, ids[83:], dev), pos0=83)
+    two, h2 = eng.prefill(_emb(packed, ids[83:], dev), pos0=83, want_hidden=True, want_route=True)
+    r2 = eng.route_ids
     torch.cuda.synchronize()
+    flipped = (torch.sort(r1, -1).values != torch.sort(r2, -1).values).any(-1)          # [layers, 67]
+    layers_hit = torch.nonzero(flipped.any(-1)).flatten().tolist()
+    first = layers_hit[0] if layers_hit else L
+    n_flip = int(flipped.sum())
     err = float((one - two).abs().max())
-    print(f"max|one-shot - chunked| = {err:.2e}")
-    assert err < TOL and int(one.argmax()) == int(two.argmax())
+    print(f"max|one-shot - chunked| = {err:.2e}; router decisions that differ: {n_flip} of {flipped.numel()}, first at layer {first if layers_hit else None}")
+    for l in range(first):
+        scale = max(1.0, float(h1[l].abs().max()))
+        e = float((h1[l] - h2[l]).abs().max())
+        assert e < 1e-3 * scale, f"hidden states after layer {l} differ by {e:.2e} before any routing decision does"
+    n_first = int(flipped[first].sum()) if layers_hit else 0      # later layers see the consequences of the first flip
+    assert first >= 2 and n_first <= 2, "chunked and one-shot prefill route differently early or often: not a near-tie effect"
+    if not layers_hit:
+        assert err < TOL and int(one.argmax()) == int(two.argmax())
 
 
 def test_deterministic_and_batched_steps(full, dev):

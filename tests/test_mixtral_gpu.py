@@ -205,7 +205,7 @@ def test_rccl_binding_single_rank(dev):
 
 @pytest.mark.parametrize("knob,value", [("fuse_attn_oproj", 1), ("prefill_moe_gemm", 1), ("prefill_attn_gemm", 1), ("gemm_prefetch", 1), ("gemm_prefetch", 3),
                                         ("down_grid", 24), ("dec_prefetch", 1), ("gemv_rows", 4), ("gemv_rows", 16),
-                                        ("prefill_fuse_rows", 0), ("attn_impl", 1)])
+                                        ("prefill_fuse_rows", 0), ("attn_impl", 1), ("attn_impl", 2), ("attn_presplit", 1)])
 def test_alternative_paths(dev, knob, value):
     """the non-default code paths stay correct: two-kernel attention / O-projection (also the fallback
     for contexts too long to co-schedule), the general GEMM kernel under the MoE and the attention projections
@@ -216,7 +216,7 @@ def test_alternative_paths(dev, knob, value):
     cfg.text = TextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
                           intermediate_size=1024, num_local_experts=8, vocab_size=2000)
     default = {"fuse_attn_oproj": 0, "prefill_moe_gemm": 0, "prefill_attn_gemm": 0, "gemm_prefetch": 2, "down_grid": 0,
-               "dec_prefetch": 0, "gemv_rows": 8, "prefill_fuse_rows": 1, "attn_impl": 0}[knob]
+               "dec_prefetch": 0, "gemv_rows": 8, "prefill_fuse_rows": 1, "attn_impl": 0, "attn_presplit": 0}[knob]
     _lib.tune(knob, value)
     try:
         _run(dev, cfg, S=200, n_new=8, seed=9)

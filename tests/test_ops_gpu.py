@@ -335,21 +335,24 @@ def test_attention_vit_like(dev, rows, N, groups):
     B, H, d = 2, 3, 64
     _lib.tune("attn_rows", rows)
     _lib.tune("attn_ksplit", groups)
+    _lib.tune("attn_presplit", 1 if N != 1025 else 0)      # the scratch it passes is used: K / V planes by the pre-pass (off by default)
     try:
         _attention_vit_like(dev, rng, B, H, N, d)
     finally:
         _lib.tune("attn_rows", 0)
         _lib.tune("attn_ksplit", 0)
+        _lib.tune("attn_presplit", 0)
 
 
 def _attention_vit_like(dev, rng, B, H, N, d):
     from vita_amd import ops
+    ws = torch.empty(ops.attention_ws_bytes(B, H, N, d), dtype=torch.uint8, device=dev)   # K / V planes by the pre-pass when N > 64
     qkv = rng.standard_normal((B * N, 3 * H * d), dtype=np.float32)
     t = _dev(qkv, dev)
     out = torch.empty((B * N, H * d), dtype=torch.float32, device=dev)
     ops.attention(t, t[:, H * d:], t[:, 2 * H * d:], out, B=B, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=3 * H * d, hsq=d,
                   ldk=3 * H * d, hsk=d, ldv=3 * H * d, hsv=d, ldo=H * d, bsq=N * 3 * H * d, bsk=N * 3 * H * d,
-                  bso=N * H * d, scale=d ** -0.5)
+                  bso=N * H * d, scale=d ** -0.5, ws=ws)
     for b in range(B):
         r = qkv[b * N:(b + 1) * N].reshape(N, 3, H, d).transpose(1, 2, 0, 3)
         ref = _attn_ref(r[0], r[1], r[2], d ** -0.5)
@@ -416,10 +419,12 @@ def test_attention_big_scores(dev):
     assert_close("attn big scores", to_np(out), _attn_ref(sp(q), sp(k), sp(v), d ** -0.5), atol=4 * ATTN_X3_ATOL)   # scores x 9
 
 
+@pytest.mark.parametrize("presplit", [False, True])
 @pytest.mark.parametrize("Sq,pos0", [(70, 0), (33, 45), (1, 99)])
-def test_attention_causal_gqa(dev, Sq, pos0):
-    """Mixtral prefill shape: 4 q-heads / 2 kv-heads x 128, K/V in cache layout [nkv][max_ctx][128]."""
-    from vita_amd import ops
+def test_attention_causal_gqa(dev, Sq, pos0, presplit):
+    """Mixtral prefill shape: 4 q-heads / 2 kv-heads x 128, K/V in cache layout [nkv][max_ctx][128]; with and without the
+    scratch that lets the kernel convert K / V to bf16 planes once per call (k_attn_prep)."""
+    from vita_amd import _lib, ops
     rng = np.random.default_rng(10 + Sq)
     nq, nkv, d, max_ctx = 4, 2, 128, 160
     Sk = pos0 + Sq
@@ -427,9 +432,12 @@ def test_attention_causal_gqa(dev, Sq, pos0):
     kc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
     vc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
     out = torch.empty((Sq, nq * d), dtype=torch.float32, device=dev)
+    ws = torch.empty(ops.attention_ws_bytes(1, nkv, Sk, d), dtype=torch.uint8, device=dev) if presplit else None
+    _lib.tune("attn_presplit", int(presplit))
     ops.attention(_dev(q, dev), _dev(kc, dev), _dev(vc, dev), out, B=1, Hq=nq, Hkv=nkv, Sq=Sq, Sk=Sk, d=d, ldq=nq * d,
                   hsq=d, ldk=d, hsk=max_ctx * d, ldv=d, hsv=max_ctx * d, ldo=nq * d, scale=d ** -0.5, causal=True,
-                  q_off=pos0)
+                  q_off=pos0, ws=ws)
+    _lib.tune("attn_presplit", 0)
     mask = np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]
     ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), kc[:, :Sk], vc[:, :Sk], d ** -0.5, mask)
     assert_close(f"attn causal gqa Sq={Sq} pos0={pos0}", to_np(out), ref, atol=ATTN_X3_ATOL)

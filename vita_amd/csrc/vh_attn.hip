@@ -489,15 +489,62 @@ __device__ __forceinline__ void at_split8(const f32x4& a, const f32x4& b, bf16x8
 }
 #define AT_PSTR3 36     // patch row stride (floats): 16-byte aligned 8-float reads at 8 lg, rows 4 banks apart mod 64
 
+// ---- pre-pass of the PRE variant: one block per (32-key tile, kv head, batch) ------------------------------------------------
+// ws layout per (batch, kv head): Kh | Kl as [Skp][D] bf16 (key-major), Vth | Vtl as [D][Skp] bf16 (TRANSPOSED), Skp = Sk rounded
+// up to 32; keys >= Sk are written as zeros (their probabilities are zero, their values must not be NaN bit patterns).
+template <int D, bool PAGED>
+__global__ __launch_bounds__(256) void k_attn_prep(const VhAttnArgs p) {
+    __shared__ float vt[32][D + 1];
+    const int k0 = blockIdx.x * 32, hk = blockIdx.y, b = blockIdx.z;
+    const int Skp = (p.Sk + 31) & ~31;
+    const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
+    const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
+    uint16_t* base = reinterpret_cast<uint16_t*>(p.ws) + (size_t)(b * p.Hkv + hk) * 4 * Skp * D;
+    uint16_t* Kh = base; uint16_t* Kl = base + (size_t)Skp * D;
+    uint16_t* Vh = base + (size_t)2 * Skp * D; uint16_t* Vl = base + (size_t)3 * Skp * D;
+    constexpr int C4 = D / 4;
+#pragma unroll
+    for (int i = threadIdx.x; i < 32 * C4; i += 256) {
+        const int kk = i / C4, c4 = i - kk * C4;
+        const int key = k0 + kk;
+        f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+        if (key < p.Sk) {
+            const size_t row = PAGED ? (size_t)p.ktable[key >> 6] * 64 + (key & 63) : (size_t)key;
+            kv = *reinterpret_cast<const f32x4*>(Kb + row * p.ldk + 4 * c4);
+            vv = *reinterpret_cast<const f32x4*>(Vb + row * p.ldv + 4 * c4);
+        }
+        uint32_t h[2], l[2];
+        at_split2(kv[0], kv[1], h[0], l[0]);
+        at_split2(kv[2], kv[3], h[1], l[1]);
+        *reinterpret_cast<uint2*>(Kh + (size_t)key * D + 4 * c4) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(Kl + (size_t)key * D + 4 * c4) = make_uint2(l[0], l[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vt[kk][4 * c4 + j] = vv[j];
+    }
+    __syncthreads();
+    // column d, key group g8 (8 keys): one 16-byte store per plane
+    for (int i = threadIdx.x; i < D * 4; i += 256) {
+        const int d = i % D, g8 = i / D;
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int u2 = 0; u2 < 4; ++u2) at_split2(vt[8 * g8 + 2 * u2][d], vt[8 * g8 + 2 * u2 + 1][d], h[u2], l[u2]);
+        *reinterpret_cast<uint4*>(Vh + (size_t)d * Skp + k0 + 8 * g8) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(Vl + (size_t)d * Skp + k0 + 8 * g8) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
 // RT = 16-row tiles per wave.  With one tile the launch is bound by operand traffic, not by either pipe: every wave pulls
 // the whole K and V of its head through L2 -> registers (ViT: 4160 waves x 128 KB = 532 MB per launch, 8.7 TB/s at 61 us;
 // the fp32 kernel moved the same bytes in 78 us).  Two tiles per wave (d = 64) halve the bytes and the conversions per row.
 // MODE fixes the mask flavour at compile time (0 = pad mask only, 1 = causal, 2 = causal + KV page table): with the flavours
 // as run-time branches the loop body held 34 branches / 20 exec-mask regions, each a scheduling barrier between the loads,
 // conversions and MFMAs it should interleave.
-template <int D, int KS, int WPE, int RT, int MODE>
+// PRE: K and V come as bf16 hi/lo planes written once per launch by k_attn_prep (K row-major, V TRANSPOSED so that a lane's eight
+// keys of one output column are one 16-byte load) instead of being converted by every wave that reads them — the loop was
+// VALU-issue-bound and the conversions were 160 of its 510 instructions.  The page table is resolved by the pre-pass.
+template <int D, int KS, int WPE, int RT, int MODE, bool PRE>
 __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_attn_x3(const VhAttnArgs p) {
-    constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
+    constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2 && !PRE;
     constexpr int NC = D / 16;          // output column tiles = floats of a V row per lane
     constexpr int VQ = NC / 4;          // float4s of V per lane per key
     constexpr int C32 = D / 32;         // 32-deep chunks of the head dimension
@@ -540,7 +587,15 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         for (int t = 0; t < NC; ++t) o[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    f32x4 kf[2][C32][2], vf[8][VQ];
+    // PRE operands: planes of this (batch, kv head): Kh | Kl [Skp][D], Vth | Vtl [D][Skp] (attn_prep_layout)
+    const int Skp = (p.Sk + 31) & ~31;
+    const uint16_t* pl_base = PRE ? reinterpret_cast<const uint16_t*>(p.ws) + (size_t)(b * p.Hkv + hk) * 4 * Skp * D : nullptr;
+    const uint16_t* Khp = pl_base;
+    const uint16_t* Klp = PRE ? pl_base + (size_t)Skp * D : nullptr;
+    const uint16_t* Vhp = PRE ? pl_base + (size_t)2 * Skp * D : nullptr;
+    const uint16_t* Vlp = PRE ? pl_base + (size_t)3 * Skp * D : nullptr;
+    bf16x8 kph[PRE ? 2 : 1][PRE ? C32 : 1], kpl[PRE ? 2 : 1][PRE ? C32 : 1], vph[PRE ? NC : 1], vpl[PRE ? NC : 1];
+    f32x4 kf[PRE ? 1 : 2][PRE ? 1 : C32][2], vf[PRE ? 1 : 8][PRE ? 1 : VQ];
     // Row addresses are a uniform base + a 32-bit byte offset from a 24-bit multiply (the launcher checks that rows x stride
     // fits): the first version spent 63 quarter-rate 32/64-bit multiplies and ~100 more VALU per tile on 64-bit row pointers,
     // a third of the loop's issue cycles in a kernel that is VALU-bound.
@@ -552,6 +607,18 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         return (__umul24((unsigned)key, ld) + col) * 4u;
     };
     auto load_k = [&](int kt0) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const unsigned off = (unsigned)min(kt0 + 16 * jt + lr, klast) * D + 8 * lg;
+#pragma unroll
+                for (int c = 0; c < C32; ++c) {
+                    kph[jt][c] = *reinterpret_cast<const bf16x8*>(Khp + off + 32 * c);
+                    kpl[jt][c] = *reinterpret_cast<const bf16x8*>(Klp + off + 32 * c);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             const char* row = reinterpret_cast<const char*>(Kb) + row_bytes(kt0 + 16 * jt + lr, ldk, 8 * lg);
@@ -563,6 +630,15 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
     };
     auto load_v = [&](int kt0) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+            const unsigned kcol = (unsigned)min(kt0 + 8 * lg, Skp - 8);      // (clamped prefetch past the last tile)
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                vph[t] = *reinterpret_cast<const bf16x8*>(Vhp + (unsigned)(lr * NC + t) * Skp + kcol);
+                vpl[t] = *reinterpret_cast<const bf16x8*>(Vlp + (unsigned)(lr * NC + t) * Skp + kcol);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const char* row = reinterpret_cast<const char*>(Vb) + row_bytes(kt0 + 8 * lg + u, ldv, lr * NC);
@@ -585,7 +661,8 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
             for (int c = 0; c < C32; ++c) {
                 bf16x8 kh, kl;
-                at_split8(kf[jt][c][0], kf[jt][c][1], kh, kl);
+                if constexpr (PRE) { kh = kph[jt][c]; kl = kpl[jt][c]; }
+                else at_split8(kf[jt][c][0], kf[jt][c][1], kh, kl);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     f32x4 a = sacc[rt][jt];
@@ -641,12 +718,17 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
 #pragma unroll
         for (int t = 0; t < NC; ++t) {
-            uint32_t vh[4], vl[4];
+            bf16x8 bh, bl;
+            if constexpr (PRE) {
+                bh = vph[t]; bl = vpl[t];
+            } else {
+                uint32_t vh[4], vl[4];
 #pragma unroll
-            for (int u2 = 0; u2 < 4; ++u2)
-                at_split2(vf[2 * u2][t >> 2][t & 3], vf[2 * u2 + 1][t >> 2][t & 3], vh[u2], vl[u2]);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, at_u32x4{vh[0], vh[1], vh[2], vh[3]});
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, at_u32x4{vl[0], vl[1], vl[2], vl[3]});
+                for (int u2 = 0; u2 < 4; ++u2)
+                    at_split2(vf[2 * u2][t >> 2][t & 3], vf[2 * u2 + 1][t >> 2][t & 3], vh[u2], vl[u2]);
+                bh = __builtin_bit_cast(bf16x8, at_u32x4{vh[0], vh[1], vh[2], vh[3]});
+                bl = __builtin_bit_cast(bf16x8, at_u32x4{vl[0], vl[1], vl[2], vl[3]});
+            }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 o[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rt], bh, o[rt][t], 0, 0, 0);
@@ -762,15 +844,31 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
             // was VALU-lean; only when the launch still gives every SIMD two waves
             const int rows = vh_tuning()->attn_rows;
             const bool two = a.d == 64 && mode == 0 && (rows == 32 || (rows == 0 && (long)g32.x * g32.y * g32.z * ks >= 8L * vh_num_cus()));
-#define X3(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM>), G, dim3(64 * KK), 0, st, a)
+            // pre-split K / V planes when the caller gave scratch for them and the key count takes the full key-group split
+            const long skp = (a.Sk + 31) & ~31L;
+            const size_t need = (size_t)a.B * a.Hkv * 4 * skp * a.d * sizeof(uint16_t);
+            const int full_ks = a.d == 64 ? 4 : 2;
+            const bool pre = vh_tuning()->attn_presplit != 0 && mode != 2 && a.ws && a.ws_bytes >= need && ks == full_ks &&
+                             (reinterpret_cast<uintptr_t>(a.ws) & 15) == 0 && skp * a.d * 4 < (1L << 31);
+            if (pre) {
+                const dim3 gp((unsigned)(skp / 32), a.Hkv, a.B);
+                if (a.d == 64) hipLaunchKernelGGL((k_attn_prep<64, false>), gp, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_attn_prep<128, false>), gp, dim3(256), 0, st, a);
+            }
+#define X3(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM, false>), G, dim3(64 * KK), 0, st, a)
+#define X3P(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM, true>), G, dim3(64 * KK), 0, st, a)
 #define X3_MODES(DD, KK, WW) do { if (mode == 0) X3(DD, KK, WW, 1, 0, g16); else if (mode == 1) X3(DD, KK, 2, 1, 1, g16); else X3(DD, KK, 2, 1, 2, g16); } while (0)
-            if (two) {
+            if (pre) {
+                if (a.d == 64) { if (two) X3P(64, 4, 2, 2, 0, g32); else if (mode == 0) X3P(64, 4, 2, 1, 0, g16); else X3P(64, 4, 2, 1, 1, g16); }
+                else { if (mode == 0) X3P(128, 2, 2, 1, 0, g16); else X3P(128, 2, 2, 1, 1, g16); }
+            } else if (two) {
                 if (ks == 1) X3(64, 1, 2, 2, 0, g32); else if (ks == 2) X3(64, 2, 2, 2, 0, g32); else X3(64, 4, 2, 2, 0, g32);
             } else if (a.d == 64) {
                 if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else if (wpe_raw != 3) X3_MODES(64, 4, 2); else X3_MODES(64, 4, 3);
             } else {
                 if (ks == 1) X3_MODES(128, 1, 2); else X3_MODES(128, 2, 2);
             }
+#undef X3P
 #undef X3_MODES
 #undef X3
             return 0;

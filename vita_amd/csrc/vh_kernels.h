@@ -21,6 +21,7 @@ struct VhTuning {
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
     int attn_wpe = 0;          // d = 64 attention: waves per SIMD the register allocation aims at; 0 = auto (fp32 kernel 3: 145 VGPRs; bf16 x 3 kernel 2: 216, no spills)
     int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernels (16 rows per wave, no LDS tiles; plain / causal on bf16 x 3 MFMAs), 1 = LDS-tiled fp32 kernel, 2 = direct-operand fp32-MFMA kernel everywhere
+    int attn_presplit = 0;     // bf16 x 3 attention: 1 = K / V converted to planes once per launch by a pre-pass (k_attn_prep) when the caller provides scratch; measured slower (ViT 66 vs 61 us, prefill 78 vs 49 us incl. the pre-pass), kept as a tested option
     int attn_rows = 0;         // bf16 x 3 attention at d = 64: query rows per wave, 0 = auto (32 when the launch still fills the chip), 16, 32
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
@@ -186,6 +187,7 @@ struct VhAttnArgs {
     float scale;
     const int* ktable;                    // nullable: keys / values live in 64-row pages, logical block j>>6 -> page ktable[j>>6]
     long kv_rows;                         // rows a page-table entry may address (the pool); 0 = Sk.  Bounds the 32-bit offsets of k_attn_x3
+    void* ws; size_t ws_bytes;            // nullable scratch for the pre-split K / V planes of k_attn_x3: B * Hkv * roundup(Sk, 32) * d * 8 bytes
 };
 int vhk_attn(hipStream_t st, const VhAttnArgs& a);
 
