@@ -31,7 +31,9 @@ def _run(dev, cfg, S, n_new, seed=0, nsplit=0, max_ctx=None, chunked=False):
     logits, hid = eng.prefill(torch.from_numpy(emb).to(dev), want_hidden=True)
     torch.cuda.synchronize()
     for l in range(cfg.text.num_hidden_layers):
-        assert_close(f"prefill hidden after layer {l}", to_np(hid[l]), ref_hid[l], atol=2e-4, rtol=1e-4)
+        # hidden states reach |x| ~ 12 at the real width; the prefill attention runs on bf16 x 3 MFMAs (products exact to 2^-17
+        # like the GEMMs): max error 2.0-2.8e-4 against 1.2-1.5e-4 with the fp32-MFMA kernel (profiles/debug_tol.py)
+        assert_close(f"prefill hidden after layer {l}", to_np(hid[l]), ref_hid[l], atol=4e-4, rtol=1e-4)
     got_lg = [to_np(logits).copy()]
     if chunked:
         eng.decode(n_new - 1)  # one C call, no host interaction; scores come from the logits history

@@ -562,14 +562,16 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
     const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
 
+    const float qscale = p.scale * 1.44269504088896340736f;
     bf16x8 qh[RT][C32], ql[RT][C32];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int q = min(q0 + 16 * rt + lr, p.Sq - 1);     // rows past Sq compute on a copy of the last row, never stored
 #pragma unroll
         for (int c = 0; c < C32; ++c) {
+            // scale * log2(e) folded into Q: the scores come out of the MFMAs in the log2 domain, softmax runs on v_exp_f32 directly
             const float* src = Qb + (size_t)q * p.ldq + 32 * c + 8 * lg;
-            at_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), qh[rt][c], ql[rt][c]);
+            at_split8(*reinterpret_cast<const f32x4*>(src) * qscale, *reinterpret_cast<const f32x4*>(src + 4) * qscale, qh[rt][c], ql[rt][c]);
         }
     }
 
@@ -676,6 +678,8 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         load_k(kt0 + STEP);                                  // (clamped) K of this wave's next tile: lands under softmax + PV
 
         // ---- online softmax in D layout: lane holds S[q0 + 16rt + 4lg + r][kt0 + 16jt + lr] ---------------------------
+        // every key of the tile visible to every row of the wave (first row's causal limit, pad limit)?
+        const bool full_tile = kt0 + AT_KT <= (CAUSAL ? min(kend, q0 + p.q_off + 1) : kend);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float* ps = Ps[kg][rt];
@@ -683,16 +687,18 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + 16 * rt + lg * 4 + r;
-                float s0 = sacc[rt][0][r] * p.scale, s1 = sacc[rt][1][r] * p.scale;
-                const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;      // keys < klim are visible
-                s0 = (kt0 + lr < klim) ? s0 : -INFINITY;
-                s1 = (kt0 + 16 + lr < klim) ? s1 : -INFINITY;
+                float s0 = sacc[rt][0][r], s1 = sacc[rt][1][r];
+                if (!full_tile) {                                                 // (wave-uniform) only the tiles that cross a mask edge
+                    const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;  // keys < klim are visible
+                    s0 = (kt0 + lr < klim) ? s0 : -INFINITY;
+                    s1 = (kt0 + 16 + lr < klim) ? s1 : -INFINITY;
+                }
                 const float mx = grp16_max(fmaxf(s0, s1));
                 const float mn = fmaxf(m[rt][r], mx);
-                const bool none = mn == -INFINITY;                                // nothing visible yet: exp(-inf + inf) is discarded
-                alpha[r] = none ? 1.f : __expf(m[rt][r] - mn);
-                const float p0 = none ? 0.f : __expf(s0 - mn);
-                const float p1 = none ? 0.f : __expf(s1 - mn);
+                const bool none = mn == -INFINITY;                                // nothing visible yet: exp2(-inf + inf) is discarded
+                alpha[r] = none ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
+                const float p0 = none ? 0.f : __builtin_amdgcn_exp2f(s0 - mn);
+                const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1 - mn);
                 l[rt][r] = l[rt][r] * alpha[r] + grp16_sum(p0 + p1);
                 m[rt][r] = mn;
                 ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
@@ -768,8 +774,8 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 for (int r = 0; r < 4; ++r) {
                     const float m2 = mr[r], l2 = mr[4 + r];
                     const float mn = fmaxf(m[rt][r], m2);
-                    const float a1 = (mn == -INFINITY) ? 1.f : __expf(m[rt][r] - mn);
-                    const float a2 = (mn == -INFINITY) ? 0.f : __expf(m2 - mn);
+                    const float a1 = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
+                    const float a2 = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
                     l[rt][r] = l[rt][r] * a1 + l2 * a2;
                     m[rt][r] = mn;
 #pragma unroll

@@ -82,7 +82,9 @@ __device__ __forceinline__ uint4 ld_weight16(const void* p) {
 // cross-row steps of a full-wave reduction still go through ds_bpermute.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    // full row / bank masks + bound_ctrl: no lane of these controls reads out of its row, and the `old` operand is dead, so
+    // the move folds into the consuming VALU op (v_max_f32_dpp ...); with bound_ctrl off hipcc kept "v_mov 0; v_mov_dpp; v_max"
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 #define VH_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
 #define VH_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
