@@ -295,6 +295,7 @@ struct vh_mixtral {
     float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
     uint16_t* pkv_planes = nullptr; size_t pkv_bytes = 0;   // bf16 hi/lo planes of one layer's K / V for the prefill attention (k_attn_prep)
+    bool presplit_at_create = false;                        // vh_tune("attn_presplit") when the workspace was sized (carve must agree with it)
     int *pids, *pgoff, *pstok, *psslot, *pnslab;
     // ---- concurrent sequences over a paged KV cache (vLLM's block tables).  The KV pool above is cut into
     // 64-token pages (= one decode-attention tile); a sequence owns a page table, a residual-stream state, its counters
@@ -382,7 +383,9 @@ struct vh_mixtral {
         px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
         pqkv = cv.take<float>(Sm * nqkv);
         pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
-        {   // K / V planes of the context a prefill attends to: up to max(max_prefill, 8192) keys (longer contexts convert in the kernel)
+        pkv_planes = nullptr; pkv_bytes = 0;
+        if (presplit_at_create) {   // only engines created under vh_tune("attn_presplit", 1) carry the scratch of the pre-pass:
+            // K / V planes of the context a prefill attends to, up to max(max_prefill, 8192) keys (longer contexts convert in the kernel)
             size_t keys = (size_t)c.max_ctx < (Sm > 8192 ? Sm : (size_t)8192) ? (size_t)c.max_ctx : (Sm > 8192 ? Sm : (size_t)8192);
             keys = (keys + 31) & ~(size_t)31;
             pkv_bytes = (size_t)nkv * 4 * keys * hd * sizeof(uint16_t);
@@ -504,6 +507,7 @@ size_t vh_mixtral_workspace_bytes(const vh_mixtral_cfg* cfg) {
     vh_mixtral tmp{};
     tmp.c = *cfg;
     tmp.derive();
+    tmp.presplit_at_create = vh_tuning()->attn_presplit != 0;
     return tmp.carve(nullptr);
 }
 
@@ -518,6 +522,7 @@ vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_laye
     vh_mixtral* m = new vh_mixtral{};
     m->c = *cfg;
     m->derive();
+    m->presplit_at_create = vh_tuning()->attn_presplit != 0;
     m->L.assign(layers, layers + cfg->n_layers);
     m->embed = embed; m->final_norm = final_norm; m->lm_head = lm_head;
     m->rope_cos = rope_cos; m->rope_sin = rope_sin;
