@@ -211,6 +211,31 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.vh_mixtral_workspace_bytes(ctypes.byref(cfg)) == 0 and b"head_dim" in lib.vh_last_error()
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """every struct the Python binding mirrors has the size AND field offsets the C header gives it (compiled here with gcc):
+    the binding and the header are edited by hand in two places."""
+    from vita_amd import _lib
+    pairs = {"vh_gemm_args": _lib.GemmArgs, "vh_gemm_ps_args": _lib.GemmPsArgs, "vh_attn_args": _lib.AttnArgs,
+             "vh_encoder_layer_args": _lib.EncoderLayerArgs, "vh_mixtral_cfg": _lib.MixtralCfg, "vh_mixtral_layer": _lib.MixtralLayer}
+    lines = []
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vita_hip.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line in out:
+        cname, size, *offs = line.split()
+        cls = pairs[cname]
+        assert ctypes.sizeof(cls) == int(size), f"{cname}: ctypes {ctypes.sizeof(cls)} vs C {size}"
+        got = [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert got == [int(o) for o in offs], f"{cname}: field offsets differ: {got} vs {offs}"
+
+
 def test_workspace_size_real_geometry():
     from vita_amd import _lib
     lib = _lib.load()
