@@ -82,6 +82,33 @@ def test_fbank_matches_independent_oracle_and_token_count():
     assert audio_token_count(352) == 44 and audio_token_count(998) == 124 and audio_token_count(400) == 50
 
 
+def test_fbank_matches_third_party_kaldi_implementation():
+    """A4 pinned to code the builder did not write: HF transformers' Kaldi-compatible front end
+    (transformers.audio_utils: povey window, remove_dc_offset, 0.97 pre-emphasis, kaldi mel scale triangularised in mel
+    space, 257 frequency bins = FFT bin width sr/512 — the parameters of torchaudio.compliance.kaldi.fbank as
+    whale/init_model.py:46-56 calls it: num_mel_bins 80, 25/10 ms, energy_floor 0, dither 0) on asset/q1.wav scaled to the
+    int16 range.  Both the product and the committed fixture must agree with it to fp32 rounding."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    from vita_amd.audio_frontend import kaldi_fbank
+    g = np.load(os.path.join(GOLD, "q1_audio.npz"))
+    wav = g["pcm16"].astype(np.float64)                # = waveform * (1 << 15), init_model.py:46
+    mel = mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=20, max_frequency=8000,
+                          sampling_rate=16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    hf = spectrogram(wav, window_function(400, "povey", periodic=False), frame_length=400, hop_length=160, fft_length=512,
+                     power=2.0, center=False, preemphasis=0.97, mel_filters=mel, log_mel="log",
+                     mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+    assert hf.shape == (352, 80)
+    assert np.abs(hf - g["fbank"]).max() < 1e-5         # measured 1.9e-6
+    assert np.abs(hf - kaldi_fbank(wav, int(g["sr"]))).max() < 1e-5
+    # a shorter, offset excerpt as a second input (framing / edge handling, not only the one file)
+    part = wav[777:777 + 400 + 160 * 57]
+    hf2 = spectrogram(part, window_function(400, "povey", periodic=False), frame_length=400, hop_length=160, fft_length=512,
+                      power=2.0, center=False, preemphasis=0.97, mel_filters=mel, log_mel="log",
+                      mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+    fb2 = kaldi_fbank(part, 16000)
+    assert fb2.shape == hf2.shape == (58, 80) and np.abs(hf2 - fb2).max() < 1e-5
+
+
 def test_oracle_fbank_live_equals_fixture():
     """the committed fixture is what oracle/kaldi_fbank.py computes (first 40 frames re-run here)."""
     from oracle import kaldi_fbank as okf
