@@ -37,8 +37,10 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
-/* Kernel-variant knobs for experiments (keys: "gateup_variant", "gateup_grid", "fuse_attn_oproj", "prefill_moe_gemm", "gemm_order", ...); the defaults are
- * the measured-best variants, results are identical across variants. */
+/* Kernel-variant knobs (15 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_presplit", "attn_rows", "attn_ksplit",
+ * "prefill_attn_gemm", "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse",
+ * "comm_allow_coarse"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
+ * measured-best variants, ids are identical across variants.  Unknown keys (e.g. of variants removed in r04) return VH_E_ARG. */
 int vh_tune(const char* key, int value);
 
 /* ---- generic operators --------------------------------------------------------------

@@ -171,12 +171,7 @@ def main():
         _lib.tune("ps_nt", 0)
         gu, dn = time_pair(2)
         report("stream, default-policy weight loads", gu, dn)
-        _lib.tune("ps_nt", 1)
-        for grid in (128, 248):
-            _lib.tune("ps_grid", grid)
-            gu, dn = time_pair(2)
-            report(f"stream grid={grid}", gu, dn)
-        _lib.tune("ps_grid", 0)
+        _lib.tune("ps_nt", -1)
 
         def ggu(L):
             ops.gemm(x, L["w1"], w_up=L["w3"], a_rowidx=stok, group_off=goff, ngroups=E, w_group_stride=I * H, m=2 * S)

@@ -111,7 +111,7 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1):
         rng = np.random.default_rng(5)
         ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
         emb = packed["embed"][torch.as_tensor(ids, device=dev)].float()
-        row0, _ = eng.prefill(emb)               # sharded head: the returned row is already the full one (collective inside)
+        row0, _ = eng.prefill(emb, gather_logits=True)   # sharded head: the full row (collective inside)
         row0 = row0.cpu()
         eng.decode(9)
         torch.cuda.synchronize()

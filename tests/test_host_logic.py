@@ -238,6 +238,23 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.vh_mixtral_workspace_bytes(ctypes.byref(cfg)) == 0 and b"head_dim" in lib.vh_last_error()
 
 
+def test_removed_knobs_are_rejected():
+    """vh_tune refuses keys of variants that no longer exist (a script that still sets them must fail loudly)."""
+    import pytest
+    from vita_amd import _lib
+    for key in ("gateup_variant", "down_grid", "dec_prefetch", "batch_moe", "fuse_attn_oproj", "prefill_moe_gemm"):
+        with pytest.raises(_lib.VitaHipError):
+            _lib.tune(key, 1)
+    _lib.tune("attn_rows", 0)      # a live key is accepted (no GPU needed)
+    assert len(KNOBS_R04) <= 15
+    for key in KNOBS_R04:
+        _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4}.get(key, 0))
+
+
+KNOBS_R04 = ("batch_moe_min", "batch_decode", "attn_impl", "attn_presplit", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
+             "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse", "comm_allow_coarse")
+
+
 def test_ctypes_structs_match_the_header(tmp_path):
     """every struct the Python binding mirrors has the size AND field offsets the C header gives it (compiled here with gcc):
     the binding and the header are edited by hand in two places."""

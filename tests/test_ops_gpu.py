@@ -203,10 +203,10 @@ def test_gemm_grouped_glu_and_scatter(dev):
     assert_close("grouped down + scatter", to_np(y), yref, atol=2e-4)
 
 
-@pytest.fixture(params=[-1, 1, 2], ids=["cfg-auto", "cfg-regstaged", "cfg-ws"])
+@pytest.fixture(params=[-1, 0, 1], ids=["cfg-auto", "cfg-dma-ring", "cfg-regstaged"])
 def ps_cfg(request):
-    """every vh_gemm_ps test runs on the default selection, the r02 register-staged kernel and the r03 kernel whose
-    weights go straight to registers (vh_gemm_ws.hip)."""
+    """every vh_gemm_ps test runs on the default selection (by rows per group) and on each of the two ring geometries forced:
+    64-row tiles with the weights in an LDS-DMA ring, 192-row tiles with register-staged weights."""
     from vita_amd import _lib
     _lib.tune("ps_cfg", request.param)
     yield request.param
@@ -359,13 +359,13 @@ def _attention_vit_like(dev, rng, B, H, N, d):
         assert_close(f"attn vit b{b}", to_np(out[b * N:(b + 1) * N]), ref, atol=ATTN_X3_ATOL)
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2])
+@pytest.mark.parametrize("impl", [0, 2])
 @pytest.mark.parametrize("groups", [1, 2, 4])
 def test_attention_key_groups(dev, groups, impl):
     """every key-group instantiation (attn_ksplit: tiles dealt to 1 / 2 / 4 wave groups, merged in group order) gives the
     single-pass result: plain d=64, rel-pos d=64, causal d=128 (4 falls back to 2 there).  impl 0 = the default kernels (plain and
     causal on bf16 x 3 MFMAs: products exact to 2^-17 per term like the GEMMs, tolerance ATTN_X3_ATOL; rel-pos on the fp32 MFMA),
-    1 = LDS-tiled fp32, 2 = direct-operand fp32 everywhere (fp32 rounding: 2e-5)."""
+    2 = fp32 MFMA everywhere (fp32 rounding: 2e-5)."""
     from vita_amd import _lib, ops
     rng = np.random.default_rng(80)
     _lib.tune("attn_ksplit", groups)

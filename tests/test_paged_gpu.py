@@ -160,7 +160,7 @@ def test_continuous_batcher_matches_oracle(dev):
     eng.close()
 
 
-@pytest.mark.parametrize("batched", [1, 3, 2, 0])
+@pytest.mark.parametrize("batched", [1, 3, 0])
 def test_six_sequences_batched_kernels_match_oracle(dev, batched):
     """six sequences advance together: groups of 4 + 2 through the batched decode kernels (shared attention weights and LM
     head, every distinct routed expert streamed once) — or one after the other (batch_decode = 0); ids equal the oracle's
@@ -170,9 +170,8 @@ def test_six_sequences_batched_kernels_match_oracle(dev, batched):
     lens = [40, 97, 64, 130, 20, 75]
     _, _, eng, reqs = _setup(dev, lens, n_new, seed=11, pool=2048, max_seqs=6)
     # 1: default (iterations of >= 3 sequences run the MoE once on the weight-streaming GEMM, smaller ones per sequence),
-    # 3: expert GEMVs per sequence at every size, 2: de-duplicating expert GEMVs, 0: one sequence after the other
+    # 3: expert GEMVs per sequence at every size, 0: one sequence after the other
     _lib.tune("batch_decode", min(batched, 1))
-    _lib.tune("batch_moe", 1 if batched == 2 else 0)
     _lib.tune("batch_moe_min", 3 if batched == 1 else 0)
     try:
         seqs = []
@@ -199,7 +198,6 @@ def test_six_sequences_batched_kernels_match_oracle(dev, batched):
         assert _ids(eng, late, n_new) == reqs[5]["ref_ids"]
     finally:
         _lib.tune("batch_decode", 1)
-        _lib.tune("batch_moe", 0)
         _lib.tune("batch_moe_min", 3)
     eng.close()
 

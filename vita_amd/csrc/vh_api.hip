@@ -41,34 +41,21 @@ const char* vh_last_error(void) { return g_err; }
 
 int vh_tune(const char* key, int value) {
     if (!key) return fail(VH_E_ARG, "vh_tune: null key");
-    if (!strcmp(key, "gateup_variant")) { g_tuning.gateup_variant = value; return VH_OK; }
-    if (!strcmp(key, "gemv_rows")) { g_tuning.gemv_rows = value; return VH_OK; }
-    if (!strcmp(key, "gateup_grid")) { g_tuning.gateup_grid = value; return VH_OK; }
-    if (!strcmp(key, "down_grid")) { g_tuning.down_grid = value; return VH_OK; }
-    if (!strcmp(key, "dec_prefetch")) { g_tuning.dec_prefetch = value; return VH_OK; }
     if (!strcmp(key, "batch_moe_min")) { g_tuning.batch_moe_min = value; return VH_OK; }
-    if (!strcmp(key, "batch_moe")) { g_tuning.batch_moe = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
-    if (!strcmp(key, "attn_wpe")) { g_tuning.attn_wpe = value; return VH_OK; }
+    if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_presplit")) { g_tuning.attn_presplit = value; return VH_OK; }
     if (!strcmp(key, "attn_rows")) { g_tuning.attn_rows = value; return VH_OK; }
-    if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
     if (!strcmp(key, "prefill_fuse_rows")) { g_tuning.prefill_fuse_rows = value; return VH_OK; }
-    if (!strcmp(key, "prefill_moe_gemm")) { g_tuning.prefill_moe_gemm = value; return VH_OK; }
-    if (!strcmp(key, "fuse_attn_oproj")) { g_tuning.fuse_attn_oproj = value; return VH_OK; }
-    if (!strcmp(key, "fuse_max_blocks")) { g_tuning.fuse_max_blocks = value; return VH_OK; }
-    if (!strcmp(key, "gemm_prefetch")) { g_tuning.gemm_prefetch = value; return VH_OK; }
     if (!strcmp(key, "ps_cfg")) { g_tuning.ps_cfg = value; return VH_OK; }
-    if (!strcmp(key, "ps_grid")) { g_tuning.ps_grid = value; return VH_OK; }
     if (!strcmp(key, "ps_nt")) { g_tuning.ps_nt = value; return VH_OK; }
-    if (!strcmp(key, "moe_ksplit")) { g_tuning.moe_ksplit = value; return VH_OK; }
     if (!strcmp(key, "tp_overlap")) { g_tuning.tp_overlap = value; return VH_OK; }
+    if (!strcmp(key, "moe_ksplit")) { g_tuning.moe_ksplit = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
-    if (!strcmp(key, "ws_pad")) { g_tuning.ws_pad = value; return VH_OK; }
-    if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
     if (!strcmp(key, "tp_fuse")) { g_tuning.tp_fuse = value; return VH_OK; }
+    if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -132,6 +119,9 @@ int vh_attention(const vh_attn_args* a, void* stream) {
         (reinterpret_cast<uintptr_t>(a->K) & 15) || (reinterpret_cast<uintptr_t>(a->V) & 15) ||
         (a->P && ((a->ldp % 4) || (a->hsp % 4) || (reinterpret_cast<uintptr_t>(a->P) & 15))))
         return fail(VH_E_SHAPE, "vh_attention: K/V/P rows must be 16-byte aligned (strides multiples of 4 floats)");
+    if ((a->ldq % 4) || (a->hsq % 4) || (a->bsq % 4) || (a->ldo % 4) || (a->bso % 4) || (reinterpret_cast<uintptr_t>(a->Q) & 15) ||
+        (reinterpret_cast<uintptr_t>(a->O) & 15) || (a->d != 64 && a->d != 128) || (a->P && a->d != 64))
+        return fail(VH_E_SHAPE, "vh_attention: Q/O rows must be 16-byte aligned, head_dim 64 or 128 (rel-pos: 64)");
     return check_launch("vh_attention", vhk_attn(S(stream), g));
 }
 
@@ -206,8 +196,7 @@ int vh_attn_decode(const float* qkv, float* kcache, float* vcache, int pos, cons
     if (pos < 0 || pos >= max_ctx) return fail(VH_E_SHAPE, "vh_attn_decode: position %d outside the cache (%d)", pos, max_ctx);
     const int max_splits = (max_ctx + 63) / 64;
     return check_launch("vh_attn_decode", vhk_dec_attn(S(stream), qkv, kcache, vcache, nullptr, rope_cos, rope_sin, part_o, part_ml,
-                                                      tickets, attn_out, nq, nkv, max_ctx, max_splits, pos + 1, scale, table,
-                                                      nullptr, 0));
+                                                      tickets, attn_out, nq, nkv, max_ctx, max_splits, pos + 1, scale, table));
 }
 
 int vh_lmhead_argmax(const float* x, const float* delta, const float* norm_w, float eps, const uint16_t* W, int V, int H,
@@ -286,13 +275,12 @@ struct vh_mixtral {
     int v0 = 0, Vn = 0;         // this rank's rows of the LM head ([v0, v0 + Vn); the whole table when unsharded)
     float* cand = nullptr;      // [tp_world][2] (value, index) candidates of the vocab-sharded head
     int host_pos = 0;  // host mirror of counters[0] (sizes the split-KV grid without a device read)
-    int attn_epoch = 0;  // fused attention+O-proj launches since the last reset (counters[2] grows by nkv per launch)
     // state
     float *kcache, *vcache;  // [layer][nkv][max_ctx][hd]
     float *xa, *xb, *delta_attn, *delta_moe, *qkv, *part_o, *part_ml, *attn_out, *hbuf, *logits, *blk_val;
     int *blk_idx, *route, *counters, *out_tokens, *attn_cnt;
     // prefill scratch
-    float *px, *pxn, *pqkv, *pq, *pattn, *ph, *py, *ptmp, *pwts;
+    float *px, *pxn, *pqkv, *pq, *pattn, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
     uint16_t* pkv_planes = nullptr; size_t pkv_bytes = 0;   // bf16 hi/lo planes of one layer's K / V for the prefill attention (k_attn_prep)
     bool presplit_at_create = false;                        // vh_tune("attn_presplit") when the workspace was sized (carve must agree with it)
@@ -304,7 +292,7 @@ struct vh_mixtral {
     // state, so prefill and decode are the same code for both.
     struct Seq {
         bool live = false;
-        int host_pos = 0, attn_epoch = 0, poisoned = 0, npages = 0;
+        int host_pos = 0, poisoned = 0, npages = 0;
         std::vector<int> pages;        // host mirror of the device table (sized once: uploads read from it)
     };
     std::vector<Seq> seqs;
@@ -318,25 +306,25 @@ struct vh_mixtral {
     int *l_attn_cnt[VH_BMAX] = {}, *l_route[VH_BMAX] = {}, *l_blk_idx[VH_BMAX] = {};
     const int* table = nullptr;        // device page table of the bound sequence; null = contiguous rows (default state)
     int bound = -1;
-    struct { float *xa, *xb, *da, *dm; int *counters, *out_tokens; int host_pos, attn_epoch, poisoned; } dflt{};
+    struct { float *xa, *xb, *da, *dm; int *counters, *out_tokens; int host_pos, poisoned; } dflt{};
     int n_pages() const { return c.max_ctx / 64; }
     int live_seqs() const { int n = 0; for (const Seq& q : seqs) n += q.live; return n; }
     void bind(int s) {
-        dflt = {xa, xb, delta_attn, delta_moe, counters, out_tokens, host_pos, attn_epoch, poisoned};
+        dflt = {xa, xb, delta_attn, delta_moe, counters, out_tokens, host_pos, poisoned};
         float* x = seq_x + (size_t)s * 4 * H;
         xa = x; xb = x + H; delta_attn = x + 2 * H; delta_moe = x + 3 * H;
         counters = seq_counters + 4 * s;
         out_tokens = seq_tokens + (size_t)s * (c.max_new > 0 ? c.max_new : 1);
         table = seq_table + (size_t)s * max_splits;
-        host_pos = seqs[s].host_pos; attn_epoch = seqs[s].attn_epoch; poisoned = seqs[s].poisoned;
+        host_pos = seqs[s].host_pos; poisoned = seqs[s].poisoned;
         bound = s;
     }
     void unbind() {
         Seq& q = seqs[bound];
-        q.host_pos = host_pos; q.attn_epoch = attn_epoch; q.poisoned = poisoned;
+        q.host_pos = host_pos; q.poisoned = poisoned;
         xa = dflt.xa; xb = dflt.xb; delta_attn = dflt.da; delta_moe = dflt.dm;
         counters = dflt.counters; out_tokens = dflt.out_tokens;
-        host_pos = dflt.host_pos; attn_epoch = dflt.attn_epoch; poisoned = dflt.poisoned;
+        host_pos = dflt.host_pos; poisoned = dflt.poisoned;
         table = nullptr; bound = -1;
     }
     // pages covering positions [0, n_tokens) of sequence s; new table entries are uploaded on st.  -1: pool exhausted.
@@ -354,7 +342,7 @@ struct vh_mixtral {
     void release(int s) {
         Seq& q = seqs[s];
         for (int j = q.npages - 1; j >= 0; --j) free_pages.push_back(q.pages[j]);
-        q.npages = 0; q.live = false; q.host_pos = 0; q.attn_epoch = 0; q.poisoned = 0;
+        q.npages = 0; q.live = false; q.host_pos = 0; q.poisoned = 0;
     }
     void init_seqs() {
         seqs.assign(c.max_seqs > 0 ? c.max_seqs : 0, Seq{});
@@ -375,7 +363,7 @@ struct vh_mixtral {
     size_t prof_used = 0;
 
     size_t carve(void* ws) {
-        Carver cv{reinterpret_cast<char*>(ws), (size_t)(vh_tuning()->ws_pad > 0 ? vh_tuning()->ws_pad : 0) * 65536};
+        Carver cv{reinterpret_cast<char*>(ws), 0};
         const size_t Sm = (size_t)c.max_prefill;
         // ---- prefill scratch first: fixed offsets for a given (max_prefill, geometry) --------------------------------
         pxn_hi = cv.take<uint16_t>(Sm * H); pxn_lo = cv.take<uint16_t>(Sm * H);
@@ -393,7 +381,6 @@ struct vh_mixtral {
         }
         py = cv.take<float>(4 * 2 * Sm * H);   // py: up to 4 K-split slabs of the MoE down projection / 8 of the projections
         ptmp = cv.take<float>(Sm * H);
-        ph = cv.take<float>(2 * Sm * I);       // fp32 intermediates of the general-kernel path only
         pwts = cv.take<float>(2 * Sm);
         pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
         pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
@@ -632,7 +619,7 @@ int vh_mixtral_reset(vh_mixtral_t* m, void* stream) {
     if (!m) return fail(VH_E_ARG, "null engine");
     if (hipMemsetAsync(m->counters, 0, 4 * sizeof(int), S(stream)) != hipSuccess)
         return fail(VH_E_HIP, "reset memset failed");
-    m->host_pos = 0; m->attn_epoch = 0; m->poisoned = 0;
+    m->host_pos = 0; m->poisoned = 0;
     for (int s = 0; s < (int)m->seqs.size(); ++s)
         if (m->seqs[s].live) m->release(s);      // the pool is one: a reset returns every page
     return VH_OK;
@@ -662,7 +649,6 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     if (hipMemcpyAsync(m->px, embeds, (size_t)Sn * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(VH_E_HIP, "prefill: embed copy failed");
     if (hipMemsetAsync(m->counters + 1, 0, 3 * sizeof(int), st) != hipSuccess) return fail(VH_E_HIP, "memset failed");
-    m->attn_epoch = 0;
     m->poisoned = 0;
     if (m->c.vocab_n > 0 && m->c.tp_world > 1 &&
         hipMemsetAsync(m->logits, 0, (size_t)m->hist_rows() * m->V * sizeof(float), st) != hipSuccess)
@@ -685,8 +671,8 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                              H <= 4096 && (m->nqkv % 4) == 0;
     // (r03) K-split slabs are summed by the norm kernel that consumes the rows (VhRowUpdate) on the single-rank path;
     // vh_tune("prefill_fuse_rows", 0) restores the separate slab-sum / combine launches
-    const bool fuse_rows = !tp && vh_tuning()->prefill_fuse_rows != 0 && stream_attn && vh_tuning()->prefill_moe_gemm == 0;
-    const bool attn_planes = stream_attn && vh_tuning()->attn_impl != 1 && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
+    const bool fuse_rows = !tp && vh_tuning()->prefill_fuse_rows != 0 && stream_attn;
+    const bool attn_planes = stream_attn && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
     bool combine_pending = false;
     int pend_nslab = 1;
     const int* pend_nslab_dev = nullptr;
@@ -808,13 +794,12 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                 }
             }
         }
-        const bool stream_moe = vh_tuning()->prefill_moe_gemm == 0;
         bool moe_done = false;
         int nslab = 1;
         const int* nslab_dev = nullptr;
         const long slab = (long)2 * m->c.max_prefill * H;
-        if (stream_moe) {
-            // weight-streaming path: the norm kernel emits the bf16 hi/lo planes directly, one tall m-tile per
+        {
+            // weight-streaming MoE: the norm kernel emits the bf16 hi/lo planes directly, one tall m-tile per
             // expert (weights cross the fabric once), gate|up emits the planes of h, the down projection is
             // K-split into `nslab` partial slabs that the combine kernel adds
             const VhRowUpdate ou{m->py, (long)H, (long)Sm * H, m->pnslab + 2, 1, nullptr};     // the O projection's slabs
@@ -864,26 +849,6 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                 moe_done = true;
             } else {
                 VH_TRY(vhk_gemm_ps(st, d), "down gemm");
-            }
-        } else {
-            VH_TRY(vhk_rmsnorm_route(st, m->px, m->pxn, nullptr, nullptr, w.ffn_norm, Sn, H, m->c.rms_eps, w.wrouter, E,
-                                     m->pids, m->pwts), "rmsnorm + route");
-            VH_TRY(vhk_moe_sort(st, m->pids, Sn, E, m->pgoff, m->pstok, m->psslot), "sort");
-            {
-                VhGemmArgs g{};
-                g.A = m->pxn; g.lda = H; g.a_rows = Sn; g.a_rowidx = m->pstok; g.nseg = 1; g.seglen = H;
-                g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
-                g.group_off = m->pgoff; g.ngroups = E;
-                g.C = m->ph; g.ldc = I; g.M = 2 * Sn; g.N = I; g.K = H;
-                VH_TRY(vhk_gemm(st, g), "gate/up gemm");
-            }
-            {
-                VhGemmArgs g{};
-                g.A = m->ph; g.lda = I; g.a_rows = 2 * Sn; g.nseg = 1; g.seglen = I;
-                g.W = w.w2; g.ldw = I; g.w_group_stride = (long)H * I;
-                g.group_off = m->pgoff; g.ngroups = E;
-                g.C = m->py; g.ldc = H; g.c_rowidx = m->psslot; g.M = 2 * Sn; g.N = H; g.K = I;
-                VH_TRY(vhk_gemm(st, g), "down gemm");
             }
         }
         if (moe_done) {
@@ -993,19 +958,18 @@ static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, con
 }
 
 // One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
-// mirrors (host_pos, attn_epoch) are advanced by the CALLER only after the step was enqueued without error.
-static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
+// mirror of the position (host_pos) is advanced by the CALLER only after the step was enqueued without error.
+static int decode_one_step(vh_mixtral* m, hipStream_t st) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
-    *epoch_inc = 0;
     // Tensor parallel over the library's IPC transport: the two all-reduces of a layer are FUSED into the kernels around
     // them (VhXchg, vh_kernels.h): the O projection / MoE down projection push their partial outputs straight into the
     // peers' receive slots, the first blocks of the next kernel (gate|up, next layer's QKV, LM head) sum the slots and every
     // block of it waits for that sum behind its own weight loads — "all-reduce over xGMI overlapped with the expert GEMMs"
     // (web_demo/vllm_tools/vllm_file/mixtral.py:405-414,470-476), 65 kernel launches per token fewer than r02.
     const bool fuse = m->comm != nullptr && m->c.tp_world > 1 && vh_tuning()->tp_fuse != 0 && (H % 2) == 0 &&
-                      (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->fuse_attn_oproj && !vh_tuning()->force_allreduce;
+                      (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
     bool have_xm = false;
     for (int l = 0; l < m->c.n_layers; ++l) {
@@ -1014,23 +978,12 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int* epoch_inc) {
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
         VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                            m->qkv, have_xm ? &xm : nullptr), "dec qkv");
-        int fused = 1;
-        if (vh_tuning()->fuse_attn_oproj) {
-            fused = vhk_dec_attn_oproj(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o,
-                                       m->part_ml, m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits,
-                                       m->host_pos + 1, scale, m->counters + 2, (m->attn_epoch + *epoch_inc + 1) * nkv,
-                                       m->counters + 3, w.wo, H, nq * hd, m->delta_attn, m->table);
-            if (fused < 0) return launch_failed("dec attn+oproj");
-            if (fused == 0) *epoch_inc += 1;
-        }
-        if (fused != 0) {  // long contexts (grid not co-resident) or fusion disabled: two kernels
-            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
-                                m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
-                                scale, m->table, w.wo, (size_t)H * nq * hd * 2), "dec attn");
-            if (fuse && vh_comm_xchg_next(m->comm, H, 0, vhk_dec_consumer_blocks(1, 0, H, I), &xa, st) != VH_OK)
-                return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
-            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
-        }
+        VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                            m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
+                            scale, m->table), "dec attn");
+        if (fuse && vh_comm_xchg_next(m->comm, H, 0, vhk_dec_consumer_blocks(1, 0, H, I), &xa, st) != VH_OK)
+            return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
+        VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
         if (!fuse && m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
@@ -1063,16 +1016,14 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_decode: sequences own pages of the KV pool (use vh_mixtral_seq_decode)");
     for (int step = 0; step < n_steps; ++step) {
         if (m->host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx);
-        int epoch_inc = 0;
-        const int rc = decode_one_step(m, st, &epoch_inc);
+        const int rc = decode_one_step(m, st);
         if (rc != VH_OK) {
-            // the step was not (fully) enqueued: host_pos / attn_epoch keep their values, i.e. they describe the
+            // the step was not (fully) enqueued: host_pos keeps its value, i.e. it describes the
             // last COMPLETE step; the device state of the partial step is discarded by the next prefill / reset
             m->poisoned = 1;
             return rc;
         }
         m->host_pos += 1;
-        m->attn_epoch += epoch_inc;
     }
     return VH_OK;
 }
@@ -1222,27 +1173,11 @@ static int decode_iteration(vh_mixtral* m, hipStream_t st, const int* ids, int n
         } else {
             for (int g0 = 0; g0 < n; g0 += VH_BMAX) {
                 const int gn = n - g0 < VH_BMAX ? n - g0 : VH_BMAX;
-                if (vh_tuning()->batch_moe != 0) {
-                    // experimental: every DISTINCT routed expert of the group streamed once through the GEMV kernels
-                    // (measured SLOWER than one sequence after the other at B <= 4: 334 + 208 us vs 4 x (79 + 40))
-                    VhDecBatchVec g{};
-                    VhDecBatchRoute rt{};
-                    VhDecBatchOut ot{};
-                    g.n = gn;
-                    for (int b = 0; b < gn; ++b) {
-                        g.x_in[b] = xb[g0 + b]; g.delta[b] = da[g0 + b]; g.x_out[b] = xa[g0 + b];
-                        rt.route[b] = m->l_route[b]; rt.hbuf[b] = m->l_hbuf[b];
-                        ot.out[b] = dm[g0 + b];
-                    }
-                    VH_TRY(vhk_decb_gateup(st, g, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, rt), "batched gateup");
-                    VH_TRY(vhk_decb_down(st, rt, gn, w.w2, H, I, ot), "batched down");
-                } else {
                     for (int b = 0; b < gn; ++b) {
                         VH_TRY(vhk_dec_gateup(st, xb[g0 + b], da[g0 + b], xa[g0 + b], w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
                                               m->l_route[b], m->l_hbuf[b], 0), "dec gateup");
                         VH_TRY(vhk_dec_down(st, m->l_hbuf[b], m->l_route[b], w.w2, H, I, dm[g0 + b]), "dec down");
                     }
-                }
             }
             for (int b = 0; b < n; ++b)
                 if (m->allreduce(dm[b], H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
@@ -1320,10 +1255,9 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", s, i);
         if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
         m->bind(s);
-        int epoch_inc = 0;
-        const int rc = decode_one_step(m, st, &epoch_inc);
+        const int rc = decode_one_step(m, st);
         if (rc != VH_OK) m->poisoned = 1;
-        else { m->host_pos += 1; m->attn_epoch += epoch_inc; }
+        else m->host_pos += 1;
         m->unbind();
         if (rc != VH_OK) return rc;
     }

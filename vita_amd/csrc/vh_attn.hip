@@ -1,23 +1,15 @@
-// vh_attn.hip — multi-query-row attention in exact fp32 on the matrix cores
-// (v_mfma_f32_16x16x4_f32, gfx950 keeps an f32-in/f32-acc MFMA at the vector rate).
+// vh_attn.hip — multi-query-row attention on the matrix cores, operands straight from L2 (no LDS tiles).
 // Serves three call sites:
 //   K5  InternViT global attention, 16 heads x 64, N=1025, no mask
-//       (internvit/modeling_intern_vit.py:158-177)
+//       (internvit/modeling_intern_vit.py:158-177)                                   -> k_attn_x3 (bf16 x 3 MFMAs)
 //   K14 Whale rel-pos attention, 16 heads x 64: scores = ((q+u)k^T + (q+v)p^T)/sqrt(d),
 //       NO rel-shift, pad/chunk mask -> excluded keys (whale/module/layer/attention.py:370-419,
-//       whale/utils.py:88-146)
+//       whale/utils.py:88-146)                                                       -> k_attn_direct (fp32 MFMA)
 //   K23 Mixtral prefill: causal GQA, 32 q-heads / 8 kv-heads x 128, K/V read from the fp32
-//       KV cache (HF eager_attention_forward, modeling_mixtral.py:256-279)
-// The FLOP count of all three is small next to the GEMMs (53 GF for a 450-token prefill,
-// 103 GF per ViT tile), so exact fp32 costs <1-2 ms and removes attention from the
-// parity error budget.
-//
-// Structure: grid (ceil(Sq/64), Hq, B); 4 waves, each owning 16 query rows; K/V (and P)
-// tiles of 32 keys staged through LDS and shared by the 4 waves; flash-style online
-// softmax in the MFMA D layout (row = (lane>>4)*4 + r, col = lane&15) with 16-lane
-// shuffles; probabilities go D-layout -> A-layout through a per-wave LDS patch.
-// LDS row strides are chosen for the ds_read_b32 32-bank model: K/P stride D+2 (B-operand
-// read of K^T: 16 rows x {k,k+1}), V stride D+16 (B-operand read: 2 rows x 16 cols).
+//       KV cache (HF eager_attention_forward, modeling_mixtral.py:256-279)           -> k_attn_x3
+// One wave owns 16 (or 32) query rows and a share of the keys; flash-style online softmax in the MFMA D layout
+// (row = (lane>>4)*4 + r, col = lane&15) with DPP row reductions; probabilities go D-layout -> A-layout through a
+// wave-private LDS patch.  (r01's LDS-tiled 4-wave kernel was removed in r04: 143 us on the ViT against 50 here.)
 #include "vh_common.h"
 #include "vh_kernels.h"
 
@@ -37,215 +29,6 @@ __device__ __forceinline__ bool key_visible(const VhAttnArgs& p, int q, int key,
     }
     return true;
 }
-
-// KS: the keys of a query block are dealt to KS groups of 4 waves, 32-key tile by tile (tile t -> group t % KS), each
-// group running the flash recurrence on its share with its own LDS tiles; the partial (m, l, O) are merged in group
-// order at the end.  With 16 query rows per wave the whole problem is only ~1 wave per SIMD (ViT: 65 x 16 waves on 1024
-// SIMDs): a lone wave per SIMD cannot hide its LDS reads, barriers and the 8-pass fp32 MFMAs behind anything, which is
-// what the KS = 1 kernel measured (143 us against a 28 us matrix-pipe floor).  KS = 4 (d = 64) / 2 (d = 128) puts
-// 4 / 2 waves on every SIMD and shortens every wave's serial loop by the same factor.
-template <int D, bool REL, int KS>
-__global__ __launch_bounds__(256 * KS) void k_attn(const VhAttnArgs p) {
-    constexpr int KSTR = D + 2, VSTR = D + 16, NS = D / 4, NT = D / 16;
-    constexpr int K_SZ = AT_KT * KSTR, V_SZ = AT_KT * VSTR, P_SZ = REL ? AT_KT * KSTR : 0, PS_SZ = 16 * AT_PSTR;
-    constexpr int TILE_SZ = KS * (K_SZ + V_SZ + P_SZ);            // floats: the groups' K / V / P tiles
-    constexpr int MG_SZ = 4 * 64 * (8 + NT * 4);                  // one group's partial state for the merge (aliases the tiles)
-    constexpr int BASE_SZ = TILE_SZ > MG_SZ ? TILE_SZ : MG_SZ;
-    __shared__ __attribute__((aligned(16))) float smem[BASE_SZ + 4 * KS * PS_SZ];
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int kg = wid >> 2, wq = wid & 3, tl = tid & 255;        // key group, query sub-block, thread within the group
-    float* Kt = smem + kg * K_SZ;
-    float* Vt = smem + KS * K_SZ + kg * V_SZ;
-    float* Pt = smem + KS * (K_SZ + V_SZ) + kg * P_SZ;
-    float* Ps = smem + BASE_SZ + wid * PS_SZ;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int hk = h / (p.Hq / p.Hkv);
-    const int qblk = blockIdx.x * 64;
-    const int q0 = qblk + wq * 16;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
-    const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
-    const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
-    const float* Pb = REL ? (p.P + (size_t)h * p.hsp) : nullptr;
-
-    // Q fragments (A operand): a_s = Q[q0 + lr][4s + lg]
-    float qa[NS];
-    float qb[REL ? NS : 1];
-    {
-        const int q = q0 + lr;
-        const bool ok = q < p.Sq;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int dd = 4 * s + lg;
-            const float v = ok ? Qb[(size_t)q * p.ldq + dd] : 0.f;
-            if (REL) {
-                qa[s] = v + p.bias_u[h * D + dd];
-                qb[s] = v + p.bias_v[h * D + dd];
-            } else {
-                qa[s] = v;
-            }
-        }
-    }
-
-    int kend = min(p.Sk, p.klen);
-    int kloop = kend;
-    if (p.causal) kloop = min(kloop, min(qblk + 63, p.Sq - 1) + p.q_off + 1);
-
-    float m[4], l[4];
-    f32x4 o[NT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // K/V(/P) tiles are prefetched one tile ahead into NATIVE vector registers with unconditional, clamped
-    // 16-byte loads (rows past Sk are zeroed when the tile is written to LDS): the loads of tile t+1 are in
-    // flight during the MFMAs of tile t.
-    constexpr int F4 = AT_KT * (D / 4) / 256;   // 16-byte pieces per thread per operand: 2 (D=64) / 4 (D=128)
-    f32x4 kr[F4], vr[F4], pr[REL ? F4 : 1];
-    auto load_tile = [&](int kt0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < F4; ++i) {
-            const int idx = tl + i * 256;
-            const int row = idx / (D / 4), c4 = idx % (D / 4);
-            int key = min(kt0 + row, p.Sk - 1);
-            if (p.ktable) key = p.ktable[key >> 6] * 64 + (key & 63);       // paged KV cache (Mixtral prefill of a sequence)
-            kr[i] = reinterpret_cast<const f32x4*>(Kb + (size_t)key * p.ldk)[c4];
-            vr[i] = reinterpret_cast<const f32x4*>(Vb + (size_t)key * p.ldv)[c4];
-            if (REL) pr[i] = reinterpret_cast<const f32x4*>(Pb + (size_t)key * p.ldp)[c4];
-        }
-    };
-    auto store_tile = [&](int kt0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < F4; ++i) {
-            const int idx = tl + i * 256;
-            const int row = idx / (D / 4), c4 = idx % (D / 4);
-            const bool ok = kt0 + row < p.Sk;
-            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 kv = ok ? kr[i] : z, vv = ok ? vr[i] : z;
-            float* kd = &Kt[row * KSTR + c4 * 4];          // KSTR = D + 2: 8-byte aligned rows
-            *reinterpret_cast<float2*>(kd) = make_float2(kv[0], kv[1]);
-            *reinterpret_cast<float2*>(kd + 2) = make_float2(kv[2], kv[3]);
-            *reinterpret_cast<f32x4*>(&Vt[row * VSTR + c4 * 4]) = vv;   // VSTR = D + 16: 16-byte aligned rows
-            if (REL) {
-                const f32x4 pv = ok ? pr[i] : z;
-                float* pd = &Pt[row * KSTR + c4 * 4];
-                *reinterpret_cast<float2*>(pd) = make_float2(pv[0], pv[1]);
-                *reinterpret_cast<float2*>(pd + 2) = make_float2(pv[2], pv[3]);
-            }
-        }
-    };
-
-    // group kg walks tiles kg, kg + KS, ...; the trip count is block-uniform (barriers), a tile past kloop is all
-    // masked keys (loads clamped) and leaves (m, l, O) untouched
-    const int clamp_k = max(kloop - 1, 0);
-    if (kloop > 0) load_tile(min(kg * AT_KT, clamp_k));
-    for (int it0 = 0; it0 < kloop; it0 += KS * AT_KT) {
-        const int kt0 = it0 + kg * AT_KT;
-        store_tile(kt0);
-        __syncthreads();
-        load_tile(min(kt0 + KS * AT_KT, clamp_k));   // always issued (clamped): counted by the compiler
-
-        // ---- S = Q K^T (+ Qv P^T) for two 16-key sub-tiles ---------------------------
-        f32x4 sacc[2];
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* kp = &Kt[(jt * 16 + lr) * KSTR + lg];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kp[4 * s], a, 0, 0, 0);
-            if (REL) {
-                const float* pp = &Pt[(jt * 16 + lr) * KSTR + lg];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[s], pp[4 * s], a, 0, 0, 0);
-            }
-            sacc[jt] = a;
-        }
-
-        // ---- online softmax in D layout --------------------------------------------
-        float alpha[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = q0 + lg * 4 + r;
-            float s0 = sacc[0][r] * p.scale, s1 = sacc[1][r] * p.scale;
-            if (kt0 >= kloop || !key_visible(p, q, kt0 + lr, kend)) s0 = -INFINITY;
-            if (kt0 >= kloop || !key_visible(p, q, kt0 + 16 + lr, kend)) s1 = -INFINITY;
-            const float mx = grp16_max(fmaxf(s0, s1));
-            const float mn = fmaxf(m[r], mx);
-            float p0, p1;
-            if (mn == -INFINITY) {
-                alpha[r] = 1.f; p0 = 0.f; p1 = 0.f;
-            } else {
-                alpha[r] = __expf(m[r] - mn);
-                p0 = __expf(s0 - mn);
-                p1 = __expf(s1 - mn);
-            }
-            l[r] = l[r] * alpha[r] + grp16_sum(p0 + p1);
-            m[r] = mn;
-            Ps[(lg * 4 + r) * AT_PSTR + lr] = p0;
-            Ps[(lg * 4 + r) * AT_PSTR + 16 + lr] = p1;
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[t][r] *= alpha[r];
-        __syncthreads();  // P patch visible to the whole wave (block-uniform trip count)
-
-        // ---- O += P V --------------------------------------------------------------
-#pragma unroll
-        for (int s = 0; s < AT_KT / 4; ++s) {
-            const float pa = Ps[lr * AT_PSTR + 4 * s + lg];
-            const float* vp = &Vt[(4 * s + lg) * VSTR + lr];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vp[16 * t], o[t], 0, 0, 0);
-        }
-        __syncthreads();  // tiles and P patch are rewritten next iteration
-    }
-
-    // ---- merge the key groups into group 0, in group order (deterministic) ---------------------------------------
-    if (KS > 1) {
-        float* mg = smem + (wq * 64 + lane) * (8 + NT * 4);   // aliases the K/V tiles: the loop's last barrier has passed
-        for (int g = 1; g < KS; ++g) {
-            if (kg == g) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { mg[r] = m[r]; mg[4 + r] = l[r]; }
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mg[8 + t * 4 + r] = o[t][r];
-            }
-            __syncthreads();
-            if (kg == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float m2 = mg[r], l2 = mg[4 + r];
-                    const float mn = fmaxf(m[r], m2);
-                    const float a1 = (mn == -INFINITY) ? 1.f : __expf(m[r] - mn);
-                    const float a2 = (mn == -INFINITY) ? 0.f : __expf(m2 - mn);
-                    l[r] = l[r] * a1 + l2 * a2;
-                    m[r] = mn;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) o[t][r] = o[t][r] * a1 + mg[8 + t * 4 + r] * a2;
-                }
-            }
-            __syncthreads();
-        }
-        if (kg != 0) return;
-    }
-
-    float* Ob = p.O + (size_t)b * p.bso + (size_t)h * D;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int q = q0 + lg * 4 + r;
-        if (q >= p.Sq) continue;
-        const float inv = (l[r] > 0.f) ? 1.0f / l[r] : 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) Ob[(size_t)q * p.ldo + 16 * t + lr] = o[t][r] * inv;
-    }
-}
-
 
 // ---- direct-operand variant (default) ----------------------------------------------------------------------------
 // One wave = 16 query rows x one share of the keys; NO LDS tiles and no block barriers in the loop.  The MFMA operand
@@ -821,7 +604,7 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
     auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     if (!a.O && !a.O_hi) return -1;
     if (a.O_hi && (!a.O_lo || a.B != 1 || (a.ldo_split % 4) != 0 || !al16(a.O_hi) || !al16(a.O_lo))) return -1;
-    const bool direct_ok = vh_tuning()->attn_impl != 1 && al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
+    const bool direct_ok = al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
                            (!rel || (al16(a.bias_u) && al16(a.bias_v) && (a.ldp % 4) == 0 && (a.hsp % 4) == 0)) &&
                            ((a.ldq | a.hsq | a.bsq | a.ldk | a.hsk | a.bsk | a.ldv | a.hsv | a.ldo | a.bso) % 4) == 0;
     if (direct_ok && (a.d == 64 || (a.d == 128 && !rel))) {
@@ -834,8 +617,6 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
         // blocks for the ViT's 1040 instead of 512), 2 elsewhere (rel-pos and d = 128 need > 200 registers)
 #define AT_LAUNCH(DD, RR, KK) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, 2>), g16, dim3(64 * KK), 0, st, a)
 #define AT_LAUNCH_W(DD, RR, KK, WW) hipLaunchKernelGGL((k_attn_direct<DD, RR, KK, WW>), g16, dim3(64 * KK), 0, st, a)
-        const int wpe_raw = vh_tuning()->attn_wpe;          // 0 = auto: 3 for the fp32 kernel, 2 for bf16 x 3 (3 spills inside its loop)
-        const int wpe = wpe_raw == 0 ? 3 : wpe_raw;
         // bf16 x 3 products (attn_impl 2: the fp32-MFMA kernel below).  Mask flavours are compile-time: pad mask only, causal,
         // causal + page table; anything else (chunk masks, a page table without causal) takes the fp32 kernel.
         int mode = a.chunk > 0 ? -1 : (!a.causal ? (a.ktable ? -1 : 0) : (a.ktable ? 2 : 1));
@@ -870,7 +651,7 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
             } else if (two) {
                 if (ks == 1) X3(64, 1, 2, 2, 0, g32); else if (ks == 2) X3(64, 2, 2, 2, 0, g32); else X3(64, 4, 2, 2, 0, g32);
             } else if (a.d == 64) {
-                if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else if (wpe_raw != 3) X3_MODES(64, 4, 2); else X3_MODES(64, 4, 3);
+                if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else X3_MODES(64, 4, 2);
             } else {
                 if (ks == 1) X3_MODES(128, 1, 2); else X3_MODES(128, 2, 2);
             }
@@ -882,8 +663,6 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
         if (a.d == 64 && !rel) {
             if (ks == 1) AT_LAUNCH(64, false, 1);
             else if (ks == 2) AT_LAUNCH(64, false, 2);
-            else if (wpe == 2) AT_LAUNCH_W(64, false, 4, 2);
-            else if (wpe == 4) AT_LAUNCH_W(64, false, 4, 4);
             else AT_LAUNCH_W(64, false, 4, 3);
         }
         else if (a.d == 64) { if (ks == 1) AT_LAUNCH(64, true, 1); else if (ks == 2) AT_LAUNCH(64, true, 2); else AT_LAUNCH(64, true, 4); }
@@ -892,22 +671,5 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
 #undef AT_LAUNCH_W
         return 0;
     }
-    if (a.O_hi || !a.O) return -1;                    // plane output exists in the direct kernel only
-    const dim3 grid((a.Sq + 63) / 64, a.Hq, a.B);
-    // key groups per block: 4 (d = 64) / 2 (d = 64 rel-pos, d = 128) when the context is long enough to deal out (attn_ksplit = 1 keeps
-    // the single-group kernel: tests compare the two)
-    const bool one = want == 1 || kl <= 2 * AT_KT;
-    if (a.d == 64 && !rel) {
-        if (one) hipLaunchKernelGGL((k_attn<64, false, 1>), grid, dim3(256), 0, st, a);
-        else if (want == 2) hipLaunchKernelGGL((k_attn<64, false, 2>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_attn<64, false, 4>), grid, dim3(1024), 0, st, a);
-    } else if (a.d == 64 && rel) {    // (4 groups need 12 spilled VGPRs at the 128-register budget of 1024 threads: auto = 2)
-        if (one) hipLaunchKernelGGL((k_attn<64, true, 1>), grid, dim3(256), 0, st, a);
-        else if (want == 4) hipLaunchKernelGGL((k_attn<64, true, 4>), grid, dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_attn<64, true, 2>), grid, dim3(512), 0, st, a);
-    } else if (a.d == 128 && !rel) {
-        if (one) hipLaunchKernelGGL((k_attn<128, false, 1>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_attn<128, false, 2>), grid, dim3(512), 0, st, a);
-    } else return -1;
-    return 0;
+    return -1;   // rows that do not allow 16-byte accesses, d outside {64, 128}, rel-pos at d = 128: rejected (VH_E_SHAPE)
 }

@@ -72,13 +72,21 @@ __device__ __forceinline__ void xchg_reduce(const VhXchg& cx) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cx.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// consumer, step 2 (AFTER the weight loads are in flight): the summed vector is complete
+// consumer, step 2 (AFTER the weight loads are in flight): the summed vector is complete.
+// Ordering: `reduced` is written and read ONLY with 8-byte agent-scope atomics (write-through sc1 stores, L1-bypassing sc1
+// loads: guide G16 "8-B agent atomics both sides"), every reducer wave drains its stores (vmcnt(0)) before the block's one
+// relaxed arrival, so no release / acquire fence is needed and the consumer's weight loads stay in flight.
+// Residency: the nred reducer blocks are the FIRST blocks of the consumer grid, and every consumer grid of the decode step
+// (768 / 384 / <= 1024 blocks of 256 threads) is co-resident on one device's 256 CUs, so a waiting block can never keep a
+// reducer from being scheduled when each rank owns its GPU; ranks SHARING a device (tests) can starve each other, which is
+// why the spin is bounded and ends in the sticky error word rather than a hang.
 __device__ __forceinline__ void xchg_wait(const VhXchg& cx) {
     if (cx.world == 0) return;
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while ((int)((unsigned)__hip_atomic_load(cx.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)cx.target) < 0) {   // modulo 2^32
-            if (++spins > VH_XCHG_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(cx.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if ((spins & 1023u) == 1023u && __hip_atomic_load(cx.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // someone else failed: keep ITS code
+            if (++spins > VH_XCHG_SPIN_LIMIT) {                       // this block's own time-out
                 __hip_atomic_store(cx.err, 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -390,113 +398,25 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     return true;
 }
 
-// Blocks with blockIdx.y >= nsplit are PREFETCHERS: attention is a latency chain on nkv x nsplit blocks (8.7 us, HBM
-// idle, ~170 CUs without work), so the rest of the launch can pull the O-projection weights, which the next kernel
-// streams, through the memory-side cache (plain loads, results discarded).  Experiment, OFF by default: the launch gets
-// longer than the O-projection gets shorter (211.5 -> 198 tok/s).
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
                                                   float* __restrict__ vcache, const int pos, const int* __restrict__ table,
-                                                  const int nsplit_attn, const u32x4* __restrict__ pf, const long pf_n,
                                                   const float* __restrict__ rope_cos,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
                                                   int max_splits, float scale) {
-    if ((int)blockIdx.y >= nsplit_attn) {
-        const long nthreads = (long)(gridDim.y - nsplit_attn) * gridDim.x * 256;
-        long i = ((long)(blockIdx.y - nsplit_attn) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        u32x4 acc = u32x4{0u, 0u, 0u, 0u};
-        for (; i < pf_n; i += nthreads) acc |= pf[i];
-        asm volatile("" ::"v"(acc));          // keep the loads
-        return;
-    }
-    dec_attn_block(blockIdx.x, blockIdx.y, nsplit_attn, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
+    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
                    part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
-}
-
-// ---- K_B + K_C in one launch: attention blocks and O-projection blocks run side by side ------
-// The O-projection is a pure weight stream that depends on the attention output only through its
-// 16 KB activation vector.  Its blocks therefore put their weight rows in flight FIRST (R rows x K
-// bf16 per block, the whole 33.5 MB matrix across the grid), then wait for the attention blocks of
-// the same launch to publish attn_out, then multiply: the HBM stream hides behind the latency-bound
-// attention instead of following it across a kernel boundary.
-// Hand-off (guide §6 G16, counter form): the merging block of each KV head stores its attn_out rows ->
-// vmcnt(0) -> barrier -> lane 0 agent-scope release -> monotonic done counter += 1.  O-proj blocks:
-// lane 0 polls the counter with relaxed agent-scope loads (s_sleep between polls, bounded) until it
-// reaches epoch*nkv, one agent-scope acquire, barrier, plain loads.  The counter only grows (the host
-// passes the launch's epoch), so nothing has to be reset between launches.
-// No-deadlock argument: only O-proj blocks wait, attention blocks never do; the launcher sizes the
-// grid so that ALL blocks of the launch are co-resident (<= 2 per CU by LDS), hence every attention
-// block is scheduled no matter in which order the dispatcher places blocks.
-template <int NJ, int R>
-__global__ __launch_bounds__(256) void k_dec_attn_oproj(const float* __restrict__ qkv, float* __restrict__ kcache,
-                                                        float* __restrict__ vcache, const int pos,
-                                                        const float* __restrict__ rope_cos,
-                                                        const float* __restrict__ rope_sin,
-                                                        float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                        int* __restrict__ cnt, float* __restrict__ attn_out, int nq,
-                                                        int nkv, int max_ctx, int max_splits, float scale,
-                                                        int nsplit, int* __restrict__ done_ctr, int done_target,
-                                                        int* __restrict__ err_flag, const uint16_t* __restrict__ Wo,
-                                                        int N, int K, float* __restrict__ out,
-                                                        const int* __restrict__ table) {
-    const int n_attn = nkv * nsplit;
-    if ((int)blockIdx.x < n_attn) {
-        const int h = blockIdx.x % nkv, sp = blockIdx.x / nkv;
-        const bool merged = dec_attn_block(h, sp, nsplit, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
-                                           part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
-        if (merged) {  // block-uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        return;
-    }
-    __shared__ float red[4 * R];
-    const int n0 = ((int)blockIdx.x - n_attn) * R;
-    const uint16_t* rows[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) rows[r] = Wo + (size_t)min(n0 + r, N - 1) * K;
-    uint4 w[R][NJ];
-    gemv_issue<NJ, R>(rows, K, w);
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_target < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) {  // ~seconds: never hang the device on a protocol bug
-                __hip_atomic_store(err_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    float xr[NJ][8];
-    load_x<NJ>(attn_out, K, xr);
-    float acc[R];
-    gemv_fma<NJ, R>(w, xr, acc);
-    block256_sum<R>(acc, red);
-    if (threadIdx.x < R && n0 + threadIdx.x < N) {
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = acc[r];
-        out[n0 + threadIdx.x] = v;
-    }
 }
 
 // ---- K_D: residual add + RMSNorm + router + gate|up GEMV + SiLU*up ------------------
 // Router (modeling_mixtral.py:96-111): logits = x_n @ Wg^T ; softmax fp32 ; top-2 ;
 // renormalise.  Every block recomputes it (8 rows, L2-resident) so the expert ids never
 // leave the device.  route_out = {e0, e1, bits(w0), bits(w1)}.  Blocks are persistent: each
-// loops over 2*RP-row groups (RP gate + RP up rows of one expert).  DB=true keeps the NEXT
-// group's weight loads in flight in a second register buffer while the current one is reduced
-// (fewer, fatter waves); DB=false relies on co-resident blocks for the overlap (measured faster
-// at K=4096: 84 vs 91 us — the second buffer costs two waves/SIMD of occupancy).
-template <int NJ, int RP, bool DB>
+// loops over 2*RP-row groups (RP gate + RP up rows of one expert) and relies on the co-resident
+// blocks of its CU for the overlap of one block's reduction with another's loads (a second register
+// buffer per block measured slower, 91 vs 84 us: it costs two waves per SIMD of occupancy; r01, git history).
+template <int NJ, int RP>
 __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                     float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                     float eps, const uint16_t* __restrict__ Wg, int E,
@@ -571,29 +491,11 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
     int it = blockIdx.x;
     if (it >= n_iter) return;
     const uint16_t* rows[2 * RP];
-    if (DB) {
-        uint4 wa[2 * RP][NJ], wb[2 * RP][NJ];
+    for (; it < n_iter; it += gridDim.x) {
+        uint4 w[2 * RP][NJ];
         rows_of(it, rows);
-        gemv_issue<NJ, 2 * RP>(rows, K, wa);
-        while (true) {
-            int nxt = it + gridDim.x;
-            if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, wb); }
-            finish(it, wa);
-            it = nxt;
-            if (it >= n_iter) break;
-            nxt = it + gridDim.x;
-            if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, wa); }
-            finish(it, wb);
-            it = nxt;
-            if (it >= n_iter) break;
-        }
-    } else {
-        for (; it < n_iter; it += gridDim.x) {
-            uint4 w[2 * RP][NJ];
-            rows_of(it, rows);
-            gemv_issue<NJ, 2 * RP>(rows, K, w);
-            finish(it, w);
-        }
+        gemv_issue<NJ, 2 * RP>(rows, K, w);
+        finish(it, w);
     }
 }
 
@@ -641,59 +543,6 @@ __global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf
         for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = tot[r];
         if (px.world) xchg_put(px, n0 + threadIdx.x, v);
         else out[n0 + threadIdx.x] = v;
-    }
-}
-
-// Persistent form of K_E: a block keeps BOTH intermediate vectors (2 x I floats) in registers and walks row pairs
-// n0, n0 + grid*R, ...: the 2 x 57 KB of activations are read from L2 once per block instead of once per row pair
-// (2048 one-shot blocks re-read 233 MB per launch), and the weight loads of the next pair are issued before the current
-// pair is reduced.
-template <int NJ, int R>
-__global__ __launch_bounds__(256) void k_dec_down_p(const float* __restrict__ hbuf, const int* __restrict__ route,
-                                                    const uint16_t* __restrict__ W2, int N, int I,
-                                                    float* __restrict__ out) {
-    __shared__ float red[4 * R];
-    const int e0 = route[0], e1 = route[1];
-    const float w0 = __int_as_float(route[2]), w1 = __int_as_float(route[3]);
-    auto rows_of = [&](int n0, const uint16_t* (&ra)[R], const uint16_t* (&rb)[R]) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            ra[r] = W2 + ((size_t)e0 * N + min(n0 + r, N - 1)) * I;
-            rb[r] = W2 + ((size_t)e1 * N + min(n0 + r, N - 1)) * I;
-        }
-    };
-    int n0 = blockIdx.x * R;
-    if (n0 >= N) return;
-    const uint16_t* ra[R];
-    const uint16_t* rb[R];
-    uint4 wa[R][NJ], wb[R][NJ];
-    rows_of(n0, ra, rb);
-    gemv_issue<NJ, R>(ra, I, wa);
-    gemv_issue<NJ, R>(rb, I, wb);
-    float xa[NJ][8], xb[NJ][8];
-    load_x<NJ>(hbuf, I, xa);
-    load_x<NJ>(hbuf + (size_t)I, I, xb);
-    while (true) {
-        float acc0[R], acc1[R], tot[R];
-        gemv_fma<NJ, R>(wa, xa, acc0);
-        gemv_fma<NJ, R>(wb, xb, acc1);
-        const int nxt = n0 + gridDim.x * R;
-        if (nxt < N) {                                   // block-uniform; the loads fly during the reduction below
-            rows_of(nxt, ra, rb);
-            gemv_issue<NJ, R>(ra, I, wa);
-            gemv_issue<NJ, R>(rb, I, wb);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) tot[r] = fmaf(w1, acc1[r], w0 * acc0[r]);
-        block256_sum<R>(tot, red);
-        if (threadIdx.x < R && n0 + threadIdx.x < N) {
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = tot[r];
-            out[n0 + threadIdx.x] = v;
-        }
-        if (nxt >= N) break;
-        n0 = nxt;
     }
 }
 
@@ -925,183 +774,6 @@ __global__ __launch_bounds__(256) void k_decb_attn(const VhDecBatchAttn bt, floa
                    bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale);
 }
 
-// top-2 of 8 router probabilities (k_dec_gateup's rule: first maximum wins)
-__device__ __forceinline__ void route_top2(const float (&lg)[8], int E, int& e0, int& e1, float& w0, float& w1) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E) mx = fmaxf(mx, lg[e]);
-    float pr[8], sum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { pr[e] = (e < E) ? expf(lg[e] - mx) : 0.f; sum += pr[e]; }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pr[e] = pr[e] / sum;
-    float b0 = -1.f, b1 = -1.f;
-    e0 = 0; e1 = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
-    const float t = b0 + b1;
-    w0 = b0 / t; w1 = b1 / t;
-}
-// the distinct experts of a batch, 4 bits each (first-use order), and their count
-__device__ __forceinline__ void uniq_add(unsigned& packed, int& nu, int e) {
-    bool have = false;
-    for (int u = 0; u < nu; ++u) have |= (int)((packed >> (4 * u)) & 15u) == e;
-    if (!have) { packed |= (unsigned)e << (4 * nu); ++nu; }
-}
-
-// router (per sequence) + gate|up GEMV of every DISTINCT routed expert, each expert's rows streamed once and multiplied
-// against every sequence that picked it.  hbuf[b] = [slot 0 | slot 1][I] as in k_dec_gateup.
-template <int NJ, int RP>
-__global__ __launch_bounds__(256) void k_decb_gateup(const VhDecBatchVec bt, const float* __restrict__ norm_w, float eps,
-                                                     const uint16_t* __restrict__ Wg, int E,
-                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
-                                                     int I, int K, const VhDecBatchRoute rt) {
-    __shared__ float red[4 * VH_BMAX * 9];
-    float xr[VH_BMAX][NJ][8];
-    float inv[VH_BMAX];
-    int e0[VH_BMAX], e1[VH_BMAX];
-    {
-        const uint16_t* rrows[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rrows[e] = Wg + (size_t)min(e, E - 1) * K;
-        uint4 wr[8][NJ];
-        gemv_issue<NJ, 8>(rrows, K, wr);
-        float vals[VH_BMAX * 9];
-#pragma unroll
-        for (int b = 0; b < VH_BMAX; ++b) {
-            const int bb = min(b, bt.n - 1);
-            vals[b * 9 + 8] = load_add_norm<NJ>(bt.x_in[bb], bt.delta[bb], norm_w, b < bt.n ? bt.x_out[bb] : nullptr, K, xr[b]);
-        }
-#pragma unroll
-        for (int b = 0; b < VH_BMAX; ++b) {
-            float lg[8];
-            gemv_fma<NJ, 8>(wr, xr[b], lg);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) vals[b * 9 + e] = lg[e];
-        }
-        block256_sum<VH_BMAX * 9>(vals, red);
-#pragma unroll
-        for (int b = 0; b < VH_BMAX; ++b) {
-            inv[b] = rsqrtf(vals[b * 9 + 8] / (float)K + eps);
-            float lg[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) lg[e] = vals[b * 9 + e] * inv[b];
-            float w0, w1;
-            route_top2(lg, E, e0[b], e1[b], w0, w1);
-            if (b < bt.n && blockIdx.x == 0 && threadIdx.x == 0) {
-                int* ro = rt.route[b];
-                ro[0] = e0[b]; ro[1] = e1[b]; ro[2] = __float_as_int(w0); ro[3] = __float_as_int(w1);
-            }
-        }
-    }
-    unsigned packed = 0;
-    int nu = 0;
-#pragma unroll
-    for (int b = 0; b < VH_BMAX; ++b)
-        if (b < bt.n) { uniq_add(packed, nu, e0[b]); uniq_add(packed, nu, e1[b]); }
-
-    const int per_exp = I / RP;
-    const int n_iter = nu * per_exp;
-    __shared__ float red2[4 * 2 * RP];
-    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const int u = it / per_exp;
-        const int i0 = (it - u * per_exp) * RP;
-        const int e = (int)((packed >> (4 * u)) & 15u);
-        const uint16_t* rows[2 * RP];
-#pragma unroll
-        for (int r = 0; r < RP; ++r) {
-            rows[r] = W1 + ((size_t)e * I + i0 + r) * K;
-            rows[RP + r] = W3 + ((size_t)e * I + i0 + r) * K;
-        }
-        uint4 w[2 * RP][NJ];
-        gemv_issue<NJ, 2 * RP>(rows, K, w);
-#pragma unroll
-        for (int b = 0; b < VH_BMAX; ++b) {
-            if (b >= bt.n) break;
-#pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
-                if ((slot ? e1[b] : e0[b]) != e) continue;              // block-uniform
-                float acc[2 * RP];
-                gemv_fma<NJ, 2 * RP>(w, xr[b], acc);
-                block256_sum<2 * RP>(acc, red2);
-                if (threadIdx.x < RP) {
-                    float g = 0.f, up = 0.f;
-#pragma unroll
-                    for (int r = 0; r < RP; ++r) if (threadIdx.x == r) { g = acc[r]; up = acc[RP + r]; }
-                    rt.hbuf[b][(size_t)slot * I + i0 + threadIdx.x] = silu_f(g * inv[b]) * (up * inv[b]);
-                }
-            }
-        }
-    }
-}
-
-// down projection of the batch: rows [n0, n0 + R) of every distinct expert are streamed once, two experts in flight
-// (as k_dec_down holds both experts of its one sequence), and multiplied against every (sequence, slot) that picked it
-template <int NJ, int R>
-__global__ __launch_bounds__(256) void k_decb_down(const VhDecBatchRoute rt, int n, const uint16_t* __restrict__ W2, int N,
-                                                   int I, const VhDecBatchOut ot) {
-    __shared__ float red[4 * VH_BMAX * R];
-    int e0[VH_BMAX], e1[VH_BMAX];
-    float w0[VH_BMAX], w1[VH_BMAX];
-    unsigned packed = 0;
-    int nu = 0;
-#pragma unroll
-    for (int b = 0; b < VH_BMAX; ++b) {
-        const int* ro = rt.route[min(b, n - 1)];
-        e0[b] = ro[0]; e1[b] = ro[1]; w0[b] = __int_as_float(ro[2]); w1[b] = __int_as_float(ro[3]);
-        if (b < n) { uniq_add(packed, nu, e0[b]); uniq_add(packed, nu, e1[b]); }
-    }
-    const int n0 = blockIdx.x * R;
-    float tot[VH_BMAX * R];
-#pragma unroll
-    for (int i = 0; i < VH_BMAX * R; ++i) tot[i] = 0.f;
-    for (int u = 0; u < nu; u += 2) {
-        const int ea = (int)((packed >> (4 * u)) & 15u);
-        const bool two = u + 1 < nu;
-        const int eb = two ? (int)((packed >> (4 * (u + 1))) & 15u) : ea;
-        const uint16_t* rowsa[R];
-        const uint16_t* rowsb[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            rowsa[r] = W2 + ((size_t)ea * N + min(n0 + r, N - 1)) * I;
-            rowsb[r] = W2 + ((size_t)eb * N + min(n0 + r, N - 1)) * I;
-        }
-        uint4 wa[R][NJ], wb[R][NJ];
-        gemv_issue<NJ, R>(rowsa, I, wa);
-        gemv_issue<NJ, R>(rowsb, I, wb);
-#pragma unroll
-        for (int b = 0; b < VH_BMAX; ++b) {
-            if (b >= n) break;
-#pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
-                const int es = slot ? e1[b] : e0[b];
-                const float ws = slot ? w1[b] : w0[b];
-                const bool ua = es == ea, ub = two && es == eb;       // block-uniform
-                if (!ua && !ub) continue;
-                float xr[NJ][8];
-                load_x<NJ>(rt.hbuf[b] + (size_t)slot * I, I, xr);
-                float acc[R];
-                if (ua) gemv_fma<NJ, R>(wa, xr, acc); else gemv_fma<NJ, R>(wb, xr, acc);
-#pragma unroll
-                for (int r = 0; r < R; ++r) tot[b * R + r] = fmaf(ws, acc[r], tot[b * R + r]);
-            }
-        }
-    }
-    block256_sum<VH_BMAX * R>(tot, red);
-#pragma unroll
-    for (int b = 0; b < VH_BMAX; ++b) {
-        if (b >= n) break;
-        if (threadIdx.x < R && n0 + threadIdx.x < N) {
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = tot[b * R + r];
-            ot.out[b][n0 + threadIdx.x] = v;
-        }
-    }
-}
-
 // final RMSNorm + LM head + per-block argmax for every sequence of the batch (the 424 MB table is read once)
 template <int NJ>
 __global__ __launch_bounds__(256) void k_decb_lmhead(const VhDecBatchVec bt, const float* __restrict__ norm_w, float eps,
@@ -1199,127 +871,68 @@ static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta
     });
 }
 
-static int dec_gemv_rows(int K) {
-    const int r = vh_tuning()->gemv_rows;   // rows per block: 8 (default), 4 or 16 (vh_tune)
-    return r == 8 ? 8 : (r == 16 && K <= 4096 ? 16 : 4);
-}
-static int dec_gateup_grid(int I, int grid) {
-    const int rp = vh_tuning()->gateup_variant == 2 ? 2 : 4;
-    const int n_iter = 2 * (I / rp);
-    if (grid <= 0) grid = vh_tuning()->gateup_grid;
-    if (grid <= 0) grid = 3 * vh_num_cus() / 2;
+// rows per block of the QKV / O GEMVs.  8: r02 sweep with the transposing block reduction (4: -0.5 % of a token, 16: -1 %)
+constexpr int DEC_GEMV_R = 8;
+static int dec_gateup_grid(int I) {
+    // 1.5 persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so fewer, longer-lived
+    // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
+    // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
+    const int n_iter = 2 * (I / 4);
+    const int grid = 3 * vh_num_cus() / 2;
     return grid > n_iter ? n_iter : grid;
 }
 // blocks of a consumer launch: the fused exchange's reducers are its first min(16, blocks) blocks
 int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
-    if (which == 0) { const int r = dec_gemv_rows(K); return (N + r - 1) / r; }
-    if (which == 1) return dec_gateup_grid(I, 0);
+    (void)K;
+    if (which == 0) return (N + DEC_GEMV_R - 1) / DEC_GEMV_R;
+    if (which == 1) return dec_gateup_grid(I);
     return N;   // LM head: the caller's grid
 }
 
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                 const uint16_t* W, int N, int K, float* out, const VhXchg* cx) {
-    const int r = dec_gemv_rows(K);
-    if (r == 8) return launch_dec_gemv<8, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
-    if (r == 16) return launch_dec_gemv<16, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
-    return launch_dec_gemv<4, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
+    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table, const void* prefetch, size_t prefetch_bytes) {
+                 const int* table) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
-    if (nsplit < 1 || nsplit > max_splits) return -1;
-    int extra = 0;
-    if (prefetch && prefetch_bytes >= (1u << 20) && vh_tuning()->dec_prefetch > 0) {
-        extra = (vh_tuning()->dec_prefetch * vh_num_cus() + nkv - 1) / nkv;     // dec_prefetch prefetching blocks per CU
-        if (nsplit + extra > 65535) extra = 65535 - nsplit;
-    }
-    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit + extra), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, nsplit,
-                       reinterpret_cast<const u32x4*>(prefetch), (long)(extra ? prefetch_bytes / 16 : 0), rope_cos,
+    if (nsplit < 1 || nsplit > max_splits || nsplit > 65535) return -1;
+    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
                        rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
     return 0;
 }
 
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px) {
-    const int r = dec_gemv_rows(K);
-    if (r == 8) return launch_dec_gemv<8, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
-    if (r == 16) return launch_dec_gemv<16, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
-    return launch_dec_gemv<4, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
-}
-
-// Fused attention + O-projection launch.  Returns 1 (nothing launched) when the launch could not be
-// fully co-resident or the shape is outside the fused instantiations: the caller then uses the two
-// separate kernels.
-int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
-                       const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
-                       float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out,
-                       const int* table) {
-    constexpr int R = 16;
-    (void)pos_ptr;
-    if (nq % nkv != 0 || nq / nkv > 4) return -1;
-    const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
-    if (nsplit < 1 || nsplit > max_splits) return -1;
-    const int n_oproj = (N + R - 1) / R;
-    // LDS (69.6 KB static) admits 2 blocks per CU; every block of the launch must be resident at once
-    const int cap = vh_tuning()->fuse_max_blocks > 0 ? vh_tuning()->fuse_max_blocks : 2 * vh_num_cus();
-    if (nkv * nsplit + n_oproj > cap || K > 4096 || (K % 8) != 0) return 1;
-    const dim3 grid(nkv * nsplit + n_oproj);
-    if (K <= 2048)
-        hipLaunchKernelGGL((k_dec_attn_oproj<1, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
-                           rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
-                           done_ctr, done_target, err_flag, Wo, N, K, out, table);
-    else
-        hipLaunchKernelGGL((k_dec_attn_oproj<2, R>), grid, dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, rope_cos,
-                           rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, nsplit,
-                           done_ctr, done_target, err_flag, Wo, N, K, out, table);
-    return 0;
+    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
 }
 
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid, const VhXchg* cxp) {
-    const int variant = vh_tuning()->gateup_variant;   // 0: RP=4 single buffer, 1: RP=4 double buffer, 2: RP=2 single
-    const int rp = variant == 2 ? 2 : 4;
-    if (E > 8 || E < 2 || I % rp != 0) return -1;
-    const int n_iter = 2 * (I / rp);
+    if (E > 8 || E < 2 || I % 4 != 0) return -1;
+    const int n_iter = 2 * (I / 4);
     const VhXchg cx = xchg_or_none(cxp);
-    if (grid <= 0) grid = vh_tuning()->gateup_grid;
-    // 1.5 persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so fewer, longer-lived
-    // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
-    // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
-    if (grid <= 0) grid = 3 * vh_num_cus() / 2;
+    if (grid <= 0) grid = dec_gateup_grid(I);
     if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        if (variant == 1)
-            hipLaunchKernelGGL((k_dec_gateup<NJ, 4, true>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                               eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
-        else if (variant == 2)
-            hipLaunchKernelGGL((k_dec_gateup<NJ, 2, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                               eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
-        else
-            hipLaunchKernelGGL((k_dec_gateup<NJ, 4, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                               eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
+        hipLaunchKernelGGL((k_dec_gateup<NJ, 4>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
+                           eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
         return 0;
     });
 }
 
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
                  const VhXchg* pxp) {
+    // one block per row pair (a persistent form that keeps both intermediate vectors in registers measured slower: 204.6-208.8
+    // against 211.5 tok/s, r02, git history)
     constexpr int R = 2;
-    const int pg = vh_tuning()->down_grid;             // > 0: persistent blocks per launch (0 = one block per row pair)
     const VhXchg px = xchg_or_none(pxp);
-    if (pg > 0 && px.world == 0)
-        return pick_nj(I, [&](auto nj) {
-            int grid = pg < (N + R - 1) / R ? pg : (N + R - 1) / R;
-            hipLaunchKernelGGL((k_dec_down_p<decltype(nj)::value, R>), dim3(grid), dim3(256), 0, st, hbuf, route, W2, N, I, out);
-            return 0;
-        });
     return pick_nj(I, [&](auto nj) {
         hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
                            W2, N, I, out, px);
@@ -1384,27 +997,6 @@ int vhk_decb_attn(hipStream_t st, const VhDecBatchAttn& bt, int n, float* kcache
     hipLaunchKernelGGL(k_decb_attn, dim3(nkv, ms, n), dim3(256), 0, st, bt, kcache, vcache, rope_cos, rope_sin, nq, nkv,
                        max_ctx, max_splits, scale);
     return 0;
-}
-int vhk_decb_gateup(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* Wg, int E,
-                    const uint16_t* W1, const uint16_t* W3, int I, int K, const VhDecBatchRoute& rt) {
-    constexpr int RP = 4;
-    if (bt.n < 1 || bt.n > VH_BMAX || E > 8 || E < 2 || I % RP != 0) return -1;
-    int grid = vh_tuning()->gateup_grid;
-    if (grid <= 0) grid = 2 * vh_num_cus();
-    return pick_nj(K, [&](auto nj) {
-        constexpr int NJ = decltype(nj)::value;
-        if (NJ > 2) return -1;
-        hipLaunchKernelGGL((k_decb_gateup<(NJ > 2 ? 2 : NJ), RP>), dim3(grid), dim3(256), 0, st, bt, norm_w, eps, Wg, E, W1, W3, I, K, rt);
-        return 0;
-    });
-}
-int vhk_decb_down(hipStream_t st, const VhDecBatchRoute& rt, int n, const uint16_t* W2, int N, int I, const VhDecBatchOut& ot) {
-    constexpr int R = 2;
-    if (n < 1 || n > VH_BMAX) return -1;
-    return pick_nj(I, [&](auto nj) {
-        hipLaunchKernelGGL((k_decb_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, rt, n, W2, N, I, ot);
-        return 0;
-    });
 }
 int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int V, int K,
                     const VhDecBatchHead& hd, int grid, int v0) {

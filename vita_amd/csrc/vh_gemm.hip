@@ -365,8 +365,7 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     }
     const dim3 grid_glu(((a.N + 63) / 64) * g.mt_slots), grid(((a.N + GM_BN - 1) / GM_BN) * g.mt_slots, ksp);
     // two K-tiles in flight pays for the small plain GEMMs (encoders: -5..-9 %), not for the grouped ones (+-0)
-    const int pf = vh_tuning()->gemm_prefetch;
-    const bool pf2 = pf == 3 || (pf == 2 && a.group_off == nullptr);
+    const bool pf2 = a.group_off == nullptr;
     if (a.W_up) {
         if (pf2) hipLaunchKernelGGL((k_gemm<true, 2, 3>), grid_glu, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_gemm<true, 1, 4>), grid_glu, dim3(256), 0, st, g);

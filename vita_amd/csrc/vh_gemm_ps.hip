@@ -642,14 +642,10 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     const int groups = a.group_off ? (a.ngroups > 0 ? a.ngroups : 1) : 1;
     const int avg = (a.M + groups - 1) / groups;
     int cfg = vh_tuning()->ps_cfg;
-    if (cfg < 0 || cfg > 2) cfg = avg <= 64 ? 0 : 1;
-    int grid = vh_tuning()->ps_grid > 0 ? vh_tuning()->ps_grid : num_cus();
+    if (cfg < 0 || cfg > 1) cfg = avg <= 64 ? 0 : 1;
+    int grid = num_cus();   // persistent: one 8-wave block per CU
     grid &= ~7;
     if (grid < 8) grid = 8;
-    if (cfg == 2) {   // r03: weights straight to registers, activation ring in LDS (vh_gemm_ws.hip)
-        bool ntw = vh_tuning()->ps_nt != 0;
-        return vhk_gemm_ws(st, a, grid, ntw);
-    }
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
     // round is M-split relies on L2 for the second reader of each weight tile (gate|up: +5 % with nt)
     bool nt = vh_tuning()->ps_nt > 0;

@@ -5,45 +5,30 @@
 #include <stdint.h>
 #include <type_traits>
 
-// ---- run-time tuning knobs (set through vh_tune(); defaults are the measured-best variants) ---
+// ---- run-time tuning knobs (set through vh_tune(); defaults are the measured-best variants).  Round 4 pruned the variants that
+// had lost their measurements in rounds 1-3 (double-buffered / 2-row gate|up GEMV, persistent down projection, O-projection
+// prefetch blocks, fused attention + O-projection launch, de-duplicating batch GEMVs, the LDS-tiled fp32 attention kernel, the
+// general-kernel MoE prefill path, the register-direct streaming GEMM): DESIGN.md 6.2 and the git history are their record. ---
 struct VhTuning {
-    int gateup_variant = 0;  // k_dec_gateup: 0 = 8 rows/iter single buffer, 1 = double buffer, 2 = 4 rows/iter
-    int gemv_rows = 8;        // rows per block of the decode QKV / O GEMVs (r01: 4 won: 12.9 / 8.3 us vs 13.1 / 9.4 at 8; r02 with the
-                              // transposing block reduction 8 is ahead by 0.5 % of a token, 16 behind by 1 %)
-    int gateup_grid = 0;     // persistent grid of k_dec_gateup (0 = 1.5 blocks per CU)
-    int down_grid = 0;         // decode down projection: > 0 = that many persistent blocks keeping the activations in registers (measured
-                               // slower: 204-209 vs 211.5 tok/s), 0 = one block per row pair
-    int dec_prefetch = 0;      // decode attention launch: n prefetching blocks per CU pull the O-projection weights through the memory-side
-                               // cache while attention runs (measured: 211.5 -> 198 tok/s at 1, 199 at 2, 202 at 4: off)
     int batch_moe_min = 3;     // concurrent sequences: from this many per iteration the layer's MoE runs ONCE on the weight-streaming GEMM
                                // (S = n rows sorted by expert, every touched expert streamed once); 0 = never
-    int batch_moe = 0;         // batched decode: 1 = expert GEMVs of a group with expert de-duplication (experimental, slower at B <= 4)
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
-    int attn_wpe = 0;          // d = 64 attention: waves per SIMD the register allocation aims at; 0 = auto (fp32 kernel 3: 145 VGPRs; bf16 x 3 kernel 2: 216, no spills)
-    int attn_impl = 0;         // multi-row attention: 0 = direct-operand kernels (16 rows per wave, no LDS tiles; plain / causal on bf16 x 3 MFMAs), 1 = LDS-tiled fp32 kernel, 2 = direct-operand fp32-MFMA kernel everywhere
-    int attn_presplit = 0;     // bf16 x 3 attention: 1 = K / V converted to planes once per launch by a pre-pass (k_attn_prep) when the caller provides scratch; measured slower (ViT 66 vs 61 us, prefill 78 vs 49 us incl. the pre-pass), kept as a tested option
+    int attn_impl = 0;         // multi-row attention: 0 = bf16 x 3 MFMAs where the mask flavour allows (plain / causal), 2 = fp32-MFMA kernel everywhere
+    int attn_presplit = 0;     // bf16 x 3 attention: 1 = K / V converted to planes once per launch by a pre-pass (k_attn_prep) when the caller provides scratch
     int attn_rows = 0;         // bf16 x 3 attention at d = 64: query rows per wave, 0 = auto (32 when the launch still fills the chip), 16, 32
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
     int prefill_fuse_rows = 1; // single-rank prefill: K-split slabs summed by the consuming norm kernel (VhRowUpdate); 0 = separate slab-sum / combine launches
-    int prefill_moe_gemm = 0; // MoE prefill GEMMs: 0 = weight-streaming pre-split kernel (vh_gemm_ps, default), 1 = general kernel
-    int fuse_attn_oproj = 0;  // decode: 1 = attention + O-projection in one launch (measured 2.7 % SLOWER than two kernels)
-    int fuse_max_blocks = 0;  // tests: override the co-residency bound of the fused launch (0 = 2 per CU)
-    int gemm_prefetch = 2;    // general GEMM: 1 = one K-tile in flight, 2 = two for plain GEMMs (default), 3 = two everywhere
-    int ps_cfg = -1;          // vh_gemm_ps variant: -1 = by rows per group, 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights,
-                              // 2 = vh_gemm_ws.hip (weights straight to registers, <= 288 rows per tile)
-    int ps_grid = 0;          // vh_gemm_ps persistent grid (0 = one block per CU)
-    int ps_nt = -1;           // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
-    int tp_overlap = 1;       // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
-    int moe_ksplit = -4;      // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
-    int force_allreduce = 0; // tests: run the collective hook even when tp_world == 1
-    int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange (default),
-                               // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Measured with 2 / 4 engine processes on
-                               // one GPU (profiles/r03_tp_fuse_latency_*.json): the fused form is 0.9 / 2.0 us per exchange SLOWER (its 16
-                               // reducer blocks + counter hand-off cost more than the kernel boundary they replace); never on real links
+    int ps_cfg = -1;           // vh_gemm_ps variant: -1 = by rows per group, 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights
+    int ps_nt = -1;            // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
+    int tp_overlap = 1;        // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
+    int moe_ksplit = -4;       // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
+    int force_allreduce = 0;   // tests: run the collective hook even when tp_world == 1
+    int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange,
+                               // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Chosen at bring-up by
+                               // vita_amd.parallel (timed on the ranks' own devices; "kernel" whenever ranks share a device)
     int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
                                // fine-grained allocation fails (same-device tests); 0 = fail loudly instead
-    int ws_pad = 0;          // experiments: 64-KB units of padding in front of the engine workspace (placement sensitivity sweeps)
 };
 VhTuning* vh_tuning();
 
@@ -80,14 +65,8 @@ int vhk_dec_consumer_blocks(int which, int N, int K, int I);   // grid of a cons
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table,    // table: nullable page table of a paged KV cache (64-token pages)
-                 const void* prefetch, size_t prefetch_bytes);   // nullable: weights of the NEXT kernel, pulled through the memory-side cache by idle CUs
+                 const int* table);   // table: nullable page table of a paged KV cache (64-token pages)
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr);
-int vhk_dec_attn_oproj(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
-                       const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
-                       float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                       int* done_ctr, int done_target, int* err_flag, const uint16_t* Wo, int N, int K, float* out,
-                       const int* table);
 // ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
 #define VH_BMAX 4
 struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
@@ -100,15 +79,10 @@ struct VhDecBatchAttn {
     const float* qkv[VH_BMAX]; int pos[VH_BMAX]; const int* table[VH_BMAX];
     float* part_o[VH_BMAX]; float* part_ml[VH_BMAX]; int* cnt[VH_BMAX]; float* attn_out[VH_BMAX];
 };
-struct VhDecBatchRoute { int* route[VH_BMAX]; float* hbuf[VH_BMAX]; };
-struct VhDecBatchOut { float* out[VH_BMAX]; };
 struct VhDecBatchHead { float* logits[VH_BMAX]; float* blk_val[VH_BMAX]; int* blk_idx[VH_BMAX]; };   // logits[b]: nullable full-vocab row
 int vhk_decb_gemv(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int N, int K, int norm);
 int vhk_decb_attn(hipStream_t st, const VhDecBatchAttn& bt, int n, float* kcache, float* vcache, const float* rope_cos,
                   const float* rope_sin, int nq, int nkv, int max_ctx, int max_splits, float scale);
-int vhk_decb_gateup(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* Wg, int E,
-                    const uint16_t* W1, const uint16_t* W3, int I, int K, const VhDecBatchRoute& rt);
-int vhk_decb_down(hipStream_t st, const VhDecBatchRoute& rt, int n, const uint16_t* W2, int N, int I, const VhDecBatchOut& ot);
 int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int V, int K,
                     const VhDecBatchHead& hd, int grid, int v0);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
@@ -166,7 +140,6 @@ struct VhGemmPsArgs {
     int* nslab_out;                                          // device int: the split the kernel used (required when ksplit < 0)
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
-int vhk_gemm_ws(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt);   // vh_gemm_ws.hip (arguments already checked)
 int vhk_split_planes(hipStream_t st, const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows,
                      int cols);
 

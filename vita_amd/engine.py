@@ -152,11 +152,12 @@ class MixtralEngine:
             out = r.to(rows.device)
         return out
 
-    def prefill(self, embeds, pos0=0, want_hidden=False, want_route=False, gather_logits=True):
+    def prefill(self, embeds, pos0=0, want_hidden=False, want_route=False, gather_logits=False):
         """embeds fp32 [S, hidden] on device.  Returns (logits_of_last_pos, hidden_dbg or None); with
         want_route the per-layer top-2 expert ids [layers, S, 2] are left in self.route_ids.  Under a vocab-sharded
-        head the returned row is all-reduced over the ranks (a collective call on every rank); gather_logits=False returns
-        this rank's raw row (its vocabulary slice, zeros elsewhere) without a collective."""
+        head the returned row is this rank's raw row (its vocabulary slice, zeros elsewhere) and the call has NO
+        collective in it — generate() and the bench only need the token the engine already selected; gather_logits=True
+        all-reduces the row over the ranks (then EVERY rank must make the same call; needs torch.distributed)."""
         if embeds.dtype != torch.float32 or not embeds.is_cuda:
             raise TypeError("embeds must be a float32 GPU tensor")
         embeds = embeds.contiguous()

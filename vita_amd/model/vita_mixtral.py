@@ -198,7 +198,7 @@ class VITAMixtralForCausalLM(_HipModule):
         if inputs_embeds is None:
             _, _, _, _, inputs_embeds, _ = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, past_key_values, labels, images, audios)
-        logits, _ = self.engine.prefill(inputs_embeds[0].to(torch.float32))
+        logits, _ = self.engine.prefill(inputs_embeds[0].to(torch.float32), gather_logits=True)   # full row (collective under a sharded head)
         return SimpleNamespace(logits=logits[None, None, :], past_key_values=self.engine)
 
     @torch.no_grad()
