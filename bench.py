@@ -119,13 +119,22 @@ class _BenchTokenizer:
         return [" ".join("</s>" if int(t) == 2 else f"w{int(t)}" for t in row) for row in ids.tolist()]
 
 
-TRAFFIC_FILES = ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+TRAFFIC_FILES = ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
 
 
-def traffic_source():
+def traffic_source(kernel=None):
     for name in TRAFFIC_FILES:
-        if os.path.exists(os.path.join(ROOT, "profiles", name)):
-            return "profiles/" + name
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        if kernel is not None:
+            try:
+                with open(path) as f:
+                    if kernel not in json.load(f):
+                        continue
+            except Exception:
+                continue
+        return "profiles/" + name
     return None
 
 
@@ -140,6 +149,29 @@ def pmc_traffic(kernel):
         except Exception:
             continue
     return None
+
+
+PREFILL_KERNEL_KEY = "k_gemm_ps_moe_gateup (prefill S=552)"     # key of the PMC traffic files (profiles/make_traffic_json.py)
+
+
+def prefill_kernel_roofline(S, E, I_r, H, layers, total_ms, samples, world=1):
+    """`roofline_prefill` of the bench line: the dominant PREFILL kernel (MoE gate|up grouped GEMM + SiLU*up) against the HBM
+    roofline, from live HIP events around its launches (vh_mixtral_profile with a negative stride).  Algorithmic bytes of one
+    launch = the gate and up weights of every expert once (all experts are touched at S >> 8) + the bf16 hi / lo planes of the
+    S normed rows once + the hi / lo planes of h (2 S rows x I) written once; re-reads through L2 are not algorithmic."""
+    nbytes = int(2 * E * I_r * H * 2 + S * H * 4 + 2 * S * I_r * 4)
+    us = total_ms * 1e3 / samples if samples else None
+    ach = nbytes / (us * 1e-6) / 1e9 if us else None
+    one_gpu = world == 1
+    return {"bound": "hbm", "kernel": "k_gemm_ps<GLU> (MoE gate|up grouped GEMM + SiLU*up, all experts)",
+            "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "bytes_per_launch": nbytes, "avg_launch_us": round(us, 2) if us else None, "samples": int(samples),
+            "launches_per_prefill": int(layers),
+            # exact mode: 2 bf16 MFMAs per weight fragment (hi + lo planes) -> 2 x (2 S rows x 2 I x H MACs) x 2 FLOP at 2.5 PF dense
+            "mfma_floor_us": round(2 * 2 * (2 * S) * (2 * I_r) * H / 2.5e15 * 1e6, 1),
+            "traffic": pmc_traffic(PREFILL_KERNEL_KEY) if one_gpu else None,
+            "traffic_source": traffic_source(PREFILL_KERNEL_KEY) if one_gpu else None}
 
 
 def native_rccl_or_fallback(eng, rank, dist, dev, backend, timeout_s=180):
@@ -364,8 +396,8 @@ def main():
     eng = model.engine
     collective = "none"
     if world > 1:
-        from vita_amd.parallel import setup_tensor_parallel
-        collective = setup_tensor_parallel(eng, rank, world, dev, backend=args.backend, collective=args.collective)
+        from vita_amd.parallel import collective_label, setup_tensor_parallel
+        collective = collective_label(eng, setup_tensor_parallel(eng, rank, world, dev, backend=args.backend, collective=args.collective))
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
@@ -418,6 +450,14 @@ def main():
         gpu_state.stop()
         buf = gpu_state.samples["prefill_steady"]
         del buf[:len(buf) // 2]
+    # the dominant PREFILL kernel (MoE gate|up grouped GEMM), timed live with HIP events the engine records on its own stream
+    # around each of the layers' launches (the prefill half of the metric recomputable from this line alone)
+    eng.profile(stride=-1, max_samples=4 * t.num_hidden_layers + 8)
+    for _ in range(3):
+        eng.prefill(emb_last)
+    torch.cuda.synchronize()
+    pf_ms, pf_n = eng.profile_read()
+    eng.profile(stride=0)
     phase = {k: float(np.median([r[k] for r in runs])) for k in ("vit_proj_ms", "audio_ms", "prefill_ms")}
     phase_min = {k: float(min(r[k] for r in runs)) for k in ("vit_proj_ms", "audio_ms", "prefill_ms")}
     assert runs[-1]["n_audio_tokens"] == n_aud_tok                     # the last run's KV cache feeds the decode below
@@ -524,6 +564,7 @@ def main():
                                                     t.num_local_experts * 3 * I_r * t.hidden_size)
                         + 2 * packed["lm_head"].numel())               # all experts are touched at S >> 8
 
+    rf_prefill = prefill_kernel_roofline(int(S), t.num_local_experts, I_r, t.hidden_size, t.num_hidden_layers, pf_ms, pf_n, world)
     if rank == 0:
         out = {
             "metric": "decode_tokens_per_s", "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world,
@@ -555,6 +596,7 @@ def main():
                          "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None,
                          "traffic_source": (f"{traffic_source()} (static: rocprofv3 --pmc FETCH_SIZE pass of this kernel, "
                                             "counters cannot be read inside this process)") if world == 1 else None},
+            "roofline_prefill": rf_prefill,
             "gpu_state": gpu_state.summary(),
             "build_s": round(t_build, 1),
         }

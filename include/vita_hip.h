@@ -315,8 +315,9 @@ int vh_attn_decode(const float* qkv, float* kcache, float* vcache, int pos, cons
 int vh_lmhead_argmax(const float* x, const float* delta, const float* norm_w, float eps, const uint16_t* W, int V, int H,
                      float* logits, int* token_out, float* blk_val, int* blk_idx, int nblk, void* stream);
 
-/* Live HIP-event timing of the dominant decode kernel (gate|up expert GEMV): sample one launch
- * every `stride` layers (0 = off), up to max_samples; read returns summed ms and sample count. */
+/* Live HIP-event timing of the dominant kernel of a phase, on the stream the engine launches it on: stride > 0 samples the
+ * DECODE gate|up expert GEMV of every stride-th layer, stride < 0 the PREFILL gate|up grouped GEMM of every |stride|-th layer
+ * (0 = off), up to max_samples launches; read returns summed ms and sample count and clears the samples. */
 int vh_mixtral_profile(vh_mixtral_t* m, int stride, int max_samples);
 int vh_mixtral_profile_read(vh_mixtral_t* m, double* total_ms /* host */, int* count /* host */);
 

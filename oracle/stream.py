@@ -63,9 +63,11 @@ def embed_rows(t, ids, seed):
     return out
 
 
-def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=False):
+def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=False, margins=False):
     """One causal forward over embeds [S, H] (positions 0..S-1) through layers 0..n_layers-1 + final norm + LM head.
-    Returns dict(logits [S - logits_from, V], hidden {layer: [S, H]}, route [n_layers, S, 2] int32)."""
+    Returns dict(logits [S - logits_from, V], hidden {layer: [S, H]}, route [n_layers, S, 2] int32); margins=True adds
+    margin [n_layers, S]: the router-logit distance between the 2nd and the 3rd expert (how far each top-2 decision is
+    from flipping)."""
     n_layers = t.num_hidden_layers if n_layers is None else n_layers
     S = embeds.shape[0]
     d, nq, nkv = t.head_dim, t.num_attention_heads, t.num_key_value_heads
@@ -73,6 +75,7 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
     bufs = LayerBuffers(t)
     x = embeds.astype(F32)
     hidden, route = {}, np.empty((n_layers, S, 2), np.int32)
+    margin = np.empty((n_layers, S), F32) if margins else None
     for l in range(n_layers):
         t0 = time.time()
         L = bufs.load(t, l, seed)
@@ -87,6 +90,9 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
         xn = om.rmsnorm(x, L["ln2"], t.rms_norm_eps)
         y, idx, _ = om.moe(xn, L, t.num_experts_per_tok)
         route[l] = idx
+        if margins:
+            rl = np.sort((xn @ L["gate"].T).astype(F32), axis=-1)
+            margin[l] = rl[:, -2] - rl[:, -3]
         x = (x + y).astype(F32)
         if l in capture:
             hidden[l] = x.copy()
@@ -95,4 +101,7 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
     norm = np.ones(t.hidden_size, F32)
     lm = hashw.fill((t.vocab_size, t.hidden_size), hashw.tensor_seed("lm_head.weight", seed))
     logits = (om.rmsnorm(x[logits_from:], norm, t.rms_norm_eps) @ lm.T).astype(F32)
-    return dict(logits=logits, hidden=hidden, route=route)
+    out = dict(logits=logits, hidden=hidden, route=route)
+    if margins:
+        out["margin"] = margin
+    return out

@@ -25,6 +25,22 @@ def test_pmc_traffic_reads_committed_profile():
     assert bench.pmc_traffic("no_such_kernel") is None
 
 
+def test_prefill_kernel_roofline_field():
+    """the bench line carries a kernel-level PREFILL roofline (`roofline_prefill`) that can be recomputed from
+    its own fields: achieved = bytes_per_launch / avg_launch_us, frac = achieved / peak, traffic from the committed PMC pass."""
+    import bench
+    S, E, I, H, L = 552, 8, 14336, 4096, 32
+    r = bench.prefill_kernel_roofline(S, E, I, H, L, total_ms=96 * 0.6, samples=96)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS and "k_gemm_ps" in r["kernel"]
+    assert r["bytes_per_launch"] == 2 * E * I * H * 2 + S * H * 4 + 2 * S * I * 4 and r["launches_per_prefill"] == L
+    assert abs(r["avg_launch_us"] - 600.0) < 1e-6 and r["samples"] == 96
+    assert abs(r["achieved"] - r["bytes_per_launch"] / 600e-6 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
+    assert 0.2 < r["frac"] < 1.0 and 150 < r["mfma_floor_us"] < 250
+    assert r["traffic"] is not None and 0.9 < r["traffic"] / (2 * E * I * H * 2) < 1.3 and r["traffic_source"].startswith("profiles/")
+    assert bench.prefill_kernel_roofline(S, E, I // 8, H, L, 0.0, 0, world=8)["traffic"] is None      # TP: no static traffic figure
+    assert bench.prefill_kernel_roofline(S, E, I, H, L, 0.0, 0)["achieved"] is None                   # no samples -> no claim
+
+
 # ---- N>1 bring-up: every rank must reach the SAME decision about the native RCCL communicator -----------------
 class _FakeEngine:
     def __init__(self, fail):

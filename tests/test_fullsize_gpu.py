@@ -55,37 +55,48 @@ def test_decode_step_equals_prefill_row(full, dev):
         assert int(lg.argmax()) == toks[i]
 
 
+CHUNK_PROMPT_SEED = 1      # chosen by profiles/pick_chunk_prompt.py (see the docstring below)
+
+
 def test_chunked_prefill_equals_one_shot(full, dev):
-    """pos0 > 0 with KV-cache append against the one-shot prefill of the same 150 tokens.  The two schedules are not the same
-    arithmetic: the K split of the projections / expert GEMMs is chosen on the device from the row count, so slabs are summed in
-    a different order (1e-5 per layer), and a 32-layer top-2 router is discontinuous — ONE near-tied decision that flips moves
-    the logits by 1e-2 (seen in r03: 9.2e-3 from this prompt once the attention rounding changed).  So the routing decisions of
-    both runs are compared: every layer up to the first differing decision must agree tightly (that is the chunking logic:
-    positions, KV append, causal offset), flips must be rare, and the logits bar applies whenever no decision flipped."""
+    """pos0 > 0 with KV-cache append (the reference's cache-suffix cropping, vita/model/language_model/vita_mixtral.py:291-382;
+    what the serving recompute uses: vita_amd/serving.py) against the ONE-SHOT prefill of the same 150 tokens AND against the
+    layer-streamed fp32 oracle (oracle/stream.py) at all 32 layers: BOTH HIP schedules must give the oracle's last-row logits
+    within 1e-3 and its argmax (north-star bar), and the oracle's router decisions on every row they computed.
+    The two schedules are not the same arithmetic (the K split of the projections / expert GEMMs is chosen on the device from
+    the row count, so slabs are summed in another order: ~1e-5 per layer), and a 32-layer top-2 router is discontinuous: a
+    near-tied decision that flips in one schedule moves its logits by ~1e-2 (r03: 9.2e-3 on the prompt of seed 1 of that
+    round's generator).  So the prompt is CHOSEN: profiles/pick_chunk_prompt.py runs the oracle over candidate prompts and
+    prints each one's smallest router margin (logit distance between the 2nd and 3rd expert over all 4800 decisions); the
+    test uses a candidate whose margin clears the schedule-to-schedule noise, prints both numbers, and keeps the logits bar."""
+    from oracle import stream
     cfg, packed, eng = full
-    L = cfg.text.num_hidden_layers
-    rng = np.random.default_rng(1)
-    ids = rng.integers(3, cfg.text.vocab_size, size=150).tolist()
+    t, L = cfg.text, cfg.text.num_hidden_layers
+    ids = np.random.default_rng(CHUNK_PROMPT_SEED).integers(3, t.vocab_size, size=150).tolist()
     one, h1 = eng.prefill(_emb(packed, ids, dev), want_hidden=True, want_route=True)
-    one, h1, r1 = one.clone(), h1[:, 83:].clone(), eng.route_ids[:, 83:].clone()
+    one, h1, r1 = one.clone(), h1.clone(), eng.route_ids.clone()
     eng.prefill(_emb(packed, ids[:83], dev))
     two, h2 = eng.prefill(_emb(packed, ids[83:], dev), pos0=83, want_hidden=True, want_route=True)
-    r2 = eng.route_ids
+    r2 = eng.route_ids.clone()
     torch.cuda.synchronize()
-    flipped = (torch.sort(r1, -1).values != torch.sort(r2, -1).values).any(-1)          # [layers, 67]
-    layers_hit = torch.nonzero(flipped.any(-1)).flatten().tolist()
-    first = layers_hit[0] if layers_hit else L
-    n_flip = int(flipped.sum())
-    err = float((one - two).abs().max())
-    print(f"max|one-shot - chunked| = {err:.2e}; router decisions that differ: {n_flip} of {flipped.numel()}, first at layer {first if layers_hit else None}")
-    for l in range(first):
-        scale = max(1.0, float(h1[l].abs().max()))
-        e = float((h1[l] - h2[l]).abs().max())
-        assert e < 1e-3 * scale, f"hidden states after layer {l} differ by {e:.2e} before any routing decision does"
-    n_first = int(flipped[first].sum()) if layers_hit else 0      # later layers see the consequences of the first flip
-    assert first >= 2 and n_first <= 2, "chunked and one-shot prefill route differently early or often: not a near-tie effect"
-    if not layers_hit:
-        assert err < TOL and int(one.argmax()) == int(two.argmax())
+    ref = stream.forward(t, 0, stream.embed_rows(t, ids, 0), n_layers=L, capture=(L - 1,), logits_from=149, margins=True)
+    ref_lg = ref["logits"][0]
+    margin = ref["margin"]                                         # [L, 150] logit distance 2nd - 3rd expert
+    print(f"oracle: smallest router margin {margin.min():.3e} (layer {int(margin.min(1).argmin())}), over the chunk's rows "
+          f"{margin[:, 83:].min():.3e}; last-row logit gap top1 - top2 {np.sort(ref_lg)[-1] - np.sort(ref_lg)[-2]:.3e}")
+    r_ref = np.sort(ref["route"], -1)
+    e12 = float((one - two).abs().max())
+    hdiff = max(float((h1[l][83:] - h2[l]).abs().max()) / max(1.0, float(h1[l].abs().max())) for l in range(L))
+    print(f"one-shot vs chunked: max |logit diff| {e12:.2e}, worst hidden-state difference {hdiff:.2e} of the layer's scale")
+    for name, lg, rt, rows in (("one-shot", one, r1, slice(0, 150)), ("chunked (83 + 67, pos0 = 83)", two, r2, slice(83, 150))):
+        d = np.sort(rt.cpu().numpy(), -1) != r_ref[:, rows]
+        err = float(np.abs(lg.cpu().numpy() - ref_lg).max())
+        print(f"{name}: max |logits - oracle| {err:.2e}, argmax {int(lg.argmax())} vs {int(ref_lg.argmax())}, "
+              f"router decisions differing from the oracle's: {int(d.any(-1).sum())} of {d.shape[0] * d.shape[1]}")
+        assert not d.any(), f"{name}: router decisions differ from the oracle's at (layer, row) {np.argwhere(d.any(-1))[:4].tolist()}"
+        assert err < TOL, f"{name}: logits {err:.2e} from the fp32 oracle"
+        assert int(lg.argmax()) == int(ref_lg.argmax())
+    assert e12 < TOL and int(one.argmax()) == int(two.argmax())
 
 
 def test_deterministic_and_batched_steps(full, dev):

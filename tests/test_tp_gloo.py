@@ -139,3 +139,54 @@ def test_vocab_shards_cover_the_table():
         rows = [vocab_shard(V, r, world) for r in range(world)]
         assert rows[0][0] == 0 and sum(n for _, n in rows) == V
         assert all(rows[r][0] + rows[r][1] == rows[r + 1][0] for r in range(world - 1))
+
+
+def _vote_worker(rank, world, port, ret):
+    """each rank brings DIFFERENT local measurements; the vote must come out the same on both (MAX-reduced times, any bad
+    trial or a shared device forces "kernel")."""
+    from vita_amd.parallel import collective_label, vote_decode_exchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cases = {
+            # name: (same_device, t_kernel per rank, t_fused per rank, fused_ok per rank)
+            "fused_wins": (False, (40.0, 41.0), (33.0, 34.0), (True, True)),
+            "fused_slower_on_one_rank": (False, (40.0, 40.0), (30.0, 45.0), (True, True)),   # slowest rank decides
+            "within_margin": (False, (40.0, 40.0), (39.5, 39.7), (True, True)),              # < 2 % better: keep the kernel form
+            "one_rank_timed_out": (False, (40.0, 40.0), (20.0, 20.0), (True, False)),
+            "shared_device": (True, (40.0, 40.0), (10.0, 10.0), (True, True)),
+            "shared_on_one_rank_only": (rank == 1, (40.0, 40.0), (10.0, 10.0), (True, True)),  # a disagreeing flag is still "shared"
+            "no_timing": (False, (0.0, 0.0), (0.0, 0.0), (True, True)),
+        }
+        out = {}
+        for name, (same, tk, tf, ok) in cases.items():
+            same_flag = same if isinstance(same, bool) else bool(same)
+            choice, tk_all, tf_all = vote_decode_exchange(dist, same_flag, tk[rank], tf[rank], ok[rank])
+            out[name] = (choice, tk_all, tf_all)
+        ret[rank] = out
+
+        class E:
+            decode_exchange = out["fused_wins"][0]
+        ret[f"label{rank}"] = (collective_label(E(), "ipc"), collective_label(E(), "rccl"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_decode_exchange_vote_is_rank_consistent():
+    """the ranks agree on the batch-1 decode exchange form from their own timings; ranks on one device always
+    get the kernel form."""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_vote_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        a, b = ret[0], ret[1]
+        assert a == b                                            # same choice AND same reduced numbers on every rank
+        assert a["fused_wins"] == ("fused", 41.0, 34.0)
+        assert a["fused_slower_on_one_rank"][0] == "kernel"
+        assert a["within_margin"][0] == "kernel"
+        assert a["one_rank_timed_out"][0] == "kernel"
+        assert a["shared_device"][0] == "kernel" and a["shared_on_one_rank_only"][0] == "kernel"
+        assert a["no_timing"][0] == "kernel"
+        assert ret["label0"] == ret["label1"] == ("ipc+fused", "rccl")

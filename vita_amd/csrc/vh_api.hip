@@ -811,7 +811,10 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             g.W = w.w1; g.W_up = w.w3; g.ldw = H; g.w_group_stride = (long)I * H;
             g.group_off = m->pgoff; g.ngroups = E;
             g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * Sn; g.N = I; g.K = H; g.ksplit = 1;
+            const bool prof = m->prof_stride < 0 && (l % -m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+            if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
             VH_TRY(vhk_gemm_ps(st, g), "gate/up gemm");
+            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             nslab = vh_tuning()->moe_ksplit;           // < 0: chosen by the kernel from the expert sizes (up to -n)
             if (nslab == 0) nslab = 1;
             if (nslab > 4) nslab = 4;

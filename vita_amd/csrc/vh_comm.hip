@@ -14,10 +14,14 @@
 // visible to a spinning kernel; they are double-buffered by epoch parity: rank A can only overwrite the slot of epoch
 // e at epoch e+2, which it reaches only after receiving B's epoch e+1 data, i.e. after B finished reading epoch e.
 //   one-shot  (count <= VH_COMM_ONESHOT_MAX): 7 remote stores + 8 local polls per element, one exchange.
-//   two-shot  (larger, the prefill messages): reduce-scatter — rank r pushes slice s of its vector to slice owner s,
+//   bulk      (larger, the prefill messages; r04): reduce-scatter — rank r pushes slice s of its vector to slice owner s,
 //             the owner sums the world contributions in rank order — then all-gather — the owner pushes the reduced
-//             slice to every rank.  1.75 N granules per rank instead of 7 N, spread over all 7 links at once
-//             (a ring moves 2 (W-1)/W N over ONE link per direction).
+//             slice to every rank: 2 (W-1)/W N elements per rank spread over all 7 links at once (a ring moves the same
+//             over ONE link per direction).  At these sizes (4.5 / 9 MB) the links' BYTES are the cost, so the payload
+//             travels as plain fp32 in 16-KB chunks with ONE flag per chunk (16-byte stores -> every wave drains ->
+//             one system-scope release -> relaxed flag store; the reader polls the flag, one system-scope acquire, plain
+//             loads: guide G16 R1) — half the bytes of r01-r03's granule form of the same schedule, which paid 8 bytes
+//             per value to save a flag round trip that does not matter here.
 // Every spin is bounded; a time-out sets the error word read by vh_comm_status().  Bring-up (vita_amd/parallel.py)
 // self-tests the path against torch.distributed before it is used and falls back to RCCL otherwise.
 #include <stdio.h>
@@ -34,7 +38,9 @@
 struct vh_comm {
     int rank, world;
     size_t cap;                              // fp32 elements per all-reduce
-    size_t region;                           // granules per parity region
+    size_t region;                           // 8-byte units per parity region: one-shot granule slots, then the bulk area
+    size_t oneshot_units;                    // size of the one-shot part (even)
+    int maxchunk;                            // flag words per rank row of the bulk area
     uint64_t* local;                         // [2 parity][region] granules, fine-grained
     uint64_t* peer[VH_COMM_MAX_WORLD];       // every rank's buffer as mapped here (peer[rank] == local)
     bool opened[VH_COMM_MAX_WORLD];
@@ -93,26 +99,105 @@ __global__ __launch_bounds__(256) void k_ar_oneshot(float* __restrict__ buf, lon
     }
 }
 
-// two-shot: region A (contributions) = [src rank][slice elements] at offset 0, region B (reduced slices) = [element] at
-// offset world * slice.  slice = ceil(count / world) elements, slice s owned by rank s.
-__global__ __launch_bounds__(256) void k_ar_twoshot(float* __restrict__ buf, long count, Peers peers, uint64_t* local,
-                                                    long slice, int rank, int world, uint32_t tag, int* err) {
-    const long nthr = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    // 1. push my contribution to every slice's owner
-    for (long i = t0; i < count; i += nthr) {
-        const int s = (int)(i / slice);
-        put(peers.p[s] + (size_t)rank * slice + (i - (long)s * slice), tag, buf[i]);
+// ---- bulk path ---------------------------------------------------------------------------------------------------------
+// slice = elements owned by one rank (multiple of 4), cut into nchunk chunks of VH_COMM_CHUNK elements (the last one short).
+// The bulk area of a parity region starts BEHIND the one-shot slots (a payload word can never be read as a granule), and its
+// flag words sit at FIXED positions in front of the payload (a flag word only ever holds flags: tags of earlier calls), in
+// 8-byte units from the region start: FA = flags [src rank][maxchunk] at offFA ("rank r's contribution to chunk k of MY
+// slice is complete"), FB = flags [owner][maxchunk] at offFB ("owner s's reduced chunk k is complete"), A = contributions
+// [src rank][slice_pad] fp32 at offA, B = reduced slices [owner][slice_pad] fp32 at offB.  A flag holds the call's tag.
+#define VH_COMM_CHUNK 4096
+struct BulkGeom { long slice, slice_pad; int nchunk, maxchunk; size_t offFA, offFB, offA, offB; };
+
+__device__ __forceinline__ void flag_set(uint64_t* f, uint32_t tag) {
+    __hip_atomic_store(reinterpret_cast<u64*>(f), (u64)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void flag_wait(const uint64_t* f, uint32_t tag, int* err, int code) {
+    unsigned spins = 0;
+    for (;;) {
+        if ((uint32_t)__hip_atomic_load(reinterpret_cast<const u64*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == tag) return;
+        if ((spins & 1023u) == 1023u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (++spins > VH_COMM_SPIN_LIMIT) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        __builtin_amdgcn_s_sleep(2);
     }
-    // 2. reduce the slice I own (rank order) and push the result to every rank
-    const long lo = (long)rank * slice, n_own = min(slice, count - lo);
-    uint64_t* const bofs = nullptr; (void)bofs;
-    for (long j = t0; j < n_own; j += nthr) {
-        float s = 0.f;
-        for (int r = 0; r < world; ++r) s += get(local + (size_t)r * slice + j, tag, err, 2);
-        for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)world * slice + lo + j, tag, s);
+}
+// every storing wave has drained, then ONE lane releases at system scope and raises the flag(s) (guide G16 R1 / pitfall 12:
+// the asm wait after the fence is what the compiler cannot drop)
+__device__ __forceinline__ void publish_begin() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // 3. collect every reduced slice
-    for (long i = t0; i < count; i += nthr) buf[i] = get(local + (size_t)world * slice + i, tag, err, 3);
+}
+__device__ __forceinline__ void consume_begin() {      // after the polling lanes saw their flags
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+}
+// n fp32 from src to dst, both 16-byte aligned at element 0 (slices and chunks are multiples of 4 elements)
+__device__ __forceinline__ void copy_f32(float* __restrict__ dst, const float* __restrict__ src, long n, bool vec) {
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    } else {
+        for (long i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ar_bulk(float* __restrict__ buf, long count, Peers peers, uint64_t* local, BulkGeom g,
+                                                 int rank, int world, uint32_t tag, int* err, int vec) {
+    const int items = world * g.nchunk;
+    auto live = [&](int s, int k) { return (long)s * g.slice + (long)k * VH_COMM_CHUNK < min(count, (long)(s + 1) * g.slice); };
+    auto len = [&](int s, int k) { return min(min(count, (long)(s + 1) * g.slice) - ((long)s * g.slice + (long)k * VH_COMM_CHUNK), (long)VH_COMM_CHUNK); };
+    // 1. my contribution to every chunk of every slice -> its owner (consecutive blocks address different owners / links)
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int s = item % world, k = item / world;
+        if (!live(s, k)) continue;                                   // block-uniform
+        float* dst = reinterpret_cast<float*>(peers.p[s] + g.offA) + (size_t)rank * g.slice_pad + (size_t)k * VH_COMM_CHUNK;
+        copy_f32(dst, buf + (size_t)s * g.slice + (size_t)k * VH_COMM_CHUNK, len(s, k), vec != 0);
+        publish_begin();
+        if (threadIdx.x == 0) flag_set(peers.p[s] + g.offFA + (size_t)rank * g.maxchunk + k, tag);
+    }
+    // 2. the chunks of MY slice: sum the world contributions in rank order, push the result to every rank
+    for (int k = blockIdx.x; k < g.nchunk; k += gridDim.x) {
+        if (!live(rank, k)) continue;
+        const long n = len(rank, k);
+        if ((int)threadIdx.x < world) flag_wait(local + g.offFA + (size_t)threadIdx.x * g.maxchunk + k, tag, err, 2);
+        consume_begin();
+        const float* A = reinterpret_cast<const float*>(local + g.offA) + (size_t)k * VH_COMM_CHUNK;
+        const size_t bo = (size_t)rank * g.slice_pad + (size_t)k * VH_COMM_CHUNK;
+        for (long i = (long)threadIdx.x * 4; i < n; i += (long)blockDim.x * 4) {
+            if (i + 4 <= n) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < world; ++r) acc += *reinterpret_cast<const f32x4*>(A + (size_t)r * g.slice_pad + i);
+                for (int p = 0; p < world; ++p)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(peers.p[p] + g.offB) + bo + i) = acc;
+            } else {
+                for (long j = i; j < n; ++j) {
+                    float acc = 0.f;
+                    for (int r = 0; r < world; ++r) acc += A[(size_t)r * g.slice_pad + j];
+                    for (int p = 0; p < world; ++p) (reinterpret_cast<float*>(peers.p[p] + g.offB) + bo)[j] = acc;
+                }
+            }
+        }
+        publish_begin();
+        if ((int)threadIdx.x < world) {
+            // (lane 0 released; the other flag-writing lanes of wave 0 run after it in program order of the same wave)
+            flag_set(peers.p[threadIdx.x] + g.offFB + (size_t)rank * g.maxchunk + k, tag);
+        }
+    }
+    // 3. collect every reduced chunk
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int s = item % world, k = item / world;
+        if (!live(s, k)) continue;
+        if (threadIdx.x == 0) flag_wait(local + g.offFB + (size_t)s * g.maxchunk + k, tag, err, 3);
+        consume_begin();
+        copy_f32(buf + (size_t)s * g.slice + (size_t)k * VH_COMM_CHUNK,
+                 reinterpret_cast<const float*>(local + g.offB) + (size_t)s * g.slice_pad + (size_t)k * VH_COMM_CHUNK, len(s, k), vec != 0);
+    }
 }
 
 // all ranks have reached this point of their streams: rank r raises row[r] in every peer's barrier row, then waits for all
@@ -165,10 +250,12 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     }
     vh_comm* c = new vh_comm{};
     c->rank = rank; c->world = world; c->cap = cap_elems;
-    // one-shot needs world * cap granules; two-shot world * slice (contributions) + count (reduced) <= 2 * cap + world
-    const size_t oneshot = (size_t)world * (cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX);
-    const size_t twoshot = 2 * cap_elems + 2 * (size_t)world;
-    c->region = oneshot > twoshot ? oneshot : twoshot;
+    // one-shot needs world * cap granules; bulk (8-byte units): A and B of world * slice_pad fp32 each + two flag arrays
+    c->oneshot_units = ((size_t)world * (cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX) + 1) & ~size_t(1);
+    c->maxchunk = (int)(cap_elems / ((size_t)world * VH_COMM_CHUNK)) + 2;
+    const size_t pad_elems = cap_elems + (size_t)world * (VH_COMM_CHUNK + 4);                 // world * slice_pad at count = cap
+    const size_t bulk = cap_elems > VH_COMM_ONESHOT_MAX ? 2 * (size_t)world * c->maxchunk + pad_elems + 2 : 0;
+    c->region = (c->oneshot_units + bulk + 1) & ~size_t(1);       // even: both parity regions start on 16-byte boundaries
     const size_t bytes = (2 * c->region + 2 * VH_COMM_MAX_WORLD) * sizeof(uint64_t);
     hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->local), bytes, hipDeviceMallocFinegrained);
     c->fine_grained = e == hipSuccess;
@@ -251,11 +338,21 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
         hipLaunchKernelGGL(k_ar_oneshot, dim3(grid), dim3(256), 0, st, buf, count, peers, local, cap1, c->rank, c->world,
                            tag, c->err);
     } else {
-        const long slice = (count + c->world - 1) / c->world;
-        long g = (count + 255) / 256;
-        if (g > 128) g = 128;                              // fully resident next to the compute stream's kernels
-        hipLaunchKernelGGL(k_ar_twoshot, dim3((int)g), dim3(256), 0, st, buf, count, peers, local, slice, c->rank, c->world,
-                           tag, c->err);
+        BulkGeom g{};
+        g.slice = (((count + c->world - 1) / c->world) + 3) & ~3L;         // multiple of 4: chunks start on 16-byte boundaries
+        g.nchunk = (int)((g.slice + VH_COMM_CHUNK - 1) / VH_COMM_CHUNK);
+        g.slice_pad = (long)g.nchunk * VH_COMM_CHUNK;
+        g.maxchunk = c->maxchunk;
+        g.offFA = c->oneshot_units;
+        g.offFB = g.offFA + (size_t)c->world * g.maxchunk;
+        g.offA = g.offFB + (size_t)c->world * g.maxchunk;                  // even: payload rows start on 16-byte boundaries
+        g.offB = g.offA + ((size_t)c->world * g.slice_pad) / 2;            // fp32 pairs per 8-byte unit
+        if (g.nchunk > g.maxchunk || g.offB + ((size_t)c->world * g.slice_pad) / 2 > c->region)
+            return cfail(VH_E_SHAPE, "vh_comm_allreduce: bulk layout above the region");
+        int grid = c->world * g.nchunk;
+        if (grid > 128) grid = 128;                        // fully resident next to the compute stream's kernels
+        const int vec = (reinterpret_cast<uintptr_t>(buf) & 15) == 0 ? 1 : 0;
+        hipLaunchKernelGGL(k_ar_bulk, dim3(grid), dim3(256), 0, st, buf, count, peers, local, g, c->rank, c->world, tag, c->err, vec);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cfail(VH_E_HIP, "vh_comm_allreduce: launch", e);
@@ -305,7 +402,7 @@ int vh_comm_status(vh_comm_t* c) {
     if (!c) return -1;
     int v = 0;
     if (hipMemcpy(&v, c->err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;   // 0 = no spin ever timed out; 1 / 2 / 3 = phase that did
+    return v;   // 0 = no spin ever timed out; 1 = one-shot, 2 / 3 = bulk reduce / gather phase, 4 = barrier, 5 / 6 = fused exchange
 }
 
 void vh_comm_destroy(vh_comm_t* c) {

@@ -69,6 +69,7 @@ class MixtralEngine:
             check(-1, "vh_mixtral_create")
         self._ar_cb = None
         self._comm = None
+        self.decode_exchange = "kernel"     # form of the batch-1 TP exchange under the IPC transport (vita_amd.parallel votes)
         self._tok_ptr = self.lib.vh_mixtral_tokens(self.h)
         self._cnt_ptr = self.lib.vh_mixtral_counters(self.h)
         self._logit_ptr = self.lib.vh_mixtral_logits(self.h)

@@ -105,10 +105,25 @@ class VITAMixtralForCausalLM(_HipModule):
             cap = int(free * float(gpu_memory_utilization or 0.8)) // bytes_per_token // 64 * 64
             pool = min(pool, cap)
         pool = max(pool, floor)
+        # SPMD tensor parallelism: every rank runs its own scheduler over its own pool; a rank whose free memory gave it a
+        # smaller pool would admit / preempt differently and the per-layer collectives would fall out of step.  All ranks take
+        # the smallest pool.
+        pool = self._agree_min(pool, world)
         import logging
         logging.getLogger("vita_amd").info("paged KV pool: %d tokens (%d pages, %.2f GB) for %d sequence slots", pool,
                                            pool // 64, pool * bytes_per_token / 1e9, max_seqs)
         return pool
+
+    def _agree_min(self, value, world):
+        if world <= 1:
+            return value
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return value          # thread ranks / IpcComm-only set-ups share one process and one memory reading
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self._device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
 
     # ---- reference surface -------------------------------------------------------------------
     def get_model(self):

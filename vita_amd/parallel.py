@@ -112,30 +112,107 @@ class IpcComm:
             self.ptr = None
 
 
-def ranks_share_one_device(dist, device, world):
-    """True when every rank of the group drives the same physical GPU (same host, same visible-device list, same index)."""
+def device_identity(device):
+    """(host, physical GPU) of a torch device: the PCI bus id when the runtime gives one, else the visible-device lists and
+    the RESOLVED index (an un-indexed "cuda" means torch.cuda.current_device(), not device 0: ADVICE r03)."""
     import socket
-    me = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""),
-          os.environ.get("CUDA_VISIBLE_DEVICES", ""), torch.device(device).index or 0)
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pci = None
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        if getattr(p, "pci_bus_id", None) is not None:
+            pci = (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+    except Exception:
+        pci = None
+    if pci is not None:
+        return (socket.gethostname(), "pci", pci)
+    return (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""),
+            os.environ.get("CUDA_VISIBLE_DEVICES", ""), idx)
+
+
+def ranks_share_one_device(dist, device, world):
+    """True when every rank of the group drives the same physical GPU."""
+    me = device_identity(device)
     all_ = [None] * world
     dist.all_gather_object(all_, me)
     return all(a == all_[0] for a in all_)
+
+
+def vote_decode_exchange(dist, same_device, t_kernel_ms, t_fused_ms, fused_ok, device="cpu", backend="gloo", margin=0.02):
+    """All ranks agree on the form of the batch-1 decode exchange (collective call: every rank passes ITS measurements).
+    "fused" (VhXchg: the exchange inside the producer / consumer kernels, no all-reduce launch) only when
+      * no two ranks share a device (a waiting consumer block then never holds a CU another rank's producer needs),
+      * the fused trial finished without a device-side time-out on EVERY rank, and
+      * the slowest rank's fused time beats the slowest rank's kernel time by more than `margin`;
+    "kernel" (one small all-reduce kernel per exchange) otherwise.  The decision uses MAX-reduced times and a MIN-reduced
+    ok flag, so every rank computes it from the same numbers."""
+    t = torch.tensor([float(t_kernel_ms), float(t_fused_ms), 0.0 if fused_ok else 1.0, 1.0 if same_device else 0.0],
+                     dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tk, tf, bad, shared = (float(v) for v in t.tolist())
+    if shared > 0 or bad > 0 or not (tf > 0 and tk > 0):
+        return "kernel", tk, tf
+    return ("fused" if tf < (1.0 - margin) * tk else "kernel"), tk, tf
+
+
+def choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same_device, steps=32):
+    """Times `steps` greedy decode steps of THIS engine under both exchange forms (tp_fuse 0 / 1) and lets the ranks vote
+    (no environment variable on a real node).  Ranks sharing a device skip the timing — the fused form's
+    waiting blocks starve the other ranks there (profiles/r03_tp_fuse_latency_*.json) — and get "kernel".
+    VITA_AMD_TP_FUSE=0/1 still forces a form (debugging).  Leaves the engine reset for the caller's first prefill."""
+    from . import _lib
+    forced = os.environ.get("VITA_AMD_TP_FUSE", "")
+    if forced in ("0", "1"):
+        _lib.tune("tp_fuse", int(forced))
+        return "fused" if forced == "1" else "kernel"
+    tk = tf = 0.0
+    ok = True
+    steps = min(steps, max(0, (eng.max_new - 4) // 2))
+    can_time = (not same_device) and steps >= 4 and eng.max_prefill >= 8 and eng.max_ctx > 8 + 2 * steps + 4
+    if can_time:
+        try:
+            emb = eng.packed["embed"][:8].float().contiguous()          # any 8 rows: only the timing matters
+            for fuse in (0, 1):
+                _lib.tune("tp_fuse", fuse)
+                eng.prefill(emb)
+                eng.decode(2)                                            # first launches of these kernels
+                torch.cuda.synchronize()
+                dist.barrier()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                eng.decode(steps)
+                ev[1].record()
+                torch.cuda.synchronize()
+                ms = ev[0].elapsed_time(ev[1])
+                if fuse:
+                    tf = ms
+                else:
+                    tk = ms
+                if comm.status() != 0 or int(eng.counters[3].item()) != 0:
+                    ok = False
+                    break
+        except Exception as e:
+            print(f"[vita_amd.parallel] rank {rank}: decode-exchange trial failed: {e}", file=sys.stderr)
+            ok = False
+    choice, tk_all, tf_all = vote_decode_exchange(dist, same_device or not can_time, tk, tf, ok, device, backend)
+    _lib.tune("tp_fuse", 1 if choice == "fused" else 0)
+    if rank == 0 and can_time:
+        print(f"[vita_amd.parallel] decode exchange: {choice} (kernel {tk_all / max(steps, 1):.3f} ms/token, fused "
+              f"{tf_all / max(steps, 1):.3f} ms/token over {steps} steps, slowest rank)", file=sys.stderr)
+    return choice
 
 
 def ipc_allreduce(eng, rank, world, dist, device, backend):
     """Bring up IpcComm for the engine and self-test it against torch.distributed before use.  Returns True when every
     rank's self-test passed (the engine then routes its all-reduces through it)."""
     comm, ok = None, 0
+    same = False
     try:
         same = ranks_share_one_device(dist, device, world)
         comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden, same_device=same)
-        # The decode exchange can be FUSED into the kernels around it (tp_fuse = 1, vh_api.hip:decode_one_step / VhXchg).  It is
-        # correct (tests/test_comm_gpu.py runs it at world 2 / 4 / 8) but measured slower than one small all-reduce kernel per
-        # exchange wherever it could be measured (several ranks on one GPU: profiles/r03_tp_fuse_latency_*.json), and on a
-        # shared device at the released geometry its 384-1024 waiting consumer blocks starve the other ranks' kernels.
-        # Default off; VITA_AMD_TP_FUSE=1 selects it (e.g. to try it on real xGMI links).
         from . import _lib
-        _lib.tune("tp_fuse", int(os.environ.get("VITA_AMD_TP_FUSE", "0")))
+        _lib.tune("tp_fuse", 0)                      # the self-test below and the trial start from the kernel form
         handles = [None] * world
         dist.all_gather_object(handles, comm.handle)
         comm.connect(handles)
@@ -170,7 +247,22 @@ def ipc_allreduce(eng, rank, world, dist, device, backend):
         comm.destroy()
         return False
     eng.attach_comm(comm)
+    # which form the batch-1 decode exchange takes is measured here, on the ranks' own devices, and agreed by all ranks
+    eng.decode_exchange = choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same)
+    if not _agree(dist, comm.status() == 0, device, backend):
+        # a trial that timed out leaves the communicator's error word set (sticky): no IPC collective for this job
+        eng.attach_comm(None)
+        comm.destroy()
+        eng.decode_exchange = "kernel"
+        from . import _lib
+        _lib.tune("tp_fuse", 0)
+        return False
     return True
+
+
+def collective_label(engine, name):
+    """what bench.py prints as config.collective: the transport plus the decode exchange form ("ipc+fused" / "ipc+kernel")."""
+    return f"{name}+{getattr(engine, 'decode_exchange', 'kernel')}" if name == "ipc" else name
 
 
 def setup_tensor_parallel(engine, rank, world, device, backend="nccl", collective="auto", rccl_timeout_s=180):
