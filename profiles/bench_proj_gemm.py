@@ -13,6 +13,8 @@ ap.add_argument("--S", type=int, default=552)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--variants", action="store_true", help="also time tile-shape / K-split alternatives (ps_cfg 0 = 64-row m-tiles)")
+ap.add_argument("--ab", default="", help="comma list of ps_cfg values to time the two default cases on, interleaved (e.g. 1,2)")
+ap.add_argument("--rounds", type=int, default=3)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 S, H = args.S, 4096
@@ -22,6 +24,8 @@ xh, xl = ops.split_planes(x)
 out = {}
 nslab = torch.zeros(1, dtype=torch.int32, device=dev)
 cases = [("qkv", 6144, -4, -1), ("o", 4096, -8, -1)]
+if args.ab:
+    cases = [(f"r{r}_{n}_cfg{c}", N, k, int(c)) for r in range(args.rounds) for c in args.ab.split(",") for n, N, k in (("qkv", 6144, -4), ("o", 4096, -8))]
 if args.variants:
     cases += [(f"{n}_cfg{c}_ks{k}", N, k, c) for n, N in (("qkv", 6144), ("o", 4096)) for c in (0, 1) for k in (1, 2, 3)]
 for name, N, ks, cfg in cases:
@@ -42,6 +46,6 @@ for name, N, ks, cfg in cases:
     torch.cuda.synchronize()
     ts = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(args.iters)]
     out[name] = {"us_median": round(float(np.median(ts)), 1), "us_min": round(min(ts), 1), "slabs": int(nslab.item()) if ks < 0 else ks}
-    if args.variants:
+    if args.variants or args.ab:
         print(name, out[name], file=sys.stderr, flush=True)
 print(json.dumps(out))

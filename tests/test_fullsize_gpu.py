@@ -55,7 +55,8 @@ def test_decode_step_equals_prefill_row(full, dev):
         assert int(lg.argmax()) == toks[i]
 
 
-CHUNK_PROMPT_SEED = 1      # chosen by profiles/pick_chunk_prompt.py (see the docstring below)
+CHUNK_PROMPT_SEED = 28     # chosen by profiles/pick_chunk_prompt.py among seeds 1..30 (profiles/r04_pick_chunk_prompt.txt): smallest
+                           # router margin over all 4800 decisions 4.7e-4 (seed 1, r03's prompt: 3.8e-5), last-row logit gap 0.44
 
 
 def test_chunked_prefill_equals_one_shot(full, dev):
