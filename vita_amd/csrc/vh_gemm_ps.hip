@@ -374,7 +374,9 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     const int groups = a.group_off ? (a.ngroups > 0 ? a.ngroups : 1) : 1;
     const int avg = (a.M + groups - 1) / groups;
     int cfg = vh_tuning()->ps_cfg;
-    if (cfg < 0 || cfg > 2) cfg = avg <= 64 ? 0 : 1;
+    // default: 64-row tiles with the weight DMA ring for small groups (batched decode iterations), else the 12-wave specialised
+    // kernel (r04: 8 % faster than the 8-wave form on the MoE pair, 5-12 % on the projections: profiles/r04_sp_ab_*.txt, r04_proj_ab.txt)
+    if (cfg < 0 || cfg > 2) cfg = avg <= 64 ? 0 : 2;
     int grid = num_cus();   // persistent: one 8-wave block per CU
     grid &= ~7;
     if (grid < 8) grid = 8;

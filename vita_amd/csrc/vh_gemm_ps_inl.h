@@ -12,6 +12,9 @@ typedef const __attribute__((address_space(1))) void* glb_void_t;
 #ifndef PS_ABLATE
 #define PS_ABLATE 0
 #endif
+#ifndef PS_SCHED
+#define PS_SCHED 0                  // tile -> block schedule: 0 = contiguous run per XCD, 1 = cost-ordered grid stride (experiment)
+#endif
 
 #define MG_SUB 2048                  // one 16-row x 128-byte (BK = 64) sub-tile
 #define MG_SLOT 16384                // weight half-stage slot: 8 sub-tiles = 128 weight rows
@@ -238,21 +241,32 @@ __device__ __forceinline__ void for_each_tile(const VhGemmPsArgs& p, F&& f) {
     // run — the cheapest tiles in its last round.  (Runs of equal COST instead of equal count were tried: with ~1 tile
     // per CU an uneven count costs a whole extra round: down projection 264 -> 426 us.)
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+#if PS_SCHED == 1
+    // (r04 experiment) COST-ORDERED GRID STRIDE: round `it` is the 8 nb consecutive tiles [it * 8 nb, (it + 1) * 8 nb) of the list
+    // (experts by decreasing rows), one per block: the tiles of a round cost about the same, every block gets one tile of every
+    // cost class, and all XCDs work on the same 2-3 experts at a time.  With the contiguous per-XCD runs below XCD 0 holds only
+    // the LARGEST experts' tiles and XCD 7 the smallest: the launch lasts as long as XCD 0.  Position q of a block inside a round
+    // keeps the pairs (q, q ^ 1) — the two m-tiles of one weight tile, or the two halves of an M-split tail tile — on one XCD.
+    const int stride = 8 * nb;
+    const int jj = (nb & 1) ? (int)blockIdx.x : (((j >> 1) << 4) | (xcd << 1) | (j & 1));
+    const int g0 = 0, Tx = T;
+#else
     const int g0 = (int)(((long)T * xcd) >> 3), g1 = (int)(((long)T * (xcd + 1)) >> 3);
 
     // Block j of the XCD takes tiles g0 + j, g0 + j + nb, ...  A run is seldom a multiple of nb (896 gate|up tiles
     // = 3.5 per CU): the tiles of the last, partial round are cut in TWO along M when that gives every block
     // something to do — both halves stream the same weight tile at the same time on the same XCD (second reader
     // hits L2), each multiplies half the rows; the full-width last round would leave half the CUs idle.
-    const int Tx = g1 - g0;
-    const int R = Tx / nb, r = Tx - R * nb;
-    const bool split_tail = r > 0 && 2 * r <= nb;
+    const int Tx = g1 - g0, stride = nb, jj = j;
+#endif
+    const int R = Tx / stride, r = Tx - R * stride;
+    const bool split_tail = r > 0 && 2 * r <= stride;
     for (int it = 0; it <= R; ++it) {
         int g, half = -1;
-        if (it < R) g = g0 + it * nb + j;
+        if (it < R) g = g0 + it * stride + jj;
         else if (r == 0) break;
-        else if (split_tail) { if (j >= 2 * r) break; g = g0 + R * nb + (j >> 1); half = j & 1; }
-        else { if (j >= r) break; g = g0 + R * nb + j; }
+        else if (split_tail) { if (jj >= 2 * r) break; g = g0 + R * stride + (jj >> 1); half = jj & 1; }
+        else { if (jj >= r) break; g = g0 + R * stride + jj; }
         // ---- decode tile g: expert (in sorted order), then (ks, n-tile, m-tile) with the m-tile fastest ----------
         int e = 0, li = g, rows = 0, mt = 0, oi = 0;
         for (; oi < n_exp; ++oi) {

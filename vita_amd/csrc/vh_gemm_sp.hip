@@ -12,9 +12,9 @@
 //   waves 0-7   MFMA waves (2 M x 4 N as before): per stage ONE barrier, fragment reads, MFMAs.  No vector-memory
 //               instruction, no LDS store, no vmcnt wait anywhere in their loop;
 //   waves 8, 9  weight stagers by stage parity: wave 8+g owns the stages s = 1 + g (mod 2) (stage 0: half each): 32 KB of
-//               weights global -> 128 staging VGPRs during stage s-2, registers -> LDS during stage s-1 (it issues nothing in
-//               between, so the compiler's vmcnt(0) in front of the stores is exact); its stall for HBM happens while the MFMA
-//               waves work;
+//               weights global -> 128 staging VGPRs right behind barrier s-3 (as soon as the registers are free), registers ->
+//               LDS behind barrier s-1: two stage times for the HBM latency, and it issues nothing in between, so the compiler's
+//               vmcnt(0) in front of the stores is exact; its stall for HBM happens while the MFMA waves work;
 //   waves 10,11 activation DMA (global_load_lds, inline asm as in vh_gemm_ps.hip): the 8-row half 0 / 1 of every row tile,
 //               both planes, one stage ahead (L2 hits).
 // Each SIMD therefore holds two MFMA waves (one of either M half: the matrix pipe sees all row tiles of the stage) plus one
@@ -30,7 +30,10 @@ namespace {
 #define SP_WAVES 12
 #define SP_NSLOT 4
 #ifndef SP_PRIO
-#define SP_PRIO 0          // experiment (profiles/r04_run3.sh): s_setprio level of the MFMA waves
+#define SP_PRIO 1          // s_setprio level of the MFMA waves (static).  0 / 1 / 3 measured (profiles/r04_sp_prio.txt): 520 / 505 / 502 us gate|up
+#endif
+#ifndef SP_LEAD
+#define SP_LEAD 2          // stage times the weight loads have to land (1 = first form, profiles/r04_run4.sh A/B)
 #endif
 
 template <bool GLU, int RTMAX, int RTW, int RTA, bool NTW>
@@ -193,6 +196,8 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+#if SP_LEAD == 1
+        // first form (kept for the A/B in profiles/r04_run4.sh): reload one barrier AFTER the store: the loads have ONE stage to land
         for (; k < t.nk; k += 2) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // barrier k: stage k-1 is consumed, its slots take stage k+1
@@ -207,6 +212,25 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#else
+        // registers -> LDS and, as soon as a register has been stored, its reload for the stage after next: the loads of stage
+        // k+3 are in flight from just behind barrier k until the store behind barrier k+2 — TWO stage times for the HBM latency
+        // (measured ~2.5 us under load against stages of ~2 us: with one stage of lead the stager was late at every barrier);
+        // nothing else is issued in between, so the vmcnt(0) hipcc puts in front of the stores is still exact.
+        for (; k < t.nk; k += 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // barrier k: stage k-1 is consumed, its slots take stage k+1
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < t.nk) {
+                w_store(k + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                w_load(k + 3);                         // (clamped past the tile's end: never stored)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the stores (not the loads) are complete
+                __builtin_amdgcn_s_barrier();          // barrier k+1: nothing to do for this stager
+            }
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // clamped tail loads
         __builtin_amdgcn_s_barrier();
     } else {
