@@ -203,11 +203,11 @@ def test_gemm_grouped_glu_and_scatter(dev):
     assert_close("grouped down + scatter", to_np(y), yref, atol=2e-4)
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["cfg-auto", "cfg-dma-ring", "cfg-regstaged", "cfg-specialised", "cfg-pingpong"])
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["cfg-auto", "cfg-dma-ring", "cfg-regstaged", "cfg-specialised"])
 def ps_cfg(request):
     """every vh_gemm_ps test runs on the default selection (by rows per group) and on each kernel form forced: 64-row tiles
     with the weights in an LDS-DMA ring, 192-row tiles with register-staged weights (all 8 waves load and multiply), and the
-    12-wave forms with dedicated loader waves (vh_gemm_sp.hip: one barrier per stage / two with the MFMA waves half a stage apart)."""
+    12-wave form with dedicated loader waves (vh_gemm_sp.hip)."""
     from vita_amd import _lib
     _lib.tune("ps_cfg", request.param)
     yield request.param

@@ -376,12 +376,11 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     int cfg = vh_tuning()->ps_cfg;
     // default: 64-row tiles with the weight DMA ring for small groups (batched decode iterations), else the 12-wave specialised
     // kernel (r04: 8 % faster than the 8-wave form on the MoE pair, 5-12 % on the projections: profiles/r04_sp_ab_*.txt, r04_proj_ab.txt)
-    if (cfg < 0 || cfg > 3) cfg = avg <= 64 ? 0 : 2;
+    if (cfg < 0 || cfg > 2) cfg = avg <= 64 ? 0 : 2;
     int grid = num_cus();   // persistent: one 8-wave block per CU
     grid &= ~7;
     if (grid < 8) grid = 8;
     if (cfg == 2) return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt != 0);   // specialised waves (vh_gemm_sp.hip)
-    if (cfg == 3) return vhk_gemm_pp(st, a, grid, vh_tuning()->ps_nt != 0);   // ... with the two MFMA waves of a SIMD half a stage apart
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
     // round is M-split relies on L2 for the second reader of each weight tile (gate|up: +5 % with nt)
     bool nt = vh_tuning()->ps_nt > 0;

@@ -17,6 +17,9 @@
 //               vmcnt(0) in front of the stores is exact; its stall for HBM happens while the MFMA waves work;
 //   waves 10,11 activation DMA (global_load_lds, inline asm as in vh_gemm_ps.hip): the 8-row half 0 / 1 of every row tile,
 //               both planes, one stage ahead (L2 hits).
+// Tried on top of this and removed again (r04, profiles/r04_sp_pingpong_ab.txt): two barriers per stage with the MFMA waves of a
+// SIMD half a stage apart, so that one of them always has prefetched fragments at a barrier ("ping-pong"): correct, 534-538 us
+// against 520-532 — the stage time is set by what the CU can keep in flight, not by the fragment prologue.
 // Each SIMD therefore holds two MFMA waves (one of either M half: the matrix pipe sees all row tiles of the stage) plus one
 // loader whose issue slots interleave with theirs.  Numerics are those of vh_gemm_ps.hip (same fragments, same order of the
 // MFMAs per accumulator).
@@ -34,11 +37,6 @@ namespace {
 #define SP_NSLOT 4
 #ifndef SP_PRIO
 #define SP_PRIO 1          // s_setprio level of the MFMA waves (static).  0 / 1 / 3 measured (profiles/r04_sp_prio.txt): 520 / 505 / 502 us gate|up
-#endif
-#ifndef SP_LEAD
-#define SP_LEAD 1          // stage times the weight loads have to land.  2 (reload right behind the store: 64 KB of weights in flight
-                           // per CU all the time) measured SLOWER: 549-555 / 631 us (uniform / skewed) against 503-531 / 594 — the CU's
-                           // in-flight request budget (~56 KB) is shared with the activation DMA (profiles/r04_sp_lead_sched_ab.txt)
 #endif
 
 template <bool GLU, int RTMAX, int RTW, int RTA, bool NTW>
@@ -201,8 +199,10 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-#if SP_LEAD == 1
-        // first form (kept for the A/B in profiles/r04_run4.sh): reload one barrier AFTER the store: the loads have ONE stage to land
+        // The reload is issued one barrier AFTER the store, so the loads have one stage time to land and each stager has loads in
+        // flight only every other stage.  Reloading right behind the store (two stage times of lead, 64 KB of weights in flight per
+        // CU at all times) was measured SLOWER — 549-555 / 631 us (uniform / skewed) against 503-531 / 594: the CU's in-flight
+        // request budget (~56 KB) is shared with the activation DMA (profiles/r04_sp_lead_sched_ab.txt).
         for (; k < t.nk; k += 2) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();              // barrier k: stage k-1 is consumed, its slots take stage k+1
@@ -217,25 +217,6 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#else
-        // registers -> LDS and, as soon as a register has been stored, its reload for the stage after next: the loads of stage
-        // k+3 are in flight from just behind barrier k until the store behind barrier k+2 — TWO stage times for the HBM latency
-        // (measured ~2.5 us under load against stages of ~2 us: with one stage of lead the stager was late at every barrier);
-        // nothing else is issued in between, so the vmcnt(0) hipcc puts in front of the stores is still exact.
-        for (; k < t.nk; k += 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();              // barrier k: stage k-1 is consumed, its slots take stage k+1
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < t.nk) {
-                w_store(k + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                w_load(k + 3);                         // (clamped past the tile's end: never stored)
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the stores (not the loads) are complete
-                __builtin_amdgcn_s_barrier();          // barrier k+1: nothing to do for this stager
-            }
-        }
-#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // clamped tail loads
         __builtin_amdgcn_s_barrier();
     } else {
@@ -281,279 +262,6 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
 }
 
 
-// ======================================================================================================================
-// Ping-pong form (ps_cfg = 3): the same 12 waves, but TWO barriers per K stage and the two MFMA waves of a SIMD half a stage
-// apart.  In run_tile_sp every MFMA wave starts a stage at the same barrier with the same prologue — ten fragment reads before
-// its first MFMA — so the matrix pipe of every SIMD idles through that prologue (MFMA-only ablation: 353 us against a ~250 us
-// pipe time, profiles/r04_sp_ablate.txt).  Here the waves with wm = 0 start stage k at barrier 2k, the waves with wm = 1 at
-// barrier 2k + 1; each wave crosses the OTHER group's barrier in the middle of its stage, between its k-step 0 and k-step 1
-// halves, with the fragments of the second half already in registers.  At every barrier one wave of each SIMD therefore issues
-// MFMAs at once while its partner reads the new stage (MI355X_MICROARCH.md "Two waves per SIMD": alternate a matrix segment
-// with the partner's load segment).  Buffer lifetimes: the two groups read DISJOINT activation row tiles (even / odd), so each
-// half of an activation buffer still has a whole stage between its last read and its refill; the weight slots are shared: the
-// stager writes stage s between barrier 2s - 1 (group 1 has finished stage s - 2) and barrier 2s (group 0 starts stage s) — half
-// a stage, enough for 32 ds_write_b128 from registers that were loaded two stages earlier.
-template <int S, int N, bool LASTREAD>
-struct HalfOrder {
-    static __device__ __forceinline__ void pin() {
-        if constexpr (S + 1 < N || LASTREAD) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        if constexpr (S + 1 < N) HalfOrder<S + 1, N, LASTREAD>::pin();
-    }
-};
-
-template <bool GLU, int RTMAX, int RTW, int RTA, bool NTW>
-__device__ __forceinline__ void run_tile_pp(const VhGemmPsArgs& p, const TileCtx& t, unsigned char* lds, const int lane,
-                                            const int wid) {
-    constexpr int A_BUF = RTMAX * 2 * MG_SUB;
-    constexpr int W_BASE = 2 * A_BUF;
-    constexpr int LDS_BYTES = 2 * A_BUF + SP_NSLOT * MG_SLOT;
-    const int lrow = lane >> 3;
-    const int NB = 2 * t.nk + 2;                 // barriers of this tile before the epilogue (same count in every wave)
-
-    if (wid < 8) {
-        // ================================ MFMA waves ===========================================================
-        const int wm = wid >> 2, wn = wid & 3;
-        const int fr = lane & 15;
-        const int frag_base = (fr >> 3) * 1024 + (fr & 7) * 128;
-        const int frag_x = (fr >> 1) & 7;
-        const int fo0 = frag_base + (((lane >> 4)) ^ frag_x) * 16;
-        const int fo1 = frag_base + ((4 + (lane >> 4)) ^ frag_x) * 16;
-        f32x4 acc[RTW][4];
-#pragma unroll
-        for (int i = 0; i < RTW; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if SP_PRIO
-        __builtin_amdgcn_s_setprio(SP_PRIO);
-#endif
-        auto loop = [&](auto rte_c, auto grp_c) __attribute__((always_inline)) {
-            constexpr int RTE = decltype(rte_c)::value;          // row tiles this wave multiplies
-            constexpr int GRP = decltype(grp_c)::value;          // 0: stages start at even barriers, 1: at odd ones
-            if (GRP == 1) __builtin_amdgcn_s_barrier();          // barrier 0 belongs to group 0 alone
-            for (int k = 0; k < t.nk; ++k) {
-                const unsigned char* ab = lds + (k & 1) * A_BUF;
-                const int slot_w = ((2 * k) & 3) + (wn >> 1);
-                const unsigned char* wb = lds + W_BASE + slot_w * MG_SLOT + (wn & 1) * 4 * MG_SUB;
-                bf16x8_t bw0[4], bw1[4], ah, al;
-                __builtin_amdgcn_s_barrier();                    // this group's stage k is complete in LDS
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (RTE > 0) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bw0[c] = *reinterpret_cast<const bf16x8_t*>(wb + c * MG_SUB + fo0);
-                    ah = *reinterpret_cast<const bf16x8_t*>(ab + wm * MG_SUB + fo0);
-                    al = *reinterpret_cast<const bf16x8_t*>(ab + (RTMAX + wm) * MG_SUB + fo0);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bw1[c] = *reinterpret_cast<const bf16x8_t*>(wb + c * MG_SUB + fo1);
-#pragma unroll
-                    for (int i = 0; i < RTE; ++i) {              // k-step 0; the last step fetches the first fragments of k-step 1
-                        const int rti1 = (i + 1 < RTE) ? wm + 2 * (i + 1) : wm;
-                        const int fo = (i + 1 < RTE) ? fo0 : fo1;
-                        const bf16x8_t nh_ = *reinterpret_cast<const bf16x8_t*>(ab + rti1 * MG_SUB + fo);
-                        const bf16x8_t nl_ = *reinterpret_cast<const bf16x8_t*>(ab + (RTMAX + rti1) * MG_SUB + fo);
-                        if (!(PS_ABLATE & 4)) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw0[c], ah, acc[i][c], 0, 0, 0);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw0[c], al, acc[i][c], 0, 0, 0);
-                        } else {
-                            asm volatile("" ::"v"(ah), "v"(al), "v"(bw0[0]), "v"(bw0[1]), "v"(bw0[2]), "v"(bw0[3]));
-                        }
-                        ah = nh_; al = nl_;
-                    }
-                    if ((PS_ABLATE & ~32) == 0) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);       // bw0, first activation pair, bw1
-                        HalfOrder<0, RTE, true>::pin();
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();                    // the OTHER group's stage boundary: nothing to wait for here
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (RTE > 0) {
-#pragma unroll
-                    for (int i = 0; i < RTE; ++i) {              // k-step 1
-                        bf16x8_t nh_ = ah, nl_ = al;
-                        if (i + 1 < RTE) {
-                            const int rti1 = wm + 2 * (i + 1);
-                            nh_ = *reinterpret_cast<const bf16x8_t*>(ab + rti1 * MG_SUB + fo1);
-                            nl_ = *reinterpret_cast<const bf16x8_t*>(ab + (RTMAX + rti1) * MG_SUB + fo1);
-                        }
-                        if (!(PS_ABLATE & 4)) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw1[c], ah, acc[i][c], 0, 0, 0);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw1[c], al, acc[i][c], 0, 0, 0);
-                        } else {
-                            asm volatile("" ::"v"(ah), "v"(al), "v"(bw1[0]), "v"(bw1[1]), "v"(bw1[2]), "v"(bw1[3]));
-                        }
-                        ah = nh_; al = nl_;
-                    }
-                    if ((PS_ABLATE & ~32) == 0) HalfOrder<0, RTE, false>::pin();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (GRP == 0) __builtin_amdgcn_s_barrier();          // barrier 2 nk belongs to group 1 alone
-        };
-        if (wm == 0) loop(std::integral_constant<int, RTW>{}, std::integral_constant<int, 0>{});
-        else loop(std::integral_constant<int, RTA>{}, std::integral_constant<int, 1>{});
-        __builtin_amdgcn_s_barrier();                 // barrier 2 nk + 1: every wave is done with the rings
-        tile_epilogue<GLU, RTMAX, RTW, SP_WAVES, LDS_BYTES, true>(p, t, lds, lane, wid, wm, wn, acc);
-        return;
-    }
-
-    if (wid < 10) {
-        // ================================ weight stagers ========================================================
-        const int g = wid - 8;
-        const unsigned char* w_gate = reinterpret_cast<const unsigned char*>(t.Wb);
-        const unsigned char* w_up = reinterpret_cast<const unsigned char*>(GLU ? t.Wu : t.Wb);
-        const uint32_t ldw2 = (uint32_t)(p.ldw * 2);
-        uint32_t wcol[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) wcol[u] = (uint32_t)(((lane & 7) ^ (((u * 8 + lrow) >> 1) & 7)) * 16);
-        u32x4 wreg[32];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) wreg[q] = u32x4{0u, 0u, 0u, 0u};
-        unsigned char* const wr_dst0 = lds + W_BASE + lane * 16;
-        auto w_load_range = [&](int kt, auto q0_c, auto n_c, int s16_base) __attribute__((always_inline)) {
-            constexpr int Q0 = decltype(q0_c)::value, NQ = decltype(n_c)::value;
-            const int kc = kt < t.nk ? kt : t.nk - 1;                    // clamped re-load at the tile's end: never stored
-            const size_t kb = (size_t)(t.k0 + kc) * 128;
-            int lr = lrow;
-            asm volatile("" : "+v"(lr));                                 // offsets recomputed per call: not 32 hoisted VGPRs
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int s16 = s16_base + (q >> 1), u = q & 1;
-                const unsigned char* base = ((GLU && (s16 & 2)) ? w_up : w_gate) + kb;
-                int n = GLU ? t.n0 + (s16 >> 2) * 32 + (s16 & 1) * 16 + u * 8 + lr : t.n0 + s16 * 16 + u * 8 + lr;
-                if (n > p.N - 1) n = p.N - 1;                            // clamped rows: products never stored
-                const uint32_t o = (uint32_t)n * ldw2 + wcol[u];
-                if (PS_ABLATE & 2) continue;
-                if (NTW) wreg[Q0 + q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + o));
-                else wreg[Q0 + q] = *reinterpret_cast<const u32x4*>(base + o);
-            }
-        };
-        auto w_store = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int s16 = q >> 1, u = q & 1;
-                if (!(PS_ABLATE & 2))
-                    *reinterpret_cast<u32x4*>(wr_dst0 + (((2 * kt) & 3) + (s16 >> 3)) * MG_SLOT + (s16 & 7) * MG_SUB + u * 1024) = wreg[q];
-            }
-        };
-        using I0 = std::integral_constant<int, 0>; using I16 = std::integral_constant<int, 16>; using I32 = std::integral_constant<int, 32>;
-        // stage 0: half each (sub-tiles 8g .. 8g+7 = slot g)
-        w_load_range(0, I0{}, I16{}, 8 * g);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int qq = 0; qq < 16; ++qq)
-            if (!(PS_ABLATE & 2)) *reinterpret_cast<u32x4*>(wr_dst0 + g * MG_SLOT + (qq >> 1) * MG_SUB + (qq & 1) * 1024) = wreg[qq];
-        __builtin_amdgcn_sched_barrier(0);
-        w_load_range(1 + g, I0{}, I32{}, 0);          // the first stage this stager owns
-        __builtin_amdgcn_sched_barrier(0);
-        int b = 0;
-        auto bar = [&]() __attribute__((always_inline)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            ++b;
-        };
-        for (int i = 0; i < 2 * g + 2; ++i) bar();    // up to and including barrier 2 s - 1 of its first stage s = 1 + g
-        for (int s = 1 + g; s < t.nk; s += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            w_store(s);                               // behind barrier 2 s - 1, in front of barrier 2 s
-            __builtin_amdgcn_sched_barrier(0);
-#if SP_LEAD == 2
-            w_load_range(s + 2, I0{}, I32{}, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            for (int i = 0; i < 4 && b < NB; ++i) bar();
-#else
-            if (b < NB) bar();                        // barrier 2 s
-            __builtin_amdgcn_sched_barrier(0);
-            w_load_range(s + 2, I0{}, I32{}, 0);      // three half stages to land before its store behind barrier 2 s + 3
-            __builtin_amdgcn_sched_barrier(0);
-            for (int i = 0; i < 3 && b < NB; ++i) bar();
-#endif
-        }
-        while (b < NB) bar();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail loads
-    } else {
-        // ================================ activation DMA (8-row half u of every row tile, both planes) =============
-        const int u = wid - 10;
-        const int r16 = u * 8 + lrow;
-        const int c8 = (lane & 7) ^ ((r16 >> 1) & 7);
-        uint32_t offa[RTMAX];
-#pragma unroll
-        for (int i = 0; i < RTMAX; ++i) {
-            int m = t.m_begin + i * 16 + r16;
-            if (m > t.m_end - 1) m = t.m_end - 1;
-            const long src_row = p.a_rowidx ? p.a_rowidx[m] : m;
-            offa[i] = (uint32_t)(((size_t)src_row * p.lda + c8 * 8) * 2);
-        }
-        const unsigned char* a_hi = reinterpret_cast<const unsigned char*>(p.A_hi);
-        const unsigned char* a_lo = reinterpret_cast<const unsigned char*>(p.A_lo);
-        unsigned char* const a_dst0 = lds + u * 1024;
-        auto a_tiles = [&](int kt, auto grp_c) __attribute__((always_inline)) {     // the row tiles of group grp (even / odd)
-            constexpr int GRP = decltype(grp_c)::value;
-            constexpr int NT_ = GRP == 0 ? RTW : RTA;
-            const int kc = kt < t.nk ? kt : t.nk - 1;
-            const size_t kb = (size_t)(t.k0 + kc) * 128;
-            unsigned char* dst = a_dst0 + (kt & 1) * A_BUF;
-#pragma unroll
-            for (int i = 0; i < NT_; ++i) {
-                const int rti = 2 * i + GRP;
-                if (PS_ABLATE & 1) continue;
-                glds16<false>(a_hi + kb, offa[rti], dst + rti * MG_SUB);
-                glds16<false>(a_lo + kb, offa[rti], dst + (RTMAX + rti) * MG_SUB);
-            }
-        };
-        using G0 = std::integral_constant<int, 0>; using G1 = std::integral_constant<int, 1>;
-        a_tiles(0, G0{});
-        a_tiles(0, G1{});
-        for (int k = 0; k < t.nk; ++k) {
-            wait_vm<2 * RTA>();                       // group 0's tiles of stage k have landed (group 1's, issued later, may be in flight)
-            __builtin_amdgcn_s_barrier();             // barrier 2k
-            __builtin_amdgcn_sched_barrier(0);
-            a_tiles(k + 1, G0{});                     // group 0 finished stage k - 1 (clamped at the tile's end)
-            __builtin_amdgcn_sched_barrier(0);
-            wait_vm<2 * RTW>();                       // group 1's tiles of stage k have landed
-            __builtin_amdgcn_s_barrier();             // barrier 2k + 1
-            __builtin_amdgcn_sched_barrier(0);
-            a_tiles(k + 1, G1{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                 // barrier 2 nk
-        __builtin_amdgcn_s_barrier();                 // barrier 2 nk + 1
-    }
-    f32x4 none[RTW][4];
-    tile_epilogue<GLU, RTMAX, RTW, SP_WAVES, LDS_BYTES, false>(p, t, lds, lane, wid, 0, 0, none);
-}
-
-template <bool GLU, int RTMAX, bool NTW>
-__global__ __launch_bounds__(64 * SP_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_gemm_pp(const VhGemmPsArgs p) {
-    constexpr int A_BUF = RTMAX * 2 * MG_SUB;
-    static_assert(2 * A_BUF + SP_NSLOT * MG_SLOT <= MG_LDS && (RTMAX % 2) == 0, "LDS budget / ring geometry");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * A_BUF + SP_NSLOT * MG_SLOT];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for_each_tile<GLU, RTMAX>(p, [&](const TileCtx& t) __attribute__((always_inline)) {
-        switch (t.rt) {
-#define PP_CASE(RT)                                                                                        \
-    case RT:                                                                                               \
-        if constexpr (RTMAX >= RT) run_tile_pp<GLU, RTMAX, (RT + 1) / 2, RT / 2, NTW>(p, t, lds, lane, wid); \
-        break;
-#ifdef SP_ONLY_RT
-            PP_CASE(SP_ONLY_RT)
-#else
-            PP_CASE(1) PP_CASE(2) PP_CASE(3) PP_CASE(4) PP_CASE(5) PP_CASE(6)
-            PP_CASE(7) PP_CASE(8) PP_CASE(9) PP_CASE(10) PP_CASE(11) PP_CASE(12)
-#endif
-#undef PP_CASE
-            default: break;
-        }
-    });
-}
-
 template <bool GLU, int RTMAX, bool NTW>
 __global__ __launch_bounds__(64 * SP_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_gemm_sp(const VhGemmPsArgs p) {
@@ -583,17 +291,6 @@ void k_gemm_sp(const VhGemmPsArgs p) {
 }  // namespace
 
 // arguments already checked by vhk_gemm_ps (vh_gemm_ps.hip)
-int vhk_gemm_pp(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt) {
-    if (a.W_up) {
-        if (nt) hipLaunchKernelGGL((k_gemm_pp<true, 12, true>), dim3(grid), dim3(64 * SP_WAVES), 0, st, a);
-        else hipLaunchKernelGGL((k_gemm_pp<true, 12, false>), dim3(grid), dim3(64 * SP_WAVES), 0, st, a);
-    } else {
-        if (nt) hipLaunchKernelGGL((k_gemm_pp<false, 12, true>), dim3(grid), dim3(64 * SP_WAVES), 0, st, a);
-        else hipLaunchKernelGGL((k_gemm_pp<false, 12, false>), dim3(grid), dim3(64 * SP_WAVES), 0, st, a);
-    }
-    return 0;
-}
-
 int vhk_gemm_sp(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt) {
     if (a.W_up) {
         if (nt) hipLaunchKernelGGL((k_gemm_sp<true, 12, true>), dim3(grid), dim3(64 * SP_WAVES), 0, st, a);

@@ -142,7 +142,6 @@ struct VhGemmPsArgs {
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
 int vhk_gemm_sp(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt);   // vh_gemm_sp.hip: 12-wave specialised form (arguments already checked)
-int vhk_gemm_pp(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt);   // vh_gemm_sp.hip: the same with half-stage ping-pong of the MFMA waves
 int vhk_split_planes(hipStream_t st, const float* x, long ldx, uint16_t* hi, uint16_t* lo, long ldo, int rows,
                      int cols);
 
