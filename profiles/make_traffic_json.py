@@ -15,7 +15,7 @@ alg = {   # algorithmic bytes per launch, released geometr
     "k_dec_lmhead": ("k_dec_lmhead", V * H * 2),
     "k_dec_gemv_qkv": ("k_dec_gemv<2, 8, true>", NQKV * H * 2),
     "k_dec_gemv_oproj": ("k_dec_gemv<2, 8, false>", H * H * 2),
-    "k_gemm_ps_moe_gateup (prefill S=552)": ("k_gemm_ps<true", E * 2 * I * H * 2),
+    "k_gemm_ps_moe_gateup (prefill S=552)": (("k_gemm_sp<true", "k_gemm_ps<true"), E * 2 * I * H * 2),   # r04: the specialised kernel is the default
 }
 rows = {}
 for ln in open(src):
@@ -26,12 +26,18 @@ for ln in open(src):
 out = {"_how": open(src).readline().lstrip("# ").strip() + "  (profiles/r0N_measure.sh)",
        "_units": "FETCH_SIZE in KiB; bytes = counter * 1024 * 2 on gfx950 for wide coalesced streaming reads (MI355X_MICROARCH.md HBM section)"}
 for key, (pat, ab) in alg.items():
-    m = [(n, v) for n, v in rows.items() if pat in n]
+    pats = pat if isinstance(pat, tuple) else (pat,)
+    m = []
+    for pt in pats:                       # first pattern that matches a kernel of the pass
+        m = [(n, v) for n, v in rows.items() if pt in n]
+        if m:
+            break
     if not m:
         continue
+    m.sort(key=lambda kv: -kv[1][0])      # several instantiations: the one launched most often
     n, (cnt, kib, us) = m[0]
     b = int(round(kib * 1024 * 2))
-    out[key] = {"FETCH_SIZE_KiB_mean": kib, "launch_records": cnt, "avg_us": us, "hbm_read_bytes_per_launch": b,
+    out[key] = {"kernel": n[:80], "FETCH_SIZE_KiB_mean": kib, "launch_records": cnt, "avg_us": us, "hbm_read_bytes_per_launch": b,
                 "algorithmic_bytes_per_launch": ab, "ratio": round(b / ab, 4)}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
