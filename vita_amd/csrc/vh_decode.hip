@@ -354,43 +354,43 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
             o.x = fmaf(pk, vv.x, o.x);
             o.y = fmaf(pk, vv.y, o.y);
         }
-        // the partials travel to ANOTHER CU (the last arriver merges them): published with 8-byte agent-scope stores (write-through,
-        // sc1) and read back with agent-scope loads (L1-bypassing) — guide G16 "8-B agent atomics both sides": no release / acquire
-        // fence pair (2 x ~1.7 us on the critical path of this ~9 us latency chain; r01-r03 used the fence form)
-        __hip_atomic_store(reinterpret_cast<xu64*>(part_o + ((size_t)head * max_splits + sp) * 128) + lane,
-                           ((xu64)__float_as_uint(o.y) << 32) | (xu64)__float_as_uint(o.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0)
-            __hip_atomic_store(reinterpret_cast<xu64*>(part_ml + ((size_t)head * max_splits + sp) * 2),
-                               ((xu64)__float_as_uint(l) << 32) | (xu64)__float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<float2*>(part_o + ((size_t)head * max_splits + sp) * 128)[lane] = o;
+        if (lane == 0) {
+            part_ml[((size_t)head * max_splits + sp) * 2] = m;
+            part_ml[((size_t)head * max_splits + sp) * 2 + 1] = l;
+        }
     }
 
-    // 5. publish; the last arriver of this KV head merges (placement-independent hand-off: every storing wave drains its
-    // write-through stores, then ONE relaxed arrival per block)
+    // 5. publish; the last arriver of this KV head merges (placement-independent hand-off)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int ticket = __hip_atomic_fetch_add(&cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = (ticket == nsplit - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!last_s) return false;
-    if (tid == 0) __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
     if (wid < G) {
-        const xu64* ml = reinterpret_cast<const xu64*>(part_ml + (size_t)head * max_splits * 2);
-        const xu64* po = reinterpret_cast<const xu64*>(part_o + (size_t)head * max_splits * 128);
-        auto ld = [](const xu64* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        const float* ml = part_ml + (size_t)head * max_splits * 2;
+        const float* po = part_o + (size_t)head * max_splits * 128;
         float M = -INFINITY;
-        for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, __uint_as_float((unsigned)ld(ml + sidx)));
+        for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, ml[sidx * 2]);
         float den = 0.f;
         float2 num = make_float2(0.f, 0.f);
 #pragma unroll 4
         for (int sidx = 0; sidx < nsplit; ++sidx) {
-            const xu64 mlv = ld(ml + sidx);
-            const float wgt = __expf(__uint_as_float((unsigned)mlv) - M);
-            den = fmaf(wgt, __uint_as_float((unsigned)(mlv >> 32)), den);
-            const xu64 ov = ld(po + (size_t)sidx * 64 + lane);
-            num.x = fmaf(wgt, __uint_as_float((unsigned)ov), num.x);
-            num.y = fmaf(wgt, __uint_as_float((unsigned)(ov >> 32)), num.y);
+            const float wgt = __expf(ml[sidx * 2] - M);
+            den = fmaf(wgt, ml[sidx * 2 + 1], den);
+            const float2 ov = reinterpret_cast<const float2*>(po + (size_t)sidx * 128)[lane];
+            num.x = fmaf(wgt, ov.x, num.x);
+            num.y = fmaf(wgt, ov.y, num.y);
         }
         const float inv = 1.0f / den;
         reinterpret_cast<float2*>(attn_out + (size_t)head * 128)[lane] = make_float2(num.x * inv, num.y * inv);
