@@ -39,18 +39,9 @@ for name, M, N, K, epi in SHAPES:
     xh, xl = ops.split_planes(x)
     kw = {"bias": dict(bias=b), "gelu": dict(bias=b, act="gelu"), "resid": dict(bias=b, scale=sc, resid=res)}[epi]
     row = {"shape": [M, N, K], "epi": epi}
-    ref64 = (x.double() @ w.double().T)
-    for tall in (0, 1, 2, 0, 1, 2):            # general kernel: 64-row tiles / 128-row tiles with two K-tiles in flight / with one (r04), twice each
-        _lib.tune("gemm_tall", tall)
-        tt = timeit(lambda: ops.gemm(x, w, out=out, **kw))
-        row[f"gemm_tall{tall}"] = min(tt, row.get(f"gemm_tall{tall}", 1e9))
-        if epi == "bias":
-            row[f"err_tall{tall}"] = float((ops.gemm(x, w, bias=b).double() - (ref64 + b.double())).abs().max())
-    _lib.tune("gemm_tall", 0)
-    row["gemm"] = row["gemm_tall0"]
+    row["gemm"] = timeit(lambda: ops.gemm(x, w, out=out, **kw))
     ref = ops.gemm(x, w, **kw)
-    _lib.tune("gemm_tall", 1)
-    for cfg in (1, 2):
+    for cfg in (0, 1):
         _lib.tune("ps_cfg", cfg)
         if epi == "gelu":
             row[f"ps_cfg{cfg}"] = timeit(lambda: ops.gemm_ps(xh, xl, w, out_split=True, **kw))

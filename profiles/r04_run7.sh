@@ -19,4 +19,4 @@ d = json.loads(open("$O/bench_tall$tv.json").read().strip().splitlines()[-1])
 print("gemm_tall=$tv", "vit+proj ms", d["vit_projector_ms"], "min", d["phase_min_ms"]["vit_proj_ms"], "audio ms", d["audio_encoder_ms"], "min", d["phase_min_ms"]["audio_ms"])
 PY
 done | tee $O/encoders_ab.txt
-timeout 900 python -m pytest tests/test_realgeom_gpu.py tests/test_model_gpu.py -x -q -k "encoders or vision or audio or tower" > $O/pytest_enc.log 2>&1; echo "encoder tests rc=$?" | tee -a $O/status.txt; tail -3 $O/pytest_enc.log
+timeout 900 python -m pytest tests/test_realgeom_gpu.py tests/test_model_gpu.py -x -q -k "encoders or vision or audio or vit or whale" > $O/pytest_enc.log 2>&1; echo "encoder tests rc=$?" | tee -a $O/status.txt; tail -3 $O/pytest_enc.log

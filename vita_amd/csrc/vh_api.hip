@@ -43,7 +43,6 @@ int vh_tune(const char* key, int value) {
     if (!key) return fail(VH_E_ARG, "vh_tune: null key");
     if (!strcmp(key, "batch_moe_min")) { g_tuning.batch_moe_min = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
-    if (!strcmp(key, "gemm_tall")) { g_tuning.gemm_tall = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_presplit")) { g_tuning.attn_presplit = value; return VH_OK; }
     if (!strcmp(key, "attn_rows")) { g_tuning.attn_rows = value; return VH_OK; }

@@ -37,17 +37,16 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {  // byte offset in 
 // 256 threads, waves 2 (M) x 2 (N), block tile 64 x 128 (GLU: 64 gate + 64 up weight rows -> 64 outputs).
 // Tile shapes that trade occupancy for size were all measured slower on this structure (DESIGN.md §6.2:
 // 128- and 256-row m-tiles, pre-split operand planes, XCD-contiguous block orders) and were removed again.
+// (r04 re-measured 128 x 128 tiles on the encoders' plain Linears, where they turn the ViT's 408-block qkv launch into 216 blocks in
+// one round: 58 vs 41.5 us, ViT + projector 6.9 vs 5.3 ms — at one 4-wave block per CU nothing hides the K-tile round trip;
+// profiles/r04_gemm_tall_ab.txt.)
 // MINW pins the register-allocation target: hipcc otherwise chases the occupancy the 32 KB of LDS would
 // allow (5 blocks/CU) and parks prefetched weight registers in SCRATCH to get under ~96 VGPRs, which turns
 // the asynchronous prefetch into a synchronous round trip.
-// BMT (r04): rows of the block tile, 64 (default) or 128 for the encoders' plain Linears.  Those launches are bound by the global-load
-// round trip of a K-tile (~1-2 us under load), not by either pipe: a 128 x 128 tile does twice the matrix work per round trip and turns
-// the 408-block / 1.6-round qkv launch of the ViT (M = 1025) into 216 blocks in ONE round.  (r01's 128- and 256-row experiments were on
-// the grouped MoE GEMM, thousands of blocks at 4 per CU, where occupancy mattered more.)
-template <bool GLU, int PF, int MINW, int BMT = GM_BM>
+template <bool GLU, int PF, int MINW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_gemm(const VhGemmArgs p) {
-    constexpr int BM = BMT;
+    constexpr int BM = GM_BM;
     constexpr int WMW = 2;                           // waves along M (2 along N)
     constexpr int MI = BM / WMW / 16;                // 16-row tiles per wave
     constexpr int AF4 = BM * 16 / 256;               // 16-byte pieces of A per thread per K-tile (4)
@@ -351,12 +350,7 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.ln_out && (!a.ln_w || a.W_up || a.c_rowidx || a.group_off || (a.N % 4) != 0 || (a.ldc % 4) != 0 || (a.ld_ln % 4) != 0)) return -1;
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
-    // 128-row tiles for plain GEMMs whose launch still has at least ~0.6 blocks per CU with them (encoder Linears at M >= 256)
-    const bool plain0 = !a.group_off && !a.W_up && !a.c_rowidx && !a.a_rowidx;
-    const long blocks128 = (long)((a.N + GM_BN - 1) / GM_BN) * ((a.M + 127) / 128);
-    const bool tall = plain0 && vh_tuning()->gemm_tall != 0 && a.M >= 256 && (blocks128 * 5 >= 3L * vh_num_cus() || a.ws != nullptr);
-    const int BMsel = tall ? 128 : GM_BM;
-    g.mt_slots = a.group_off ? (a.M / GM_BM + a.ngroups) : (a.M + BMsel - 1) / BMsel;  // grouped: upper bound
+    g.mt_slots = a.group_off ? (a.M / GM_BM + a.ngroups) : (a.M + GM_BM - 1) / GM_BM;  // grouped: upper bound
     // split-K when the launch would leave most CUs with at most one 4-wave block (nothing to overlap a K-tile's load ->
     // split -> LDS -> barrier chain with): aim at ~3 blocks per CU, keep >= 4 K-tiles per block
     int ksp = 1;
@@ -367,8 +361,6 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
         const long target = 3L * vh_num_cus();
         // (measured on the ViT: 136-block launches gain 1.5-1.8x, the 408-block qkv GEMM loses 20 % to the reducer)
         ksp = a.ksplit > 1 ? a.ksplit : (blocks * 4 >= 5L * vh_num_cus() ? 1 : (int)((target + blocks - 1) / blocks));
-        // 128-row tiles: a block carries twice the work and two fit a CU: one round of >= 0.6 blocks per CU needs no split, else aim at ~1.25 per CU
-        if (tall && a.ksplit <= 1) ksp = blocks * 5 >= 3L * vh_num_cus() ? 1 : (int)((5L * vh_num_cus() / 4 + blocks - 1) / blocks);
         if (ksp > nkt / 4) ksp = nkt / 4;
         if (ksp > 8) ksp = 8;
         while (ksp > 1 && (size_t)ksp * a.M * a.N * sizeof(float) > a.ws_bytes) --ksp;
@@ -381,9 +373,7 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
         if (pf2) hipLaunchKernelGGL((k_gemm<true, 2, 3>), grid_glu, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_gemm<true, 1, 4>), grid_glu, dim3(256), 0, st, g);
     } else {
-        if (tall && vh_tuning()->gemm_tall == 2) hipLaunchKernelGGL((k_gemm<false, 1, 2, 128>), grid, dim3(256), 0, st, g);
-        else if (tall) hipLaunchKernelGGL((k_gemm<false, 2, 2, 128>), grid, dim3(256), 0, st, g);
-        else if (pf2) hipLaunchKernelGGL((k_gemm<false, 2, 3>), grid, dim3(256), 0, st, g);
+        if (pf2) hipLaunchKernelGGL((k_gemm<false, 2, 3>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((k_gemm<false, 1, 4>), grid, dim3(256), 0, st, g);
         const bool ln_fused = a.ln_out && ksp > 1 && a.N <= GR_MAXJ * 1024 && (a.ldc % 4) == 0 && (a.ld_ln % 4) == 0;
         if (ksp > 1 && ln_fused) {

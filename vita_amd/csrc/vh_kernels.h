@@ -13,7 +13,6 @@ struct VhTuning {
     int batch_moe_min = 3;     // concurrent sequences: from this many per iteration the layer's MoE runs ONCE on the weight-streaming GEMM
                                // (S = n rows sorted by expert, every touched expert streamed once); 0 = never
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
-    int gemm_tall = 1;         // general GEMM: 1 = 128-row block tiles for plain GEMMs with M >= 256 (encoder Linears), 0 = always 64 rows
     int attn_impl = 0;         // multi-row attention: 0 = bf16 x 3 MFMAs where the mask flavour allows (plain / causal), 2 = fp32-MFMA kernel everywhere
     int attn_presplit = 0;     // bf16 x 3 attention: 1 = K / V converted to planes once per launch by a pre-pass (k_attn_prep) when the caller provides scratch
     int attn_rows = 0;         // bf16 x 3 attention at d = 64: query rows per wave, 0 = auto (32 when the launch still fills the chip), 16, 32
