@@ -277,22 +277,26 @@ def cpu_baseline(cfg, n_layers=2, ctx=None, n_tok=6, encoders=True, request=None
            "prefill_ms": round(prefill_ms, 1), "prefill_cores": int(pre_thr),
            "prefill_sample": f"the same {n_layers} layers over the S={S} prompt rows, x{L_full}/{n_layers} + LM head (extrapolated)"}
     if encoders and request is not None:
-        from oracle import encoders as oe
+        import torch as _torch
+        from oracle import encoders_torch as ot
         from vita_amd.checkpoint import synth_state_dict
         sd = synth_state_dict(cfg, seed=1, rich=False, parts=("vision", "audio"))
-        t0 = time.perf_counter()
-        vit = oe.internvit_tower(sd, cfg.vision, request["pixel_values"][:1])
-        oe.projector(sd, vit)
-        t_v = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        oe.whale_encoder(sd, cfg.audio, request["fbank"])
-        t_a = time.perf_counter() - t0
-        out.update({"vit_projector_ms": round(t_v * 1e3, 1), "audio_encoder_ms": round(t_a * 1e3, 1), "encoder_cores": int(all_thr),
-                    "encoder_sample": "full-depth numpy fp64 restatements (24-layer InternViT + projector on one 448x448 tile; Whale "
-                                      "encoder + adapter on the 10 s clip), one pass each, BLAS default threads",
-                    "encoder_note": "a checker, not a tuned CPU implementation: the reference's OWN torch fp32 modules take 1373 ms "
-                                    "(ViT + projector) / 349 ms (Whale) on 8 cores of the build container "
-                                    "(profiles/r02_reference_cpu_timing.json) — 8.6x / 14x faster than this restatement"})
+        t_v, t_a = [], []
+        with _torch.no_grad():
+            for _ in range(2):                                     # second pass: pages touched, thread pool up
+                t0 = time.perf_counter()
+                ot.projector(sd, ot.internvit_tower(sd, cfg.vision, request["pixel_values"][:1]))
+                t_v.append(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                ot.whale_encoder(sd, cfg.audio, request["fbank"])
+                t_a.append(time.perf_counter() - t0)
+        out.update({"vit_projector_ms": round(min(t_v) * 1e3, 1), "audio_encoder_ms": round(min(t_a) * 1e3, 1),
+                    "encoder_cores": int(_torch.get_num_threads()),
+                    "encoder_sample": "torch CPU fp32 restatement of the towers (oracle/encoders_torch.py: the operators the reference's own "
+                                      "modules run; pinned to the fp64 checker): 24-layer InternViT + projector on one 448x448 tile, Whale "
+                                      "encoder + adapter on the 10 s clip, best of two passes, torch's default thread count",
+                    "encoder_note": "the reference's OWN modules on 8 cores of the build container: 1373 ms (ViT + projector) / 349 ms (Whale) "
+                                    "(profiles/r02_reference_cpu_timing.json); this restatement there: 2208 / 727 ms"})
     return out
 
 

@@ -12,6 +12,25 @@ from scipy.special import erf
 F = np.float64  # the oracle accumulates in fp64; inputs/weights are the same fp32/bf16 values
 
 
+class precision:
+    """`with precision(np.float32): ...` runs the restatements below in another working dtype.  The CHECKER is fp64 (the default;
+    tests and smoke never change it); bench.py's cpu_baseline times the fp32 form — single-precision BLAS on the same arithmetic is
+    what a CPU implementation of the reference's fp32 modules runs, the fp64 form is 2-3x slower for no reason a baseline should carry."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global F
+        self.prev, F = F, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global F
+        F = self.prev
+        return False
+
+
 def layernorm(x, w, b, eps):
     mu = x.mean(-1, keepdims=True)
     var = ((x - mu) ** 2).mean(-1, keepdims=True)
@@ -40,17 +59,17 @@ def internvit_embeddings(sd, v, pix):
     ps = v.patch_size
     gh, gw = Hh // ps, Ww // ps
     assert gh == gw == v.grid, "pos-embed interpolation not restated (identity case only)"
-    w = sd[P + "patch_embedding.weight"].astype(F).reshape(v.hidden_size, -1)
-    patches = pix.astype(F).reshape(n, 3, gh, ps, gw, ps).transpose(0, 2, 4, 1, 3, 5).reshape(n, gh * gw, -1)
-    pe = patches @ w.T + sd[P + "patch_embedding.bias"].astype(F)
-    cls = np.broadcast_to(sd[P + "class_embedding"].astype(F), (n, 1, v.hidden_size))
-    return np.concatenate([cls, pe], 1) + sd[P + "position_embedding"].astype(F)
+    w = sd[P + "patch_embedding.weight"].astype(F, copy=False).reshape(v.hidden_size, -1)
+    patches = pix.astype(F, copy=False).reshape(n, 3, gh, ps, gw, ps).transpose(0, 2, 4, 1, 3, 5).reshape(n, gh * gw, -1)
+    pe = patches @ w.T + sd[P + "patch_embedding.bias"].astype(F, copy=False)
+    cls = np.broadcast_to(sd[P + "class_embedding"].astype(F, copy=False), (n, 1, v.hidden_size))
+    return np.concatenate([cls, pe], 1) + sd[P + "position_embedding"].astype(F, copy=False)
 
 
 def internvit_layer(sd, v, l, x):
     """InternVisionEncoderLayer.forward (:237-253) with _naive_attn (:158-177) and InternMLP (:213-217)."""
     p = f"model.vision_tower.vision_tower.encoder.layers.{l}."
-    g = lambda k: sd[p + k].astype(F)
+    g = lambda k: sd[p + k].astype(F, copy=False)
     n, N, C = x.shape
     nh = v.num_attention_heads
     d = C // nh
@@ -93,7 +112,7 @@ def internvit_tower(sd, v, pix, want_layers=False):
 
 def projector(sd, feats):
     """mlp2x_gelu — vita/model/multimodal_projector/builder.py:154-168: Linear, GELU, Linear."""
-    g = lambda k: sd["model.mm_projector." + k].astype(F)
+    g = lambda k: sd["model.mm_projector." + k].astype(F, copy=False)
     return gelu(feats @ g("0.weight").T + g("0.bias")) @ g("2.weight").T + g("2.bias")
 
 
@@ -137,11 +156,11 @@ def whale_encoder(sd, a, feats, length=None, chunk=0, left=-1, want_layers=False
     feats [T, 80] fp32.  Full attention unless chunk > 0 (hazard H1: the reference's random
     dynamic-chunk mask is pinned off; an explicit (chunk, left) mask is supported)."""
     A = "model.audio_encoder."
-    g = lambda k: sd[A + k].astype(F)
+    g = lambda k: sd[A + k].astype(F, copy=False)
     T = feats.shape[0]
     length = T if length is None else int(length)
     # whaleEncoder.forward — module/encoder/encoder.py:140-147: pad mask, GlobalCMVN (cmvn.py:29-32)
-    x = (feats.astype(F) - g("encoder.global_cmvn.mean")) * g("encoder.global_cmvn.istd")
+    x = (feats.astype(F, copy=False) - g("encoder.global_cmvn.mean")) * g("encoder.global_cmvn.istd")
     mask = np.arange(T) < length
     # Conv2dSubsampling4.forward — module/component/subsampling.py:38-43
     c = "encoder.enc.0.core."
@@ -166,7 +185,7 @@ def whale_encoder(sd, a, feats, length=None, chunk=0, left=-1, want_layers=False
     y = y * math.sqrt(C)                                    # RelPositionalEncoding.forward — attention.py:100-111
     if dbg is not None:
         dbg["embed"] = y.copy()
-    pos = sinusoid_pe(T2, C).astype(F)
+    pos = sinusoid_pe(T2, C).astype(F, copy=False)
     nh = a.num_attention_heads
     dk = C // nh
     layers = []

@@ -85,7 +85,7 @@ def test_real_width_one_layer(dev):
     _run(dev, cfg, S=48, n_new=6, seed=5)
 
 
-@pytest.mark.parametrize("knob,value", [("prefill_attn_gemm", 1), ("prefill_fuse_rows", 0), ("attn_impl", 2), ("attn_presplit", 1)])
+@pytest.mark.parametrize("knob,value", [("prefill_attn_gemm", 1), ("prefill_fuse_rows", 0), ("attn_impl", 2), ("attn_presplit", 1), ("attn_fa", 2), ("attn_fa", 0)])
 def test_alternative_paths(dev, knob, value):
     """the non-default code paths a caller can still reach stay correct: the general GEMM kernel under the attention
     projections (the automatic fallback for geometries the streaming kernel does not take), the separate slab-sum / combine /
@@ -95,7 +95,7 @@ def test_alternative_paths(dev, knob, value):
     cfg = VitaConfig.tiny()
     cfg.text = TextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
                           intermediate_size=1024, num_local_experts=8, vocab_size=2000)
-    default = {"prefill_attn_gemm": 0, "prefill_fuse_rows": 1, "attn_impl": 0, "attn_presplit": 0}[knob]
+    default = {"prefill_attn_gemm": 0, "prefill_fuse_rows": 1, "attn_impl": 0, "attn_presplit": 0, "attn_fa": 1}[knob]
     _lib.tune(knob, value)
     try:
         _run(dev, cfg, S=200, n_new=8, seed=9)

@@ -109,3 +109,24 @@ def test_live_whale_padded_batch_vs_reference():
         assert mask.tolist() == rmask.tolist()
         # rows the reference marks valid must agree; padded rows are whatever the adapter makes of zeros in both
         assert_close(f"padded whale clip {b}", z[rmask], ref["inputs_embeds"][b].numpy()[rmask], atol=5e-6)
+
+
+def test_torch_encoder_baseline_matches_the_checker():
+    """bench.py's cpu_baseline times oracle/encoders_torch.py (torch CPU fp32: the operators the reference's modules run) for the
+    encoder legs; it must compute what the fp64 checker (oracle/encoders.py, itself pinned to the reference's modules above) computes:
+    tiny towers, two images, a 101-frame clip."""
+    import torch
+    from oracle import encoders as oe, encoders_torch as ot
+    from vita_amd.checkpoint import synth_state_dict
+    from vita_amd.config import VitaConfig
+    cfg = VitaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=1, parts=("vision", "audio"))
+    rng = np.random.default_rng(0)
+    img = cfg.vision.patch_size * cfg.vision.grid
+    pix = rng.standard_normal((2, 3, img, img)).astype(np.float32)
+    fb = rng.standard_normal((101, 80)).astype(np.float32)
+    with torch.no_grad():
+        got_v = ot.projector(sd, ot.internvit_tower(sd, cfg.vision, pix)).numpy()
+        got_a = ot.whale_encoder(sd, cfg.audio, fb).numpy()
+    assert_close("torch ViT + projector vs fp64 checker", got_v, oe.projector(sd, oe.internvit_tower(sd, cfg.vision, pix)), atol=2e-6)
+    assert_close("torch Whale + adapter vs fp64 checker", got_a, oe.whale_encoder(sd, cfg.audio, fb)[0], atol=5e-6)

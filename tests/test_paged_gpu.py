@@ -20,9 +20,11 @@ from vita_amd.config import VitaConfig
 pytestmark = pytest.mark.gpu
 
 
-def _setup(dev, lens, n_new, seed=0, pool=1024, max_seqs=4, max_new=None):
+def _setup(dev, lens, n_new, seed=0, pool=1024, max_seqs=4, max_new=None, text=None):
     from vita_amd.engine import MixtralEngine
     cfg = VitaConfig.tiny()
+    if text is not None:
+        cfg.text = text
     sd = synth_state_dict(cfg, seed=seed, parts=("text",))
     rng = np.random.default_rng(seed + 7)
     orc = om.MixtralOracle(sd, cfg.text)
@@ -44,11 +46,25 @@ def _ids(eng, s, n):
     return eng.seq_tokens(s)[:n].tolist()
 
 
-def test_two_interleaved_sequences_match_oracle(dev):
+@pytest.mark.parametrize("flash", [False, True])
+def test_two_interleaved_sequences_match_oracle(dev, flash):
     """A (120 tokens) starts, decodes a little, B (70 tokens) arrives: B's pages land BETWEEN A's, then both advance in
-    batched iterations across page boundaries (A crosses 128, B crosses 64 -> wait, 70 > 64: B crosses 128 never; A does)."""
+    batched iterations across page boundaries (A crosses 128, B crosses 64 -> wait, 70 > 64: B crosses 128 never; A does).
+    flash: the released 4 : 1 head grouping with the flash-form prefill attention forced (k_attn_fa through the page table)."""
+    from vita_amd import _lib
+    from vita_amd.config import TextConfig
     n_new = 24
-    _, _, eng, (A, B) = _setup(dev, [120, 70], n_new)
+    text = TextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, intermediate_size=1024,
+                      num_local_experts=8, vocab_size=2000) if flash else None
+    _lib.tune("attn_fa", 2 if flash else 1)
+    try:
+        _two_interleaved(dev, n_new, text)
+    finally:
+        _lib.tune("attn_fa", 1)
+
+
+def _two_interleaved(dev, n_new, text):
+    _, _, eng, (A, B) = _setup(dev, [120, 70], n_new, text=text)
     total = eng.pages_free()
     a = eng.seq_alloc()
     lg = eng.seq_prefill(a, A["emb"], want_logits=True)

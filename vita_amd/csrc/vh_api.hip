@@ -44,6 +44,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "batch_moe_min")) { g_tuning.batch_moe_min = value; return VH_OK; }
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
+    if (!strcmp(key, "attn_fa")) { g_tuning.attn_fa = value; return VH_OK; }
     if (!strcmp(key, "attn_presplit")) { g_tuning.attn_presplit = value; return VH_OK; }
     if (!strcmp(key, "attn_rows")) { g_tuning.attn_rows = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }

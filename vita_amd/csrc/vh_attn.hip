@@ -593,6 +593,309 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 }
 
+
+// ---- flash form of the bf16 x 3 kernel (r04): K / V tiles shared by the four waves of a block through LDS ------------------------
+// The direct kernel above has every wave pull its keys' K and V rows from L2 in FRAGMENT shape (16 rows x 32 B per wave
+// instruction) and convert them to bf16 hi/lo itself: the ViT launch moves 277 MB through the vector-memory path at ~6 TB/s
+// and is bound there (and on the conversions), not on either pipe.  Here a block is
+//   D = 64 : one head x 64 RT query rows — wave w owns rows q0 + 16 RT w ..;
+//   D = 128: one KV head x 16 RT query rows x its FOUR query heads (Mixtral's 4 : 1 GQA) — wave w = head 4 hk + w;
+// and every 64-key tile of K and V is read from global ONCE per block in whole rows (4 threads per K row, 16 threads per V row:
+// full 128-byte lines), converted ONCE by the thread that loaded it, and laid in LDS as MFMA-ready bf16 hi/lo images:
+//   K planes [half][64 keys][128 B], 16-byte chunks XOR-swizzled by (key >> 1) & 7: the B fragment of S = Q K^T (key lr,
+//            chunk 4c + lg) is one conflict-free ds_read_b128 (the layout of vh_gemm.hip's operand tiles);
+//   V planes TRANSPOSED [rho(col)][64 keys] with rho(d) = 16 (d % NC) + d / NC: row 16 t + lr holds column lr NC + t, so the
+//            B fragment of O += P V (keys 32 s + 8 lg ..+8 of the lane's column of output tile t) is one ds_read_b128 and the
+//            output keeps the direct kernel's lane -> NC consecutive columns mapping (16-byte stores).  The transposition is
+//            free: v_cvt_pk pairs two registers, here the same column of two consecutive keys.
+// Two LDS buffers, register staging one tile ahead: the loads of tile t + 2 are issued behind the barrier that ends tile t, the
+// conversion + LDS writes of tile t + 1 run at the end of tile t into the buffer last read in tile t - 1: ONE barrier per 64 keys.
+// The arithmetic per 32-key half tile (products, softmax, accumulation order) is the direct kernel's; only the partition of the
+// keys among waves differs (none here: a wave sees all keys of its rows in order, no merge).
+template <int D, int RT, int MODE, int KS>
+__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(KS == 2 || (D == 64 && RT == 1) ? 2 : 1, KS == 2 || (D == 64 && RT == 1) ? 2 : 1)))
+void k_attn_fa(const VhAttnArgs p) {
+    // KS = 2: EIGHT waves — the four row groups (heads) twice: wave group kg takes the 32-key half kg of every 64-key tile and the two
+    // groups merge (m, l, O) once at the end, like the direct kernel's key groups.  One wave per SIMD (KS = 1) leaves every dependent
+    // latency of a half tile (fragment reads -> MFMA chain -> DPP reductions -> patch -> MFMA chain) exposed; two per SIMD overlap
+    // one group's softmax with the other's products.  Staging is split by ROLE: group 0 loads / converts / transposes V, group 1 K.
+    constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
+    constexpr int NC = D / 16, VQ = NC / 4, C32 = D / 32;
+    constexpr int PL = 64 * D * 2;                 // bytes of one plane of one 64-key tile
+    constexpr int NKR = D / 16, NVB = D / 64;      // float4s of a thread's quarter K row; 4 x 4 blocks of V per thread
+    constexpr int NST = KS == 2 ? (NKR > 4 * NVB ? NKR : 4 * NVB) : NKR + 4 * NVB;
+    constexpr int MGW = RT * (8 + NC * 4);
+    static_assert(KS == 1 || 4 * 64 * MGW * 4 <= 8 * PL, "merge area aliases the K / V buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * PL + 4 * KS * RT * 16 * AT_PSTR3 * 4];
+    float* patches = reinterpret_cast<float*>(lds + 8 * PL);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int rg = w & 3, kg = w >> 2;                        // row group (d = 64) / head of the KV group (d = 128); key half
+    const int ftid = tid & 255;                               // index inside the staging role
+    const int lr = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.z;
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;      // heaviest (latest rows under the causal mask) blocks first
+    int h, hk, q0;
+    if (D == 64) { h = blockIdx.y; hk = h / (p.Hq / p.Hkv); q0 = qb * (64 * RT) + 16 * RT * rg; }
+    else { hk = blockIdx.y; h = hk * 4 + rg; q0 = qb * (16 * RT); }
+    const int qblk0 = D == 64 ? qb * (64 * RT) : q0;                       // first row of the BLOCK
+    const int qblk1 = min(qblk0 + (D == 64 ? 64 * RT : 16 * RT), p.Sq) - 1; // last row of the block
+
+    const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
+    const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
+    const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
+
+    const float qscale = p.scale * 1.44269504088896340736f;
+    bf16x8 qh[RT][C32], ql[RT][C32];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int q = min(q0 + 16 * rt + lr, p.Sq - 1);
+#pragma unroll
+        for (int c = 0; c < C32; ++c) {
+            const float* src = Qb + (size_t)q * p.ldq + 32 * c + 8 * lg;
+            at_split8(*reinterpret_cast<const f32x4*>(src) * qscale, *reinterpret_cast<const f32x4*>(src + 4) * qscale, qh[rt][c], ql[rt][c]);
+        }
+    }
+
+    const int kend = min(p.Sk, p.klen);
+    int kloop = kend;                                                       // keys any row of the BLOCK can see
+    if (CAUSAL) kloop = min(kloop, qblk1 + p.q_off + 1);
+    const int ntiles = (kloop + 63) >> 6;
+    // keys this WAVE's rows can see (none when all its rows lie past Sq: it only helps staging)
+    const int wave_kmax = q0 >= p.Sq ? 0 : (CAUSAL ? min(kend, min(q0 + 16 * RT - 1, p.Sq - 1) + p.q_off + 1) : kend);
+
+    float m[RT][4], l[RT][4];
+    f32x4 o[RT][NC];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m[rt][r] = -INFINITY; l[rt][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NC; ++t) o[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- staging: thread -> (key, quarter row) of K, (4 keys x 4 columns) blocks of V; KS = 2: K by wave group 1, V by group 0 ----
+    const unsigned ldk = (unsigned)p.ldk, ldv = (unsigned)p.ldv;
+    const int klast = p.Sk - 1;
+    const int fk_key = ftid >> 2, fk_q = ftid & 3, fv_kg = ftid >> 4, fv_cg = ftid & 15;
+    const bool do_k = KS == 1 || kg == 1, do_v = KS == 1 || kg == 0;        // (wave-uniform)
+    constexpr int VOFF = KS == 2 ? 0 : NKR;                                  // V pieces share the K registers when the roles are split
+    f32x4 st[NST];
+    auto row_of = [&](int key) __attribute__((always_inline)) {
+        key = min(key, klast);
+        if (PAGED) key = p.ktable[key >> 6] * 64 + (key & 63);
+        return (unsigned)key;
+    };
+    auto load_tile = [&](int kt0) __attribute__((always_inline)) {
+        if (do_k) {
+            const char* src = reinterpret_cast<const char*>(Kb) + (__umul24(row_of(kt0 + fk_key), ldk) + fk_q * (D / 4)) * 4u;
+#pragma unroll
+            for (int i = 0; i < NKR; ++i) st[i] = *reinterpret_cast<const f32x4*>(src + 16 * i);
+        }
+        if (do_v) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const char* src = reinterpret_cast<const char*>(Vb) + (__umul24(row_of(kt0 + 4 * fv_kg + u), ldv) + 4 * fv_cg) * 4u;
+#pragma unroll
+                for (int bb = 0; bb < NVB; ++bb) st[VOFF + 4 * bb + u] = *reinterpret_cast<const f32x4*>(src + 256 * bb);
+            }
+        }
+    };
+    auto store_tile = [&](unsigned char* buf) __attribute__((always_inline)) {
+        unsigned char* Kh = buf; unsigned char* Kl = buf + PL; unsigned char* Vh = buf + 2 * PL; unsigned char* Vl = buf + 3 * PL;
+        if (do_k) {
+#pragma unroll
+            for (int i = 0; i < NKR / 2; ++i) {
+                bf16x8 hi, lo;
+                at_split8(st[2 * i], st[2 * i + 1], hi, lo);
+                const int gc = fk_q * (D / 32) + i;
+                const int off = (gc >> 3) * 8192 + fk_key * 128 + (((gc & 7) ^ ((fk_key >> 1) & 7)) << 4);
+                *reinterpret_cast<bf16x8*>(Kh + off) = hi;
+                *reinterpret_cast<bf16x8*>(Kl + off) = lo;
+            }
+        }
+        if (do_v) {
+#pragma unroll
+            for (int bb = 0; bb < NVB; ++bb) {
+                const int cg = fv_cg + 16 * bb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t h01, l01, h23, l23;
+                    at_split2(st[VOFF + 4 * bb + 0][j], st[VOFF + 4 * bb + 1][j], h01, l01);
+                    at_split2(st[VOFF + 4 * bb + 2][j], st[VOFF + 4 * bb + 3][j], h23, l23);
+                    const int d = 4 * cg + j;
+                    const int rho = 16 * (d % NC) + d / NC;
+                    const int off = rho * 128 + ((((fv_kg >> 1)) ^ ((rho >> 1) & 7)) << 4) + (fv_kg & 1) * 8;
+                    *reinterpret_cast<uint2*>(Vh + off) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(Vl + off) = make_uint2(l01, l23);
+                }
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        load_tile(0);
+        store_tile(lds);
+        if (ntiles > 1) load_tile(64);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* buf = lds + (t & 1) * 4 * PL;
+        const unsigned char* Kh = buf; const unsigned char* Kl = buf + PL; const unsigned char* Vh = buf + 2 * PL; const unsigned char* Vl = buf + 3 * PL;
+#pragma unroll
+        for (int s0 = 0; s0 < 2 / KS; ++s0) {
+            const int s = KS == 2 ? kg : s0;
+            const int kt0 = t * 64 + 32 * s;
+            if (kt0 >= wave_kmax) break;                              // (wave-uniform) nothing of this half tile is visible to these rows
+            // ---- S = Q K^T for the two 16-key sub-tiles ------------------------------------------------------------------------
+            f32x4 sacc[RT][2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) sacc[rt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int key = 32 * s + 16 * jt + lr;
+#pragma unroll
+                for (int c = 0; c < C32; ++c) {
+                    const int gc = 4 * c + lg;
+                    const int off = (gc >> 3) * 8192 + key * 128 + (((gc & 7) ^ ((key >> 1) & 7)) << 4);
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 a = sacc[rt][jt];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[rt][c], kh, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kl, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kh, a, 0, 0, 0);
+                        sacc[rt][jt] = a;
+                    }
+                }
+            }
+            // ---- online softmax in D layout (the direct kernel's) --------------------------------------------------------------
+            const bool full_tile = kt0 + AT_KT <= (CAUSAL ? min(kend, q0 + p.q_off + 1) : kend);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float* ps = patches + (w * RT + rt) * 16 * AT_PSTR3;
+                float alpha[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + 16 * rt + lg * 4 + r;
+                    float s0v = sacc[rt][0][r], s1v = sacc[rt][1][r];
+                    if (!full_tile) {
+                        const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;
+                        s0v = (kt0 + lr < klim) ? s0v : -INFINITY;
+                        s1v = (kt0 + 16 + lr < klim) ? s1v : -INFINITY;
+                    }
+                    const float mx = grp16_max(fmaxf(s0v, s1v));
+                    const float mn = fmaxf(m[rt][r], mx);
+                    const bool none = mn == -INFINITY;
+                    alpha[r] = none ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
+                    const float p0 = none ? 0.f : __builtin_amdgcn_exp2f(s0v - mn);
+                    const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1v - mn);
+                    l[rt][r] = l[rt][r] * alpha[r] + grp16_sum(p0 + p1);
+                    m[rt][r] = mn;
+                    ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
+                    ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
+                }
+#pragma unroll
+                for (int tt = 0; tt < NC; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[rt][tt][r] *= alpha[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- O += P V over the 32 keys -------------------------------------------------------------------------------------
+            bf16x8 ph[RT], pl[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* ps = patches + (w * RT + rt) * 16 * AT_PSTR3;
+                at_split8(*reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg),
+                          *reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg + 4), ph[rt], pl[rt]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < NC; ++tt) {
+                const int row = 16 * tt + lr;
+                const int off = row * 128 + (((4 * s + lg) ^ ((row >> 1) & 7)) << 4);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Vh + off);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Vl + off);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rt], bh, o[rt][tt], 0, 0, 0);
+                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bl, o[rt][tt], 0, 0, 0);
+                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bh, o[rt][tt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (t + 1 < ntiles) store_tile(lds + ((t + 1) & 1) * 4 * PL);      // that buffer was last read in tile t - 1: everyone is past it
+        __syncthreads();
+        if (t + 2 < ntiles) load_tile((t + 2) * 64);                        // lands under tile t + 1
+    }
+
+    // ---- KS = 2: the second key half of every row group merges into the first (every wave is past the last tile: the K / V buffers
+    // are free and hold the hand-over) ------------------------------------------------------------------------------------------------
+    if (KS == 2) {
+        float* Mg = reinterpret_cast<float*>(lds);
+        if (kg == 1) {
+            float* mg = Mg + (rg * 64 + lane) * MGW;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float* mr = mg + rt * (8 + NC * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mr[r] = m[rt][r]; mr[4 + r] = l[rt][r]; }
+#pragma unroll
+                for (int t = 0; t < NC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mr[8 + t * 4 + r] = o[rt][t][r];
+            }
+        }
+        __syncthreads();
+        if (kg == 1) return;
+        const float* mg = Mg + (rg * 64 + lane) * MGW;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float* mr = mg + rt * (8 + NC * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m2 = mr[r], l2 = mr[4 + r];
+                const float mn = fmaxf(m[rt][r], m2);
+                const float a1 = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
+                const float a2 = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+                l[rt][r] = l[rt][r] * a1 + l2 * a2;
+                m[rt][r] = mn;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) o[rt][t][r] = o[rt][t][r] * a1 + mr[8 + t * 4 + r] * a2;
+            }
+        }
+    }
+
+    float* Ob = p.O ? p.O + (size_t)b * p.bso + (size_t)h * D : nullptr;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + 16 * rt + lg * 4 + r;
+            if (q >= p.Sq) continue;
+            const float inv = (l[rt][r] > 0.f) ? 1.0f / l[rt][r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < VQ; ++j) {
+                const f32x4 v = f32x4{o[rt][4 * j][r] * inv, o[rt][4 * j + 1][r] * inv, o[rt][4 * j + 2][r] * inv, o[rt][4 * j + 3][r] * inv};
+                if (Ob) *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) = v;
+                if (p.O_hi) {
+                    uint32_t hi[2], lo[2];
+                    at_split2(v[0], v[1], hi[0], lo[0]);
+                    at_split2(v[2], v[3], hi[1], lo[1]);
+                    const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                    *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0], hi[1]);
+                    *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0], lo[1]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
@@ -626,6 +929,26 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
             if (rows >= (1L << 24) || ldmax >= (1L << 24) || ldmax < 0 || (rows * ldmax + a.d) * 4 >= (1L << 32)) mode = -1;
         }
         if (!rel && vh_tuning()->attn_impl == 0 && mode >= 0) {
+            // flash form (K / V tiles shared through LDS): d = 64 any head grouping, d = 128 with the 4 : 1 grouping it maps to its
+            // four waves; taken when its (larger) blocks still fill half the chip, or when forced (attn_fa = 2: tests)
+            const int fa = vh_tuning()->attn_fa;
+            if (fa != 0 && (a.d == 64 || a.Hq == 4 * a.Hkv)) {
+                const int rows_knob = vh_tuning()->attn_rows;
+                const long b2 = (long)((a.Sq + 127) / 128) * a.Hq * a.B;
+                const int rt = a.d == 128 ? 1 : (rows_knob == 32 ? 2 : (rows_knob == 16 ? 1 : (b2 >= 2L * vh_num_cus() ? 2 : 1)));
+                const dim3 gf(a.d == 64 ? (a.Sq + 64 * rt - 1) / (64 * rt) : (a.Sq + 15) / 16, a.d == 64 ? a.Hq : a.Hkv, a.B);
+                if (fa == 2 || (long)gf.x * gf.y * gf.z * 2 >= vh_num_cus()) {
+#define FA(DD, RR, MM, KK) hipLaunchKernelGGL((k_attn_fa<DD, RR, MM, KK>), gf, dim3(256 * KK), 0, st, a)
+#define FA_MODES(DD, RR, KK) do { if (mode == 0) FA(DD, RR, 0, KK); else if (mode == 1) FA(DD, RR, 1, KK); else FA(DD, RR, 2, KK); } while (0)
+                    const bool one = want == 1;               // attn_ksplit = 1: one wave group (4 waves); default two (8 waves)
+                    if (a.d == 128) { if (one) FA_MODES(128, 1, 1); else FA_MODES(128, 1, 2); }
+                    else if (rt == 2) { if (one) FA_MODES(64, 2, 1); else FA_MODES(64, 2, 2); }
+                    else { if (one) FA_MODES(64, 1, 1); else FA_MODES(64, 1, 2); }
+#undef FA_MODES
+#undef FA
+                    return 0;
+                }
+            }
             const dim3 g32((a.Sq + 31) / 32, a.Hq, a.B);
             // 32 rows per wave (K / V loaded and converted once for two row tiles): 57 against 63 us on the ViT once the loop
             // was VALU-lean; only when the launch still gives every SIMD two waves

@@ -248,6 +248,9 @@ __device__ __forceinline__ void for_each_tile(const VhGemmPsArgs& p, F&& f) {
     // the LARGEST experts' tiles and XCD 7 the smallest: the launch lasts as long as XCD 0.  Position q of a block inside a round
     // keeps the pairs (q, q ^ 1) — the two m-tiles of one weight tile, or the two halves of an M-split tail tile — on one XCD.
     const int stride = 8 * nb;
+    // (r04: giving XCD x the contiguous chunk [x nb, (x + 1) nb) of every round instead — one expert's activation planes per XCD
+    // per round — changed neither the time (583 vs 584 us uniform, 635-649 vs 634-636 skewed) nor FETCH_SIZE (2.436 vs 2.431 GB per
+    // launch): profiles/r04_sched_map_ab.txt.)
     const int jj = (nb & 1) ? (int)blockIdx.x : (((j >> 1) << 4) | (xcd << 1) | (j & 1));
     const int g0 = 0, Tx = T;
 #else
