@@ -37,7 +37,7 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
-/* Kernel-variant knobs (15 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_presplit", "attn_rows", "attn_ksplit",
+/* Kernel-variant knobs (15 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
  * "prefill_attn_gemm", "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse",
  * "comm_allow_coarse"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
  * measured-best variants, ids are identical across variants.  Unknown keys (e.g. of variants removed in r04) return VH_E_ARG. */
@@ -113,8 +113,6 @@ typedef struct {
     int B, Hq, Hkv, Sq, Sk, d;
     int causal, q_off, klen, chunk, left;
     float scale;
-    void* ws; size_t ws_bytes;   /* optional scratch (16-byte aligned, B * Hkv * roundup(Sk, 32) * d * 8 bytes): the plain / causal
-                                  * kernels then convert K and V to bf16 hi/lo planes ONCE per call instead of in every wave */
 } vh_attn_args;
 int vh_attention(const vh_attn_args* args, void* stream);
 
@@ -140,7 +138,6 @@ typedef struct {
     int act; float eps;
     const float* P; long ldp; const float* bias_u; const float* bias_v; int klen, chunk, left;
     float* qkv; float* attn; float* hmid; float* mid; float* ws; size_t ws_bytes;
-    void* attn_ws; size_t attn_ws_bytes;   /* optional: vh_attn_args.ws for the block's attention */
 } vh_encoder_layer_args;
 int vh_encoder_layer(const vh_encoder_layer_args* args, void* stream);
 

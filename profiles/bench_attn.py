@@ -12,6 +12,7 @@ from vita_amd import _lib, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--rounds", type=int, default=2)
+ap.add_argument("--only-default", action="store_true", help="ablated builds (VITA_AMD_LIB): time the default variant only, no reference check")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -62,8 +63,9 @@ for S in (552, 2344):
     cases[f"prefill_S{S}"] = (fn, out2, ref_attn(q2.reshape(S, nq, d2).permute(1, 0, 2), kc[:, :S], vc[:, :S], d2 ** -0.5, True), S)
 
 DEFAULTS = {"attn_impl": 0, "attn_ksplit": 0, "attn_rows": 0, "attn_fa": 1}
-VARIANTS = [{}, {"attn_fa": 0}, {"attn_fa": 2, "attn_rows": 16}, {"attn_fa": 2, "attn_rows": 32}, {"attn_fa": 2, "attn_rows": 16, "attn_ksplit": 1},
-            {"attn_fa": 2, "attn_rows": 32, "attn_ksplit": 1}]
+VARIANTS = [{}, {"attn_fa": 0}, {"attn_fa": 0, "attn_rows": 16}, {"attn_fa": 0, "attn_ksplit": 2}, {"attn_impl": 2}]
+if args.only_default:
+    VARIANTS = [{}]
 for rnd in range(args.rounds):
     for v in VARIANTS:
         for k, val in {**DEFAULTS, **v}.items():
@@ -71,7 +73,7 @@ for rnd in range(args.rounds):
         row = {"round": rnd, "variant": v or "default"}
         for name, (fn, out, ref, rows) in cases.items():
             row[name + "_us"] = timeit(fn)
-            if rnd == 0:
+            if rnd == 0 and not args.only_default:
                 out.fill_(float("nan"))
                 fn()
                 row[name + "_err"] = float("%.2e" % float(torch.nan_to_num((out[:rows].double() - ref).abs(), nan=1e30).max()))

@@ -19,8 +19,8 @@ packed = synth_mixtral_device(cfg, dev, seed=0)
 rng = np.random.default_rng(1)
 ids = rng.integers(3, cfg.text.vocab_size, size=150).tolist()
 emb = lambda i: packed["embed"][torch.as_tensor(i, device=dev)].float()
-DEF = {"attn_impl": 0, "prefill_fuse_rows": 1, "attn_presplit": 0, "ps_cfg": -1}
-for v in ({}, {"attn_impl": 2}, {"prefill_fuse_rows": 0}, {"attn_presplit": 1}, {"ps_cfg": 1}):
+DEF = {"attn_impl": 0, "prefill_fuse_rows": 1, "attn_fa": 1, "ps_cfg": -1}
+for v in ({}, {"attn_impl": 2}, {"prefill_fuse_rows": 0}, {"attn_fa": 0}, {"ps_cfg": 1}):
     for k, val in {**DEF, **v}.items():
         _lib.tune(k, val)
     eng = MixtralEngine(cfg, packed, dev, max_ctx=512, max_prefill=256, max_new=8)

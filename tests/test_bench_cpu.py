@@ -36,7 +36,7 @@ def test_prefill_kernel_roofline_field():
     assert abs(r["avg_launch_us"] - 600.0) < 1e-6 and r["samples"] == 96
     assert abs(r["achieved"] - r["bytes_per_launch"] / 600e-6 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
     assert 0.2 < r["frac"] < 1.0 and 150 < r["mfma_floor_us"] < 250
-    assert r["traffic"] is not None and 0.9 < r["traffic"] / (2 * E * I * H * 2) < 1.3 and r["traffic_source"].startswith("profiles/")
+    assert r["traffic"] is not None and 0.9 < r["traffic"] / (2 * E * I * H * 2) < 1.4 and r["traffic_source"].startswith("profiles/")
     assert bench.prefill_kernel_roofline(S, E, I // 8, H, L, 0.0, 0, world=8)["traffic"] is None      # TP: no static traffic figure
     assert bench.prefill_kernel_roofline(S, E, I, H, L, 0.0, 0)["achieved"] is None                   # no samples -> no claim
 

@@ -251,7 +251,7 @@ def test_removed_knobs_are_rejected():
         _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4}.get(key, 0))
 
 
-KNOBS_R04 = ("batch_moe_min", "batch_decode", "attn_impl", "attn_presplit", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
+KNOBS_R04 = ("batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
              "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse", "comm_allow_coarse")
 
 

@@ -85,17 +85,17 @@ def test_real_width_one_layer(dev):
     _run(dev, cfg, S=48, n_new=6, seed=5)
 
 
-@pytest.mark.parametrize("knob,value", [("prefill_attn_gemm", 1), ("prefill_fuse_rows", 0), ("attn_impl", 2), ("attn_presplit", 1), ("attn_fa", 2), ("attn_fa", 0)])
+@pytest.mark.parametrize("knob,value", [("prefill_attn_gemm", 1), ("prefill_fuse_rows", 0), ("attn_impl", 2), ("attn_fa", 2), ("attn_fa", 0)])
 def test_alternative_paths(dev, knob, value):
     """the non-default code paths a caller can still reach stay correct: the general GEMM kernel under the attention
     projections (the automatic fallback for geometries the streaming kernel does not take), the separate slab-sum / combine /
     plane-split launches (what runs under tensor parallelism; default on one rank: folded into the norm and attention kernels),
-    the fp32-MFMA attention kernel, the K / V plane pre-pass.  (r04 removed the variants that had lost their measurements.)"""
+    the fp32-MFMA attention kernel, the flash-form prefill attention forced at this small geometry (8 : 2 heads) and switched off.  (r04 removed the variants that had lost their measurements.)"""
     from vita_amd import _lib
     cfg = VitaConfig.tiny()
     cfg.text = TextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
                           intermediate_size=1024, num_local_experts=8, vocab_size=2000)
-    default = {"prefill_attn_gemm": 0, "prefill_fuse_rows": 1, "attn_impl": 0, "attn_presplit": 0, "attn_fa": 1}[knob]
+    default = {"prefill_attn_gemm": 0, "prefill_fuse_rows": 1, "attn_impl": 0, "attn_fa": 1}[knob]
     _lib.tune(knob, value)
     try:
         _run(dev, cfg, S=200, n_new=8, seed=9)

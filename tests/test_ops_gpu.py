@@ -336,24 +336,21 @@ def test_attention_vit_like(dev, rows, N, groups):
     B, H, d = 2, 3, 64
     _lib.tune("attn_rows", rows)
     _lib.tune("attn_ksplit", groups)
-    _lib.tune("attn_presplit", 1 if N != 1025 else 0)      # the scratch it passes is used: K / V planes by the pre-pass (off by default)
     try:
         _attention_vit_like(dev, rng, B, H, N, d)
     finally:
         _lib.tune("attn_rows", 0)
         _lib.tune("attn_ksplit", 0)
-        _lib.tune("attn_presplit", 0)
 
 
 def _attention_vit_like(dev, rng, B, H, N, d):
     from vita_amd import ops
-    ws = torch.empty(ops.attention_ws_bytes(B, H, N, d), dtype=torch.uint8, device=dev)   # K / V planes by the pre-pass when N > 64
     qkv = rng.standard_normal((B * N, 3 * H * d), dtype=np.float32)
     t = _dev(qkv, dev)
     out = torch.empty((B * N, H * d), dtype=torch.float32, device=dev)
     ops.attention(t, t[:, H * d:], t[:, 2 * H * d:], out, B=B, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=3 * H * d, hsq=d,
                   ldk=3 * H * d, hsk=d, ldv=3 * H * d, hsv=d, ldo=H * d, bsq=N * 3 * H * d, bsk=N * 3 * H * d,
-                  bso=N * H * d, scale=d ** -0.5, ws=ws)
+                  bso=N * H * d, scale=d ** -0.5)
     for b in range(B):
         r = qkv[b * N:(b + 1) * N].reshape(N, 3, H, d).transpose(1, 2, 0, 3)
         ref = _attn_ref(r[0], r[1], r[2], d ** -0.5)
@@ -404,64 +401,34 @@ def test_attention_key_groups(dev, groups, impl):
         _lib.tune("attn_impl", 0)
 
 
-@pytest.mark.parametrize("groups", [0, 1])
-@pytest.mark.parametrize("rows", [16, 32])
-@pytest.mark.parametrize("N,klen", [(77, 77), (333, 301), (1025, 1025), (64, 64), (129, 65)])
-def test_attention_flash_form_d64(dev, rows, N, klen, groups):
-    """k_attn_fa forced (attn_fa = 2), d = 64: 2 images x 3 heads, packed qkv rows, key pad mask, 64 / 128 query rows per block
-    (tails in the q blocks, in the 64-key tiles and in their 32-key halves; N = 1025: one live row in the last block, whose other
-    waves only help staging); groups: 0 = eight waves (two key halves merged at the end, the default), 1 = four waves."""
+@pytest.mark.parametrize("nq,nkv,causal", [(8, 2, True), (4, 1, True), (8, 2, False)])
+@pytest.mark.parametrize("Sq,pos0", [(70, 0), (33, 45), (1, 99), (150, 170), (64, 64), (129, 0)])
+def test_attention_flash_form(dev, nq, nkv, causal, Sq, pos0):
+    """k_attn_fa forced (attn_fa = 2; by default it runs when its blocks fill half the chip): d = 128, 4 : 1 head grouping (one block
+    = the four query heads of a KV head on the same 16 rows, eight waves = heads x two 32-key halves merged at the end), causal with
+    a query offset (chunked prefill) or a key pad mask, K / V in cache layout [nkv][max_ctx][d]; tails in the 16-row blocks, the
+    64-key tiles and their halves; rows past the context hold NaNs and must never reach a product."""
     from vita_amd import _lib, ops
-    rng = np.random.default_rng(81 + N)
-    B, H, d = 2, 3, 64
-    _lib.tune("attn_fa", 2)
-    _lib.tune("attn_rows", rows)
-    _lib.tune("attn_ksplit", groups)
-    try:
-        qkv = rng.standard_normal((B * N, 3 * H * d), dtype=np.float32)
-        t = _dev(qkv, dev)
-        out = torch.full((B * N, H * d), float("nan"), dtype=torch.float32, device=dev)
-        ops.attention(t, t[:, H * d:], t[:, 2 * H * d:], out, B=B, Hq=H, Hkv=H, Sq=N, Sk=N, d=d, ldq=3 * H * d, hsq=d,
-                      ldk=3 * H * d, hsk=d, ldv=3 * H * d, hsv=d, ldo=H * d, bsq=N * 3 * H * d, bsk=N * 3 * H * d,
-                      bso=N * H * d, scale=d ** -0.5, klen=klen)
-        mask = np.broadcast_to(np.arange(N)[None, :] < klen, (N, N))
-        for b in range(B):
-            r = qkv[b * N:(b + 1) * N].reshape(N, 3, H, d).transpose(1, 2, 0, 3)
-            assert_close(f"flash d64 b{b}", to_np(out[b * N:(b + 1) * N]), _attn_ref(r[0], r[1], r[2], d ** -0.5, mask), atol=ATTN_X3_ATOL)
-    finally:
-        _lib.tune("attn_fa", 1)
-        _lib.tune("attn_rows", 0)
-        _lib.tune("attn_ksplit", 0)
-
-
-@pytest.mark.parametrize("groups", [0, 1])
-@pytest.mark.parametrize("d,nq,nkv", [(128, 8, 2), (64, 4, 2), (128, 4, 1)])
-@pytest.mark.parametrize("Sq,pos0", [(70, 0), (33, 45), (1, 99), (150, 170), (64, 64)])
-def test_attention_flash_form_causal_gqa(dev, d, nq, nkv, Sq, pos0, groups):
-    """k_attn_fa forced, causal with a query offset (chunked prefill), K / V in cache layout [nkv][max_ctx][d]: d = 128 with the
-    4 : 1 grouping (one block = the four query heads of a KV head on the same 16 rows), d = 64 with a 2 : 1 grouping (one head per
-    block, four waves on consecutive row tiles: different causal limits per wave)."""
-    from vita_amd import _lib, ops
-    rng = np.random.default_rng(10 + Sq + d)
-    max_ctx = 400
+    rng = np.random.default_rng(10 + Sq + nq)
+    d, max_ctx = 128, 400
     Sk = pos0 + Sq
+    klen = Sk if causal else max(1, Sk - 37)
     q = rng.standard_normal((Sq, nq * d), dtype=np.float32)
     kc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
     vc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
-    kc[:, Sk:] = np.nan                                        # rows past the context must never reach a product
+    kc[:, Sk:] = np.nan
     vc[:, Sk:] = np.nan
     out = torch.full((Sq, nq * d), float("nan"), dtype=torch.float32, device=dev)
     _lib.tune("attn_fa", 2)
-    _lib.tune("attn_ksplit", groups)
     try:
         ops.attention(_dev(q, dev), _dev(kc, dev), _dev(vc, dev), out, B=1, Hq=nq, Hkv=nkv, Sq=Sq, Sk=Sk, d=d, ldq=nq * d,
-                      hsq=d, ldk=d, hsk=max_ctx * d, ldv=d, hsv=max_ctx * d, ldo=nq * d, scale=d ** -0.5, causal=True, q_off=pos0)
+                      hsq=d, ldk=d, hsk=max_ctx * d, ldv=d, hsv=max_ctx * d, ldo=nq * d, scale=d ** -0.5, causal=causal, q_off=pos0,
+                      klen=klen)
     finally:
         _lib.tune("attn_fa", 1)
-        _lib.tune("attn_ksplit", 0)
-    mask = np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]
+    mask = (np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]) if causal else np.broadcast_to(np.arange(Sk)[None, :] < klen, (Sq, Sk))
     ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), kc[:, :Sk], vc[:, :Sk], d ** -0.5, mask)
-    assert_close(f"flash causal gqa d={d} Sq={Sq} pos0={pos0}", to_np(out), ref, atol=ATTN_X3_ATOL)
+    assert_close(f"flash form nq={nq} causal={causal} Sq={Sq} pos0={pos0}", to_np(out), ref, atol=ATTN_X3_ATOL)
 
 
 def test_attention_big_scores(dev):
@@ -480,11 +447,10 @@ def test_attention_big_scores(dev):
     assert_close("attn big scores", to_np(out), _attn_ref(sp(q), sp(k), sp(v), d ** -0.5), atol=4 * ATTN_X3_ATOL)   # scores x 9
 
 
-@pytest.mark.parametrize("presplit", [False, True])
 @pytest.mark.parametrize("Sq,pos0", [(70, 0), (33, 45), (1, 99)])
-def test_attention_causal_gqa(dev, Sq, pos0, presplit):
-    """Mixtral prefill shape: 4 q-heads / 2 kv-heads x 128, K/V in cache layout [nkv][max_ctx][128]; with and without the
-    scratch that lets the kernel convert K / V to bf16 planes once per call (k_attn_prep)."""
+def test_attention_causal_gqa(dev, Sq, pos0):
+    """Mixtral prefill shape on the direct kernel: 4 q-heads / 2 kv-heads x 128 (a 2 : 1 grouping the flash form does not take),
+    K/V in cache layout [nkv][max_ctx][128]."""
     from vita_amd import _lib, ops
     rng = np.random.default_rng(10 + Sq)
     nq, nkv, d, max_ctx = 4, 2, 128, 160
@@ -493,12 +459,9 @@ def test_attention_causal_gqa(dev, Sq, pos0, presplit):
     kc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
     vc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
     out = torch.empty((Sq, nq * d), dtype=torch.float32, device=dev)
-    ws = torch.empty(ops.attention_ws_bytes(1, nkv, Sk, d), dtype=torch.uint8, device=dev) if presplit else None
-    _lib.tune("attn_presplit", int(presplit))
     ops.attention(_dev(q, dev), _dev(kc, dev), _dev(vc, dev), out, B=1, Hq=nq, Hkv=nkv, Sq=Sq, Sk=Sk, d=d, ldq=nq * d,
                   hsq=d, ldk=d, hsk=max_ctx * d, ldv=d, hsv=max_ctx * d, ldo=nq * d, scale=d ** -0.5, causal=True,
-                  q_off=pos0, ws=ws)
-    _lib.tune("attn_presplit", 0)
+                  q_off=pos0)
     mask = np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]
     ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), kc[:, :Sk], vc[:, :Sk], d ** -0.5, mask)
     assert_close(f"attn causal gqa Sq={Sq} pos0={pos0}", to_np(out), ref, atol=ATTN_X3_ATOL)

@@ -52,7 +52,6 @@ class AttnArgs(C.Structure):
         ("B", c_int), ("Hq", c_int), ("Hkv", c_int), ("Sq", c_int), ("Sk", c_int), ("d", c_int),
         ("causal", c_int), ("q_off", c_int), ("klen", c_int), ("chunk", c_int), ("left", c_int),
         ("scale", c_float),
-        ("ws", c_void_p), ("ws_bytes", c_size_t),
     ]
 
 
@@ -69,7 +68,6 @@ class EncoderLayerArgs(C.Structure):
         ("act", c_int), ("eps", c_float),
         ("P", c_void_p), ("ldp", c_long), ("bias_u", c_void_p), ("bias_v", c_void_p), ("klen", c_int), ("chunk", c_int), ("left", c_int),
         ("qkv", c_void_p), ("attn", c_void_p), ("hmid", c_void_p), ("mid", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t),
-        ("attn_ws", c_void_p), ("attn_ws_bytes", c_size_t),
     ]
 
 

@@ -45,7 +45,6 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "batch_decode")) { g_tuning.batch_decode = value; return VH_OK; }
     if (!strcmp(key, "attn_impl")) { g_tuning.attn_impl = value; return VH_OK; }
     if (!strcmp(key, "attn_fa")) { g_tuning.attn_fa = value; return VH_OK; }
-    if (!strcmp(key, "attn_presplit")) { g_tuning.attn_presplit = value; return VH_OK; }
     if (!strcmp(key, "attn_rows")) { g_tuning.attn_rows = value; return VH_OK; }
     if (!strcmp(key, "attn_ksplit")) { g_tuning.attn_ksplit = value; return VH_OK; }
     if (!strcmp(key, "prefill_attn_gemm")) { g_tuning.prefill_attn_gemm = value; return VH_OK; }
@@ -114,7 +113,6 @@ int vh_attention(const vh_attn_args* a, void* stream) {
     g.B = a->B; g.Hq = a->Hq; g.Hkv = a->Hkv; g.Sq = a->Sq; g.Sk = a->Sk; g.d = a->d;
     g.causal = a->causal; g.q_off = a->q_off; g.klen = a->klen; g.chunk = a->chunk; g.left = a->left;
     g.scale = a->scale;
-    g.ws = a->ws; g.ws_bytes = a->ws_bytes;
     if (a->P && (!a->bias_u || !a->bias_v)) return fail(VH_E_ARG, "vh_attention: rel-pos needs bias_u/bias_v");
     if ((a->ldk % 4) || (a->ldv % 4) || (a->hsk % 4) || (a->hsv % 4) || (a->bsk % 4) ||
         (reinterpret_cast<uintptr_t>(a->K) & 15) || (reinterpret_cast<uintptr_t>(a->V) & 15) ||
@@ -283,8 +281,6 @@ struct vh_mixtral {
     // prefill scratch
     float *px, *pxn, *pqkv, *pq, *pattn, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
-    uint16_t* pkv_planes = nullptr; size_t pkv_bytes = 0;   // bf16 hi/lo planes of one layer's K / V for the prefill attention (k_attn_prep)
-    bool presplit_at_create = false;                        // vh_tune("attn_presplit") when the workspace was sized (carve must agree with it)
     int *pids, *pgoff, *pstok, *psslot, *pnslab;
     // ---- concurrent sequences over a paged KV cache (vLLM's block tables).  The KV pool above is cut into
     // 64-token pages (= one decode-attention tile); a sequence owns a page table, a residual-stream state, its counters
@@ -372,14 +368,6 @@ struct vh_mixtral {
         px = cv.take<float>(Sm * H); pxn = cv.take<float>(Sm * H);
         pqkv = cv.take<float>(Sm * nqkv);
         pq = cv.take<float>(Sm * nq * hd); pattn = cv.take<float>(Sm * nq * hd);
-        pkv_planes = nullptr; pkv_bytes = 0;
-        if (presplit_at_create) {   // only engines created under vh_tune("attn_presplit", 1) carry the scratch of the pre-pass:
-            // K / V planes of the context a prefill attends to, up to max(max_prefill, 8192) keys (longer contexts convert in the kernel)
-            size_t keys = (size_t)c.max_ctx < (Sm > 8192 ? Sm : (size_t)8192) ? (size_t)c.max_ctx : (Sm > 8192 ? Sm : (size_t)8192);
-            keys = (keys + 31) & ~(size_t)31;
-            pkv_bytes = (size_t)nkv * 4 * keys * hd * sizeof(uint16_t);
-            pkv_planes = cv.take<uint16_t>(pkv_bytes / sizeof(uint16_t));
-        }
         py = cv.take<float>(4 * 2 * Sm * H);   // py: up to 4 K-split slabs of the MoE down projection / 8 of the projections
         ptmp = cv.take<float>(Sm * H);
         pwts = cv.take<float>(2 * Sm);
@@ -495,7 +483,6 @@ size_t vh_mixtral_workspace_bytes(const vh_mixtral_cfg* cfg) {
     vh_mixtral tmp{};
     tmp.c = *cfg;
     tmp.derive();
-    tmp.presplit_at_create = vh_tuning()->attn_presplit != 0;
     return tmp.carve(nullptr);
 }
 
@@ -510,7 +497,6 @@ vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_laye
     vh_mixtral* m = new vh_mixtral{};
     m->c = *cfg;
     m->derive();
-    m->presplit_at_create = vh_tuning()->attn_presplit != 0;
     m->L.assign(layers, layers + cfg->n_layers);
     m->embed = embed; m->final_norm = final_norm; m->lm_head = lm_head;
     m->rope_cos = rope_cos; m->rope_sin = rope_sin;
@@ -721,7 +707,6 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             a.B = 1; a.Hq = nq; a.Hkv = nkv; a.Sq = Sn; a.Sk = pos0 + Sn; a.d = hd;
             a.causal = 1; a.q_off = pos0; a.klen = pos0 + Sn; a.chunk = 0; a.left = -1; a.scale = scale;
             a.ktable = m->table; a.kv_rows = m->c.max_ctx;
-            a.ws = m->pkv_planes; a.ws_bytes = m->pkv_bytes;
             if (attn_planes) { a.O = nullptr; a.O_hi = m->ph_hi; a.O_lo = m->ph_lo; a.ldo_split = (long)nq * hd; }
             VH_TRY(vhk_attn(st, a), "attention");
         }
@@ -922,7 +907,6 @@ int vh_encoder_layer(const vh_encoder_layer_args* a, void* stream) {
         g.klen = (a->klen >= 0 && a->klen < Sq) ? a->klen : Sq; g.chunk = a->chunk; g.left = a->left;
         g.scale = 1.0f / sqrtf((float)d);
         g.P = a->P; g.ldp = a->ldp; g.hsp = d; g.bias_u = a->bias_u; g.bias_v = a->bias_v;
-        g.ws = a->attn_ws; g.ws_bytes = a->attn_ws_bytes;
         VH_TRY(vhk_attn(st, g), "encoder attention");
     }
     VH_TRY(lin(a->attn, Cw, a->proj_w, Cw, a->proj_b, VH_ACT_NONE, a->ls1, a->x, a->x, a->n2_w, a->n2_b, a->hmid), "encoder proj");

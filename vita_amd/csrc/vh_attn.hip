@@ -272,62 +272,17 @@ __device__ __forceinline__ void at_split8(const f32x4& a, const f32x4& b, bf16x8
 }
 #define AT_PSTR3 36     // patch row stride (floats): 16-byte aligned 8-float reads at 8 lg, rows 4 banks apart mod 64
 
-// ---- pre-pass of the PRE variant: one block per (32-key tile, kv head, batch) ------------------------------------------------
-// ws layout per (batch, kv head): Kh | Kl as [Skp][D] bf16 (key-major), Vth | Vtl as [D][Skp] bf16 (TRANSPOSED), Skp = Sk rounded
-// up to 32; keys >= Sk are written as zeros (their probabilities are zero, their values must not be NaN bit patterns).
-template <int D, bool PAGED>
-__global__ __launch_bounds__(256) void k_attn_prep(const VhAttnArgs p) {
-    __shared__ float vt[32][D + 1];
-    const int k0 = blockIdx.x * 32, hk = blockIdx.y, b = blockIdx.z;
-    const int Skp = (p.Sk + 31) & ~31;
-    const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
-    const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
-    uint16_t* base = reinterpret_cast<uint16_t*>(p.ws) + (size_t)(b * p.Hkv + hk) * 4 * Skp * D;
-    uint16_t* Kh = base; uint16_t* Kl = base + (size_t)Skp * D;
-    uint16_t* Vh = base + (size_t)2 * Skp * D; uint16_t* Vl = base + (size_t)3 * Skp * D;
-    constexpr int C4 = D / 4;
-#pragma unroll
-    for (int i = threadIdx.x; i < 32 * C4; i += 256) {
-        const int kk = i / C4, c4 = i - kk * C4;
-        const int key = k0 + kk;
-        f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-        if (key < p.Sk) {
-            const size_t row = PAGED ? (size_t)p.ktable[key >> 6] * 64 + (key & 63) : (size_t)key;
-            kv = *reinterpret_cast<const f32x4*>(Kb + row * p.ldk + 4 * c4);
-            vv = *reinterpret_cast<const f32x4*>(Vb + row * p.ldv + 4 * c4);
-        }
-        uint32_t h[2], l[2];
-        at_split2(kv[0], kv[1], h[0], l[0]);
-        at_split2(kv[2], kv[3], h[1], l[1]);
-        *reinterpret_cast<uint2*>(Kh + (size_t)key * D + 4 * c4) = make_uint2(h[0], h[1]);
-        *reinterpret_cast<uint2*>(Kl + (size_t)key * D + 4 * c4) = make_uint2(l[0], l[1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vt[kk][4 * c4 + j] = vv[j];
-    }
-    __syncthreads();
-    // column d, key group g8 (8 keys): one 16-byte store per plane
-    for (int i = threadIdx.x; i < D * 4; i += 256) {
-        const int d = i % D, g8 = i / D;
-        uint32_t h[4], l[4];
-#pragma unroll
-        for (int u2 = 0; u2 < 4; ++u2) at_split2(vt[8 * g8 + 2 * u2][d], vt[8 * g8 + 2 * u2 + 1][d], h[u2], l[u2]);
-        *reinterpret_cast<uint4*>(Vh + (size_t)d * Skp + k0 + 8 * g8) = make_uint4(h[0], h[1], h[2], h[3]);
-        *reinterpret_cast<uint4*>(Vl + (size_t)d * Skp + k0 + 8 * g8) = make_uint4(l[0], l[1], l[2], l[3]);
-    }
-}
-
 // RT = 16-row tiles per wave.  With one tile the launch is bound by operand traffic, not by either pipe: every wave pulls
 // the whole K and V of its head through L2 -> registers (ViT: 4160 waves x 128 KB = 532 MB per launch, 8.7 TB/s at 61 us;
 // the fp32 kernel moved the same bytes in 78 us).  Two tiles per wave (d = 64) halve the bytes and the conversions per row.
 // MODE fixes the mask flavour at compile time (0 = pad mask only, 1 = causal, 2 = causal + KV page table): with the flavours
 // as run-time branches the loop body held 34 branches / 20 exec-mask regions, each a scheduling barrier between the loads,
 // conversions and MFMAs it should interleave.
-// PRE: K and V come as bf16 hi/lo planes written once per launch by k_attn_prep (K row-major, V TRANSPOSED so that a lane's eight
-// keys of one output column are one 16-byte load) instead of being converted by every wave that reads them — the loop was
-// VALU-issue-bound and the conversions were 160 of its 510 instructions.  The page table is resolved by the pre-pass.
-template <int D, int KS, int WPE, int RT, int MODE, bool PRE>
+// (r03's pre-pass that converted K / V to bf16 planes once per launch — 160 of the loop's 510 instructions are conversions — lost to
+// its own launch: ViT 66 vs 61 us, prefill 78 vs 49 us; removed in r04.  The flash form below converts once per BLOCK instead.)
+template <int D, int KS, int WPE, int RT, int MODE>
 __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_attn_x3(const VhAttnArgs p) {
-    constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2 && !PRE;
+    constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
     constexpr int NC = D / 16;          // output column tiles = floats of a V row per lane
     constexpr int VQ = NC / 4;          // float4s of V per lane per key
     constexpr int C32 = D / 32;         // 32-deep chunks of the head dimension
@@ -372,15 +327,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         for (int t = 0; t < NC; ++t) o[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // PRE operands: planes of this (batch, kv head): Kh | Kl [Skp][D], Vth | Vtl [D][Skp] (attn_prep_layout)
-    const int Skp = (p.Sk + 31) & ~31;
-    const uint16_t* pl_base = PRE ? reinterpret_cast<const uint16_t*>(p.ws) + (size_t)(b * p.Hkv + hk) * 4 * Skp * D : nullptr;
-    const uint16_t* Khp = pl_base;
-    const uint16_t* Klp = PRE ? pl_base + (size_t)Skp * D : nullptr;
-    const uint16_t* Vhp = PRE ? pl_base + (size_t)2 * Skp * D : nullptr;
-    const uint16_t* Vlp = PRE ? pl_base + (size_t)3 * Skp * D : nullptr;
-    bf16x8 kph[PRE ? 2 : 1][PRE ? C32 : 1], kpl[PRE ? 2 : 1][PRE ? C32 : 1], vph[PRE ? NC : 1], vpl[PRE ? NC : 1];
-    f32x4 kf[PRE ? 1 : 2][PRE ? 1 : C32][2], vf[PRE ? 1 : 8][PRE ? 1 : VQ];
+    f32x4 kf[2][C32][2], vf[8][VQ];
     // Row addresses are a uniform base + a 32-bit byte offset from a 24-bit multiply (the launcher checks that rows x stride
     // fits): the first version spent 63 quarter-rate 32/64-bit multiplies and ~100 more VALU per tile on 64-bit row pointers,
     // a third of the loop's issue cycles in a kernel that is VALU-bound.
@@ -392,18 +339,6 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         return (__umul24((unsigned)key, ld) + col) * 4u;
     };
     auto load_k = [&](int kt0) __attribute__((always_inline)) {
-        if constexpr (PRE) {
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                const unsigned off = (unsigned)min(kt0 + 16 * jt + lr, klast) * D + 8 * lg;
-#pragma unroll
-                for (int c = 0; c < C32; ++c) {
-                    kph[jt][c] = *reinterpret_cast<const bf16x8*>(Khp + off + 32 * c);
-                    kpl[jt][c] = *reinterpret_cast<const bf16x8*>(Klp + off + 32 * c);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             const char* row = reinterpret_cast<const char*>(Kb) + row_bytes(kt0 + 16 * jt + lr, ldk, 8 * lg);
@@ -415,15 +350,6 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
     };
     auto load_v = [&](int kt0) __attribute__((always_inline)) {
-        if constexpr (PRE) {
-            const unsigned kcol = (unsigned)min(kt0 + 8 * lg, Skp - 8);      // (clamped prefetch past the last tile)
-#pragma unroll
-            for (int t = 0; t < NC; ++t) {
-                vph[t] = *reinterpret_cast<const bf16x8*>(Vhp + (unsigned)(lr * NC + t) * Skp + kcol);
-                vpl[t] = *reinterpret_cast<const bf16x8*>(Vlp + (unsigned)(lr * NC + t) * Skp + kcol);
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const char* row = reinterpret_cast<const char*>(Vb) + row_bytes(kt0 + 8 * lg + u, ldv, lr * NC);
@@ -446,8 +372,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
             for (int c = 0; c < C32; ++c) {
                 bf16x8 kh, kl;
-                if constexpr (PRE) { kh = kph[jt][c]; kl = kpl[jt][c]; }
-                else at_split8(kf[jt][c][0], kf[jt][c][1], kh, kl);
+                at_split8(kf[jt][c][0], kf[jt][c][1], kh, kl);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     f32x4 a = sacc[rt][jt];
@@ -508,9 +433,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
         for (int t = 0; t < NC; ++t) {
             bf16x8 bh, bl;
-            if constexpr (PRE) {
-                bh = vph[t]; bl = vpl[t];
-            } else {
+            {
                 uint32_t vh[4], vl[4];
 #pragma unroll
                 for (int u2 = 0; u2 < 4; ++u2)
@@ -594,303 +517,284 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 }
 
 
-// ---- flash form of the bf16 x 3 kernel (r04): K / V tiles shared by the four waves of a block through LDS ------------------------
+// ---- flash form of the bf16 x 3 kernel for the Mixtral prefill (r04): K / V tiles shared by a block's waves through LDS ------------
 // The direct kernel above has every wave pull its keys' K and V rows from L2 in FRAGMENT shape (16 rows x 32 B per wave
-// instruction) and convert them to bf16 hi/lo itself: the ViT launch moves 277 MB through the vector-memory path at ~6 TB/s
-// and is bound there (and on the conversions), not on either pipe.  Here a block is
-//   D = 64 : one head x 64 RT query rows — wave w owns rows q0 + 16 RT w ..;
-//   D = 128: one KV head x 16 RT query rows x its FOUR query heads (Mixtral's 4 : 1 GQA) — wave w = head 4 hk + w;
-// and every 64-key tile of K and V is read from global ONCE per block in whole rows (4 threads per K row, 16 threads per V row:
-// full 128-byte lines), converted ONCE by the thread that loaded it, and laid in LDS as MFMA-ready bf16 hi/lo images:
+// instruction) and convert them to bf16 hi/lo itself; at d = 128 that is 308 MB through the vector-memory path per S = 552
+// launch (5.6 GB at S = 2344) at ~6 TB/s, which is what the launch lasts.  Here a block is ONE KV head x 16 query rows x its FOUR
+// query heads (Mixtral's 4 : 1 grouping), EIGHT waves = the four heads x the two 32-key halves of every 64-key tile, and every
+// tile of K and V is read from global ONCE per block in whole rows (K by wave group 1: two 512-byte rows per wave instruction;
+// V by group 0), converted ONCE by the thread that loaded it, and laid in LDS as MFMA-ready bf16 hi/lo images:
 //   K planes [half][64 keys][128 B], 16-byte chunks XOR-swizzled by (key >> 1) & 7: the B fragment of S = Q K^T (key lr,
 //            chunk 4c + lg) is one conflict-free ds_read_b128 (the layout of vh_gemm.hip's operand tiles);
-//   V planes TRANSPOSED [rho(col)][64 keys] with rho(d) = 16 (d % NC) + d / NC: row 16 t + lr holds column lr NC + t, so the
-//            B fragment of O += P V (keys 32 s + 8 lg ..+8 of the lane's column of output tile t) is one ds_read_b128 and the
-//            output keeps the direct kernel's lane -> NC consecutive columns mapping (16-byte stores).  The transposition is
-//            free: v_cvt_pk pairs two registers, here the same column of two consecutive keys.
+//   V planes TRANSPOSED [rho(col)][64 keys] with rho(d) = 16 (d % 8) + d / 8: row 16 t + lr holds column 8 lr + t, so the B
+//            fragment of O += P V (keys 32 s + 8 lg ..+8 of the lane's column of output tile t) is one ds_read_b128 and the output
+//            keeps the direct kernel's lane -> 8 consecutive columns mapping (16-byte stores).  The transposition is free:
+//            v_cvt_pk pairs two registers, here the same column of two consecutive keys.
 // Two LDS buffers, register staging one tile ahead: the loads of tile t + 2 are issued behind the barrier that ends tile t, the
 // conversion + LDS writes of tile t + 1 run at the end of tile t into the buffer last read in tile t - 1: ONE barrier per 64 keys.
-// The arithmetic per 32-key half tile (products, softmax, accumulation order) is the direct kernel's; only the partition of the
-// keys among waves differs (none here: a wave sees all keys of its rows in order, no merge).
-template <int D, int RT, int MODE, int KS>
-__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(KS == 2 || (D == 64 && RT == 1) ? 2 : 1, KS == 2 || (D == 64 && RT == 1) ? 2 : 1)))
+// Wave group kg takes half kg of every tile; the groups merge (m, l, O) once at the end, like the direct kernel's key groups.
+// (With ONE group — 4 waves, both halves in turn — every dependent latency of a half tile is exposed at one wave per SIMD: 42 vs
+// 34 us at S = 552.)  The arithmetic per 32-key half tile (products, softmax, accumulation order) is the direct kernel's.
+// Measured (profiles/r04_attn_fa_v2.jsonl): S = 552 46.8 -> 34.3 us, S = 2344 468 -> 310 us.  A d = 64 instantiation for the ViT
+// (block = one head x 64 / 128 rows) was built and measured too: 50-63 vs 47 us on one image, a tie on eight — not kept.
+#ifndef FA_ABLATE
+#define FA_ABLATE 0      // development builds (profiles/ablate_fa.sh): 1 no global loads after the prologue, 2 no conversion / LDS writes after the prologue, 4 no softmax, 8 no PV products, 16 no QK products
+#endif
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_attn_fa(const VhAttnArgs p) {
-    // KS = 2: EIGHT waves — the four row groups (heads) twice: wave group kg takes the 32-key half kg of every 64-key tile and the two
-    // groups merge (m, l, O) once at the end, like the direct kernel's key groups.  One wave per SIMD (KS = 1) leaves every dependent
-    // latency of a half tile (fragment reads -> MFMA chain -> DPP reductions -> patch -> MFMA chain) exposed; two per SIMD overlap
-    // one group's softmax with the other's products.  Staging is split by ROLE: group 0 loads / converts / transposes V, group 1 K.
     constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
-    constexpr int NC = D / 16, VQ = NC / 4, C32 = D / 32;
+    constexpr int D = 128, NC = D / 16, VQ = NC / 4, C32 = D / 32;
     constexpr int PL = 64 * D * 2;                 // bytes of one plane of one 64-key tile
-    constexpr int NKR = D / 16, NVB = D / 64;      // float4s of a thread's quarter K row; 4 x 4 blocks of V per thread
-    constexpr int NST = KS == 2 ? (NKR > 4 * NVB ? NKR : 4 * NVB) : NKR + 4 * NVB;
-    constexpr int MGW = RT * (8 + NC * 4);
-    static_assert(KS == 1 || 4 * 64 * MGW * 4 <= 8 * PL, "merge area aliases the K / V buffers");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * PL + 4 * KS * RT * 16 * AT_PSTR3 * 4];
+    constexpr int MGW = 8 + NC * 4;
+    static_assert(4 * 64 * MGW * 4 <= 8 * PL, "merge area aliases the K / V buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * PL + 8 * 16 * AT_PSTR3 * 4];
     float* patches = reinterpret_cast<float*>(lds + 8 * PL);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int rg = w & 3, kg = w >> 2;                        // row group (d = 64) / head of the KV group (d = 128); key half
+    const int rg = w & 3, kg = w >> 2;                        // head of the KV group; key half
     const int ftid = tid & 255;                               // index inside the staging role
     const int lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.z;
     const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;      // heaviest (latest rows under the causal mask) blocks first
-    int h, hk, q0;
-    if (D == 64) { h = blockIdx.y; hk = h / (p.Hq / p.Hkv); q0 = qb * (64 * RT) + 16 * RT * rg; }
-    else { hk = blockIdx.y; h = hk * 4 + rg; q0 = qb * (16 * RT); }
-    const int qblk0 = D == 64 ? qb * (64 * RT) : q0;                       // first row of the BLOCK
-    const int qblk1 = min(qblk0 + (D == 64 ? 64 * RT : 16 * RT), p.Sq) - 1; // last row of the block
+    const int hk = blockIdx.y, h = hk * 4 + rg, q0 = qb * 16;
+    const int qlast = min(q0 + 16, p.Sq) - 1;
 
     const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
     const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
     const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
 
     const float qscale = p.scale * 1.44269504088896340736f;
-    bf16x8 qh[RT][C32], ql[RT][C32];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int q = min(q0 + 16 * rt + lr, p.Sq - 1);
+    bf16x8 qh[C32], ql[C32];
+    {
+        const int q = min(q0 + lr, p.Sq - 1);
 #pragma unroll
         for (int c = 0; c < C32; ++c) {
             const float* src = Qb + (size_t)q * p.ldq + 32 * c + 8 * lg;
-            at_split8(*reinterpret_cast<const f32x4*>(src) * qscale, *reinterpret_cast<const f32x4*>(src + 4) * qscale, qh[rt][c], ql[rt][c]);
+            at_split8(*reinterpret_cast<const f32x4*>(src) * qscale, *reinterpret_cast<const f32x4*>(src + 4) * qscale, qh[c], ql[c]);
         }
     }
 
     const int kend = min(p.Sk, p.klen);
-    int kloop = kend;                                                       // keys any row of the BLOCK can see
-    if (CAUSAL) kloop = min(kloop, qblk1 + p.q_off + 1);
+    const int kloop = CAUSAL ? min(kend, qlast + p.q_off + 1) : kend;       // keys the block's rows can see
     const int ntiles = (kloop + 63) >> 6;
-    // keys this WAVE's rows can see (none when all its rows lie past Sq: it only helps staging)
-    const int wave_kmax = q0 >= p.Sq ? 0 : (CAUSAL ? min(kend, min(q0 + 16 * RT - 1, p.Sq - 1) + p.q_off + 1) : kend);
 
-    float m[RT][4], l[RT][4];
-    f32x4 o[RT][NC];
+    float m[4], l[4];
+    f32x4 o[NC];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { m[rt][r] = -INFINITY; l[rt][r] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < NC; ++t) o[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int t = 0; t < NC; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- staging: thread -> (key, quarter row) of K, (4 keys x 4 columns) blocks of V; KS = 2: K by wave group 1, V by group 0 ----
+    // ---- staging by role (wave-uniform): group 1 = K, 8 x 16-byte pieces per thread: piece i = row 8 i + ftid / 32, floats
+    // 4 (ftid % 32) ..+4 (a wave instruction = two whole rows); group 0 = V, two 4-key x 4-column blocks per thread ----------------
     const unsigned ldk = (unsigned)p.ldk, ldv = (unsigned)p.ldv;
     const int klast = p.Sk - 1;
-    const int fk_key = ftid >> 2, fk_q = ftid & 3, fv_kg = ftid >> 4, fv_cg = ftid & 15;
-    const bool do_k = KS == 1 || kg == 1, do_v = KS == 1 || kg == 0;        // (wave-uniform)
-    constexpr int VOFF = KS == 2 ? 0 : NKR;                                  // V pieces share the K registers when the roles are split
-    f32x4 st[NST];
+    const int fk_key = ftid >> 5, fk_c = ftid & 31, fv_kg = ftid >> 4, fv_cg = ftid & 15;
+    f32x4 st[8];
     auto row_of = [&](int key) __attribute__((always_inline)) {
         key = min(key, klast);
         if (PAGED) key = p.ktable[key >> 6] * 64 + (key & 63);
         return (unsigned)key;
     };
-    auto load_tile = [&](int kt0) __attribute__((always_inline)) {
-        if (do_k) {
-            const char* src = reinterpret_cast<const char*>(Kb) + (__umul24(row_of(kt0 + fk_key), ldk) + fk_q * (D / 4)) * 4u;
+    // (Two parts each — K: keys 0-31 / 32-63 of the tile; V: columns 0-63 / 64-127.)  Ablations of the first form, conversion + LDS writes
+    // in one block at the END of a tile with nothing to hide behind: 320 us at S = 2344, 209 without them (profiles/r04_attn_fa_ablate.txt).
+    // Loads are unconditional (the tile index is clamped by the caller): hipcc counts vmcnt only for loads it can see on every path.
+    auto load_part = [&](int part, int kt0) __attribute__((always_inline)) {
+        if (kg == 1) {
 #pragma unroll
-            for (int i = 0; i < NKR; ++i) st[i] = *reinterpret_cast<const f32x4*>(src + 16 * i);
-        }
-        if (do_v) {
+            for (int i = 0; i < 4; ++i)
+                st[4 * part + i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Kb) +
+                                                                  (__umul24(row_of(kt0 + 8 * (4 * part + i) + fk_key), ldk) + 4 * fk_c) * 4u);
+        } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const char* src = reinterpret_cast<const char*>(Vb) + (__umul24(row_of(kt0 + 4 * fv_kg + u), ldv) + 4 * fv_cg) * 4u;
-#pragma unroll
-                for (int bb = 0; bb < NVB; ++bb) st[VOFF + 4 * bb + u] = *reinterpret_cast<const f32x4*>(src + 256 * bb);
-            }
+            for (int u = 0; u < 4; ++u)
+                st[4 * part + u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Vb) +
+                                                                  (__umul24(row_of(kt0 + 4 * fv_kg + u), ldv) + 4 * fv_cg + 64 * part) * 4u);
         }
     };
-    auto store_tile = [&](unsigned char* buf) __attribute__((always_inline)) {
-        unsigned char* Kh = buf; unsigned char* Kl = buf + PL; unsigned char* Vh = buf + 2 * PL; unsigned char* Vl = buf + 3 * PL;
-        if (do_k) {
+    auto store_part = [&](int part, unsigned char* buf) __attribute__((always_inline)) {
+        if (kg == 1) {
+            unsigned char* Kh = buf; unsigned char* Kl = buf + PL;
 #pragma unroll
-            for (int i = 0; i < NKR / 2; ++i) {
-                bf16x8 hi, lo;
-                at_split8(st[2 * i], st[2 * i + 1], hi, lo);
-                const int gc = fk_q * (D / 32) + i;
-                const int off = (gc >> 3) * 8192 + fk_key * 128 + (((gc & 7) ^ ((fk_key >> 1) & 7)) << 4);
-                *reinterpret_cast<bf16x8*>(Kh + off) = hi;
-                *reinterpret_cast<bf16x8*>(Kl + off) = lo;
+            for (int i = 4 * part; i < 4 * part + 4; ++i) {
+                uint32_t h0, l0, h1, l1;
+                at_split2(st[i][0], st[i][1], h0, l0);
+                at_split2(st[i][2], st[i][3], h1, l1);
+                const int key = 8 * i + fk_key;
+                const int off = (fk_c >> 4) * 8192 + key * 128 + (((((fk_c & 15) >> 1)) ^ ((key >> 1) & 7)) << 4) + (fk_c & 1) * 8;
+                *reinterpret_cast<uint2*>(Kh + off) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(Kl + off) = make_uint2(l0, l1);
             }
-        }
-        if (do_v) {
+        } else {
+            unsigned char* Vh = buf + 2 * PL; unsigned char* Vl = buf + 3 * PL;
+            const int cg = fv_cg + 16 * part;
 #pragma unroll
-            for (int bb = 0; bb < NVB; ++bb) {
-                const int cg = fv_cg + 16 * bb;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t h01, l01, h23, l23;
-                    at_split2(st[VOFF + 4 * bb + 0][j], st[VOFF + 4 * bb + 1][j], h01, l01);
-                    at_split2(st[VOFF + 4 * bb + 2][j], st[VOFF + 4 * bb + 3][j], h23, l23);
-                    const int d = 4 * cg + j;
-                    const int rho = 16 * (d % NC) + d / NC;
-                    const int off = rho * 128 + ((((fv_kg >> 1)) ^ ((rho >> 1) & 7)) << 4) + (fv_kg & 1) * 8;
-                    *reinterpret_cast<uint2*>(Vh + off) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(Vl + off) = make_uint2(l01, l23);
-                }
+            for (int j = 0; j < 4; ++j) {
+                uint32_t h01, l01, h23, l23;
+                at_split2(st[4 * part + 0][j], st[4 * part + 1][j], h01, l01);
+                at_split2(st[4 * part + 2][j], st[4 * part + 3][j], h23, l23);
+                const int d = 4 * cg + j;
+                const int rho = 16 * (d % NC) + d / NC;
+                const int off = rho * 128 + ((((fv_kg >> 1)) ^ ((rho >> 1) & 7)) << 4) + (fv_kg & 1) * 8;
+                *reinterpret_cast<uint2*>(Vh + off) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(Vl + off) = make_uint2(l01, l23);
             }
         }
     };
 
     if (ntiles > 0) {
-        load_tile(0);
-        store_tile(lds);
-        if (ntiles > 1) load_tile(64);
+        load_part(0, 0); load_part(1, 0);
+        store_part(0, lds); store_part(1, lds);
+        const int k1 = ntiles > 1 ? 64 : 0;
+        load_part(0, k1); load_part(1, k1);
     }
     __syncthreads();
+    float* ps = patches + w * 16 * AT_PSTR3;
     for (int t = 0; t < ntiles; ++t) {
         const unsigned char* buf = lds + (t & 1) * 4 * PL;
         const unsigned char* Kh = buf; const unsigned char* Kl = buf + PL; const unsigned char* Vh = buf + 2 * PL; const unsigned char* Vl = buf + 3 * PL;
-#pragma unroll
-        for (int s0 = 0; s0 < 2 / KS; ++s0) {
-            const int s = KS == 2 ? kg : s0;
-            const int kt0 = t * 64 + 32 * s;
-            if (kt0 >= wave_kmax) break;                              // (wave-uniform) nothing of this half tile is visible to these rows
+        const int kt0 = t * 64 + 32 * kg;
+        unsigned char* nbuf = lds + ((t + 1) & 1) * 4 * PL;              // last read in tile t - 1: everyone is past it
+        const bool more = t + 1 < ntiles && !(FA_ABLATE & 2);
+        const int knext = min(t + 2, ntiles - 1) * 64;                  // (clamped: the last tile is simply re-read)
+        if (kt0 < kloop) {                                            // (wave-uniform) this half tile has a visible key
             // ---- S = Q K^T for the two 16-key sub-tiles ------------------------------------------------------------------------
-            f32x4 sacc[RT][2];
+            f32x4 sacc[2];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) sacc[rt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int key = 32 * s + 16 * jt + lr;
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int key = 32 * kg + 16 * jt + lr;
 #pragma unroll
                 for (int c = 0; c < C32; ++c) {
                     const int gc = 4 * c + lg;
                     const int off = (gc >> 3) * 8192 + key * 128 + (((gc & 7) ^ ((key >> 1) & 7)) << 4);
                     const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
                     const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        f32x4 a = sacc[rt][jt];
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[rt][c], kh, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kl, a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kh, a, 0, 0, 0);
-                        sacc[rt][jt] = a;
-                    }
+#if defined(FA_ABLATE) && (FA_ABLATE & 16)
+                    a[0] += __builtin_bit_cast(f32x4, kh)[0] + __builtin_bit_cast(f32x4, kl)[1];
+#else
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[c], kh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[c], kl, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[c], kh, a, 0, 0, 0);
+#endif
                 }
+                sacc[jt] = a;
             }
+            // conversion + LDS writes of the NEXT tile here, behind the 24 MFMAs of S that the matrix pipe is still working through, and the
+            // reload for the tile after next right behind them: every load has a whole tile period to land.  (Splitting the staging in two
+            // — half here, half behind the PV products — made hipcc wait vmcnt(0) here for the half reloaded a quarter tile earlier.)
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { store_part(0, nbuf); store_part(1, nbuf); }
+            if (!(FA_ABLATE & 1)) { load_part(0, knext); load_part(1, knext); }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- online softmax in D layout (the direct kernel's) --------------------------------------------------------------
             const bool full_tile = kt0 + AT_KT <= (CAUSAL ? min(kend, q0 + p.q_off + 1) : kend);
+            float alpha[4];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float* ps = patches + (w * RT + rt) * 16 * AT_PSTR3;
-                float alpha[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + 16 * rt + lg * 4 + r;
-                    float s0v = sacc[rt][0][r], s1v = sacc[rt][1][r];
-                    if (!full_tile) {
-                        const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;
-                        s0v = (kt0 + lr < klim) ? s0v : -INFINITY;
-                        s1v = (kt0 + 16 + lr < klim) ? s1v : -INFINITY;
-                    }
-                    const float mx = grp16_max(fmaxf(s0v, s1v));
-                    const float mn = fmaxf(m[rt][r], mx);
-                    const bool none = mn == -INFINITY;
-                    alpha[r] = none ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
-                    const float p0 = none ? 0.f : __builtin_amdgcn_exp2f(s0v - mn);
-                    const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1v - mn);
-                    l[rt][r] = l[rt][r] * alpha[r] + grp16_sum(p0 + p1);
-                    m[rt][r] = mn;
-                    ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
-                    ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + lg * 4 + r;
+                float s0v = sacc[0][r], s1v = sacc[1][r];
+                if (!full_tile) {
+                    const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;
+                    s0v = (kt0 + lr < klim) ? s0v : -INFINITY;
+                    s1v = (kt0 + 16 + lr < klim) ? s1v : -INFINITY;
                 }
-#pragma unroll
-                for (int tt = 0; tt < NC; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[rt][tt][r] *= alpha[r];
+#if defined(FA_ABLATE) && (FA_ABLATE & 4)
+                alpha[r] = 1.f;
+                const float p0 = s0v, p1 = s1v;
+                l[r] += p0 + p1;
+#else
+                const float mx = grp16_max(fmaxf(s0v, s1v));
+                const float mn = fmaxf(m[r], mx);
+                const bool none = mn == -INFINITY;
+                alpha[r] = none ? 1.f : __builtin_amdgcn_exp2f(m[r] - mn);
+                const float p0 = none ? 0.f : __builtin_amdgcn_exp2f(s0v - mn);
+                const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1v - mn);
+                l[r] = l[r] * alpha[r] + grp16_sum(p0 + p1);
+                m[r] = mn;
+#endif
+                ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
+                ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
             }
+#pragma unroll
+            for (int tt = 0; tt < NC; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[tt][r] *= alpha[r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- O += P V over the 32 keys -------------------------------------------------------------------------------------
-            bf16x8 ph[RT], pl[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float* ps = patches + (w * RT + rt) * 16 * AT_PSTR3;
-                at_split8(*reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg),
-                          *reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg + 4), ph[rt], pl[rt]);
-            }
+            bf16x8 ph, pl;
+            at_split8(*reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg), *reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg + 4), ph, pl);
 #pragma unroll
             for (int tt = 0; tt < NC; ++tt) {
                 const int row = 16 * tt + lr;
-                const int off = row * 128 + (((4 * s + lg) ^ ((row >> 1) & 7)) << 4);
+                const int off = row * 128 + (((4 * kg + lg) ^ ((row >> 1) & 7)) << 4);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Vh + off);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Vl + off);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rt], bh, o[rt][tt], 0, 0, 0);
-                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bl, o[rt][tt], 0, 0, 0);
-                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bh, o[rt][tt], 0, 0, 0);
-                }
+#if defined(FA_ABLATE) && (FA_ABLATE & 8)
+                o[tt][0] += __builtin_bit_cast(f32x4, bh)[0] + __builtin_bit_cast(f32x4, bl)[1] + __builtin_bit_cast(f32x4, ph)[0] + __builtin_bit_cast(f32x4, pl)[0];
+#else
+                o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, o[tt], 0, 0, 0);
+                o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bl, o[tt], 0, 0, 0);
+                o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, o[tt], 0, 0, 0);
+#endif
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            if (more) { store_part(0, nbuf); store_part(1, nbuf); }
+            if (!(FA_ABLATE & 1)) { load_part(0, knext); load_part(1, knext); }
         }
-        if (t + 1 < ntiles) store_tile(lds + ((t + 1) & 1) * 4 * PL);      // that buffer was last read in tile t - 1: everyone is past it
         __syncthreads();
-        if (t + 2 < ntiles) load_tile((t + 2) * 64);                        // lands under tile t + 1
     }
 
-    // ---- KS = 2: the second key half of every row group merges into the first (every wave is past the last tile: the K / V buffers
-    // are free and hold the hand-over) ------------------------------------------------------------------------------------------------
-    if (KS == 2) {
-        float* Mg = reinterpret_cast<float*>(lds);
+    // ---- the second key half of every head merges into the first (every wave is past the last tile: the K / V buffers are free
+    // and hold the hand-over) ---------------------------------------------------------------------------------------------------------
+    {
+        float* mg = reinterpret_cast<float*>(lds) + (rg * 64 + lane) * MGW;
         if (kg == 1) {
-            float* mg = Mg + (rg * 64 + lane) * MGW;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float* mr = mg + rt * (8 + NC * 4);
+            for (int r = 0; r < 4; ++r) { mg[r] = m[r]; mg[4 + r] = l[r]; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { mr[r] = m[rt][r]; mr[4 + r] = l[rt][r]; }
+            for (int t = 0; t < NC; ++t)
 #pragma unroll
-                for (int t = 0; t < NC; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mr[8 + t * 4 + r] = o[rt][t][r];
-            }
+                for (int r = 0; r < 4; ++r) mg[8 + t * 4 + r] = o[t][r];
         }
         __syncthreads();
         if (kg == 1) return;
-        const float* mg = Mg + (rg * 64 + lane) * MGW;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const float* mr = mg + rt * (8 + NC * 4);
+        for (int r = 0; r < 4; ++r) {
+            const float m2 = mg[r], l2 = mg[4 + r];
+            const float mn = fmaxf(m[r], m2);
+            const float a1 = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[r] - mn);
+            const float a2 = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+            l[r] = l[r] * a1 + l2 * a2;
+            m[r] = mn;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m2 = mr[r], l2 = mr[4 + r];
-                const float mn = fmaxf(m[rt][r], m2);
-                const float a1 = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
-                const float a2 = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
-                l[rt][r] = l[rt][r] * a1 + l2 * a2;
-                m[rt][r] = mn;
-#pragma unroll
-                for (int t = 0; t < NC; ++t) o[rt][t][r] = o[rt][t][r] * a1 + mr[8 + t * 4 + r] * a2;
-            }
+            for (int t = 0; t < NC; ++t) o[t][r] = o[t][r] * a1 + mg[8 + t * 4 + r] * a2;
         }
     }
 
     float* Ob = p.O ? p.O + (size_t)b * p.bso + (size_t)h * D : nullptr;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + lg * 4 + r;
+        if (q >= p.Sq) continue;
+        const float inv = (l[r] > 0.f) ? 1.0f / l[r] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = q0 + 16 * rt + lg * 4 + r;
-            if (q >= p.Sq) continue;
-            const float inv = (l[rt][r] > 0.f) ? 1.0f / l[rt][r] : 0.f;
-#pragma unroll
-            for (int j = 0; j < VQ; ++j) {
-                const f32x4 v = f32x4{o[rt][4 * j][r] * inv, o[rt][4 * j + 1][r] * inv, o[rt][4 * j + 2][r] * inv, o[rt][4 * j + 3][r] * inv};
-                if (Ob) *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) = v;
-                if (p.O_hi) {
-                    uint32_t hi[2], lo[2];
-                    at_split2(v[0], v[1], hi[0], lo[0]);
-                    at_split2(v[2], v[3], hi[1], lo[1]);
-                    const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
-                    *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0], hi[1]);
-                    *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0], lo[1]);
-                }
+        for (int j = 0; j < VQ; ++j) {
+            const f32x4 v = f32x4{o[4 * j][r] * inv, o[4 * j + 1][r] * inv, o[4 * j + 2][r] * inv, o[4 * j + 3][r] * inv};
+            if (Ob) *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) = v;
+            if (p.O_hi) {
+                uint32_t hi[2], lo[2];
+                at_split2(v[0], v[1], hi[0], lo[0]);
+                at_split2(v[2], v[3], hi[1], lo[1]);
+                const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0], hi[1]);
+                *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0], lo[1]);
             }
         }
     }
@@ -929,23 +833,15 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
             if (rows >= (1L << 24) || ldmax >= (1L << 24) || ldmax < 0 || (rows * ldmax + a.d) * 4 >= (1L << 32)) mode = -1;
         }
         if (!rel && vh_tuning()->attn_impl == 0 && mode >= 0) {
-            // flash form (K / V tiles shared through LDS): d = 64 any head grouping, d = 128 with the 4 : 1 grouping it maps to its
-            // four waves; taken when its (larger) blocks still fill half the chip, or when forced (attn_fa = 2: tests)
+            // flash form (K / V tiles shared through LDS by the four query heads of a KV head): d = 128 with the 4 : 1 grouping; taken when
+            // its blocks (16 rows x 4 heads) still fill half the chip, or when forced (attn_fa = 2: tests)
             const int fa = vh_tuning()->attn_fa;
-            if (fa != 0 && (a.d == 64 || a.Hq == 4 * a.Hkv)) {
-                const int rows_knob = vh_tuning()->attn_rows;
-                const long b2 = (long)((a.Sq + 127) / 128) * a.Hq * a.B;
-                const int rt = a.d == 128 ? 1 : (rows_knob == 32 ? 2 : (rows_knob == 16 ? 1 : (b2 >= 2L * vh_num_cus() ? 2 : 1)));
-                const dim3 gf(a.d == 64 ? (a.Sq + 64 * rt - 1) / (64 * rt) : (a.Sq + 15) / 16, a.d == 64 ? a.Hq : a.Hkv, a.B);
+            if (fa != 0 && a.d == 128 && a.Hq == 4 * a.Hkv) {
+                const dim3 gf((a.Sq + 15) / 16, a.Hkv, a.B);
                 if (fa == 2 || (long)gf.x * gf.y * gf.z * 2 >= vh_num_cus()) {
-#define FA(DD, RR, MM, KK) hipLaunchKernelGGL((k_attn_fa<DD, RR, MM, KK>), gf, dim3(256 * KK), 0, st, a)
-#define FA_MODES(DD, RR, KK) do { if (mode == 0) FA(DD, RR, 0, KK); else if (mode == 1) FA(DD, RR, 1, KK); else FA(DD, RR, 2, KK); } while (0)
-                    const bool one = want == 1;               // attn_ksplit = 1: one wave group (4 waves); default two (8 waves)
-                    if (a.d == 128) { if (one) FA_MODES(128, 1, 1); else FA_MODES(128, 1, 2); }
-                    else if (rt == 2) { if (one) FA_MODES(64, 2, 1); else FA_MODES(64, 2, 2); }
-                    else { if (one) FA_MODES(64, 1, 1); else FA_MODES(64, 1, 2); }
-#undef FA_MODES
-#undef FA
+                    if (mode == 0) hipLaunchKernelGGL((k_attn_fa<0>), gf, dim3(512), 0, st, a);
+                    else if (mode == 1) hipLaunchKernelGGL((k_attn_fa<1>), gf, dim3(512), 0, st, a);
+                    else hipLaunchKernelGGL((k_attn_fa<2>), gf, dim3(512), 0, st, a);
                     return 0;
                 }
             }
@@ -954,31 +850,15 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
             // was VALU-lean; only when the launch still gives every SIMD two waves
             const int rows = vh_tuning()->attn_rows;
             const bool two = a.d == 64 && mode == 0 && (rows == 32 || (rows == 0 && (long)g32.x * g32.y * g32.z * ks >= 8L * vh_num_cus()));
-            // pre-split K / V planes when the caller gave scratch for them and the key count takes the full key-group split
-            const long skp = (a.Sk + 31) & ~31L;
-            const size_t need = (size_t)a.B * a.Hkv * 4 * skp * a.d * sizeof(uint16_t);
-            const int full_ks = a.d == 64 ? 4 : 2;
-            const bool pre = vh_tuning()->attn_presplit != 0 && mode != 2 && a.ws && a.ws_bytes >= need && ks == full_ks &&
-                             (reinterpret_cast<uintptr_t>(a.ws) & 15) == 0 && skp * a.d * 4 < (1L << 31);
-            if (pre) {
-                const dim3 gp((unsigned)(skp / 32), a.Hkv, a.B);
-                if (a.d == 64) hipLaunchKernelGGL((k_attn_prep<64, false>), gp, dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((k_attn_prep<128, false>), gp, dim3(256), 0, st, a);
-            }
-#define X3(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM, false>), G, dim3(64 * KK), 0, st, a)
-#define X3P(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM, true>), G, dim3(64 * KK), 0, st, a)
+#define X3(DD, KK, WW, RR, MM, G) hipLaunchKernelGGL((k_attn_x3<DD, KK, WW, RR, MM>), G, dim3(64 * KK), 0, st, a)
 #define X3_MODES(DD, KK, WW) do { if (mode == 0) X3(DD, KK, WW, 1, 0, g16); else if (mode == 1) X3(DD, KK, 2, 1, 1, g16); else X3(DD, KK, 2, 1, 2, g16); } while (0)
-            if (pre) {
-                if (a.d == 64) { if (two) X3P(64, 4, 2, 2, 0, g32); else if (mode == 0) X3P(64, 4, 2, 1, 0, g16); else X3P(64, 4, 2, 1, 1, g16); }
-                else { if (mode == 0) X3P(128, 2, 2, 1, 0, g16); else X3P(128, 2, 2, 1, 1, g16); }
-            } else if (two) {
+            if (two) {
                 if (ks == 1) X3(64, 1, 2, 2, 0, g32); else if (ks == 2) X3(64, 2, 2, 2, 0, g32); else X3(64, 4, 2, 2, 0, g32);
             } else if (a.d == 64) {
                 if (ks == 1) X3_MODES(64, 1, 2); else if (ks == 2) X3_MODES(64, 2, 2); else X3_MODES(64, 4, 2);
             } else {
                 if (ks == 1) X3_MODES(128, 1, 2); else X3_MODES(128, 2, 2);
             }
-#undef X3P
 #undef X3_MODES
 #undef X3
             return 0;

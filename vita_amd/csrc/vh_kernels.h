@@ -15,7 +15,6 @@ struct VhTuning {
     int batch_decode = 1;      // concurrent sequences: 1 = groups of up to 4 sequences per batched decode step, 0 = one sequence after the other
     int attn_impl = 0;         // multi-row attention: 0 = bf16 x 3 MFMAs where the mask flavour allows (plain / causal), 2 = fp32-MFMA kernel everywhere
     int attn_fa = 1;           // bf16 x 3 attention: 1 = flash form (K / V tiles through LDS, k_attn_fa) when its blocks fill half the chip, 2 = always, 0 = never
-    int attn_presplit = 0;     // bf16 x 3 attention: 1 = K / V converted to planes once per launch by a pre-pass (k_attn_prep) when the caller provides scratch
     int attn_rows = 0;         // bf16 x 3 attention at d = 64: query rows per wave, 0 = auto (32 when the launch still fills the chip), 16, 32
     int attn_ksplit = 0;       // multi-row attention: key groups per block, 0 = auto (4 at d = 64, 2 at d = 128), 1 = single group
     int prefill_attn_gemm = 0; // prefill QKV / O projections: 0 = weight-streaming pre-split kernel with a K split, 1 = general kernel
@@ -163,7 +162,6 @@ struct VhAttnArgs {
     float scale;
     const int* ktable;                    // nullable: keys / values live in 64-row pages, logical block j>>6 -> page ktable[j>>6]
     long kv_rows;                         // rows a page-table entry may address (the pool); 0 = Sk.  Bounds the 32-bit offsets of k_attn_x3
-    void* ws; size_t ws_bytes;            // nullable scratch for the pre-split K / V planes of k_attn_x3: B * Hkv * roundup(Sk, 32) * d * 8 bytes
 };
 int vhk_attn(hipStream_t st, const VhAttnArgs& a);
 

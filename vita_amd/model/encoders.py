@@ -18,7 +18,6 @@ from .. import ops
 from ..audio_frontend import AudioEncoderProcessor
 from ..config import AudioConfig, VisionConfig
 
-_ATTN_PRESPLIT = os.environ.get("VITA_AMD_ATTN_PRESPLIT", "0") == "1"
 VIT = "model.vision_tower.vision_tower."
 AUD = "model.audio_encoder."
 
@@ -138,7 +137,6 @@ class InternViTVisionTower(_HipModule):
         pe = ops.gemm(patches, w["patch_w"], bias=w["patch_b"])
         x = ops.vit_assemble(pe, w["cls"], w["pos"], n, N, C)                    # [n*N, C]
         attn = torch.empty((n * N, C), dtype=torch.float32, device=self._device)
-        attn_ws = torch.empty(ops.attention_ws_bytes(n, nh, N, d), dtype=torch.uint8, device=self._device) if _ATTN_PRESPLIT else None
         layers = []
         # every LayerNorm after the first rides on the Linear that produces its input (ops.gemm(ln=...): the split-K reducer
         # holds whole rows, so the norm costs no launch of its own at one tile)
@@ -146,8 +144,6 @@ class InternViTVisionTower(_HipModule):
         if not self.per_operator and w["layers"]:
             # one library call per block (vh_encoder_layer): 24 host calls per pass instead of ~170
             sc = ops.EncoderScratch(n * N, C, w["layers"][0]["fc1_w"].shape[0], self._device)
-            if _ATTN_PRESPLIT:   # scratch for the K / V pre-pass of the attention kernel (vh_tune("attn_presplit", 1): measured slower, off)
-                sc.attn_ws = torch.empty(ops.attention_ws_bytes(n, nh, N, d), dtype=torch.uint8, device=self._device)
             for li, L in enumerate(w["layers"]):
                 nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
                 ops.encoder_layer(x, h, sc.h[li & 1], L, sc, heads=nh, B=n, act="gelu", eps=v.layer_norm_eps,
@@ -161,7 +157,7 @@ class InternViTVisionTower(_HipModule):
             qkv = ops.gemm(h, L["qkv_w"], bias=L["qkv_b"])                        # [n*N, 3C] = (three, head, d)
             ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B=n, Hq=nh, Hkv=nh, Sq=N, Sk=N, d=d, ldq=3 * C,
                           hsq=d, ldk=3 * C, hsk=d, ldv=3 * C, hsv=d, ldo=C, bsq=N * 3 * C, bsk=N * 3 * C, bso=N * C,
-                          scale=d ** -0.5, ws=attn_ws)
+                          scale=d ** -0.5)
             _, h = ops.gemm(attn, L["proj_w"], bias=L["proj_b"], scale=L["ls1"], resid=x, out=x,
                             ln=(L["n2w"], L["n2b"], v.layer_norm_eps))
             m = ops.gemm(h, L["fc1_w"], bias=L["fc1_b"], act="gelu")

@@ -114,8 +114,7 @@ def gemm(a, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=No
 
 
 def attention(q, k, v, out, *, B, Hq, Hkv, Sq, Sk, d, ldq, hsq, ldk, hsk, ldv, hsv, ldo, bsq=0, bsk=0, bso=0, scale,
-              causal=False, q_off=0, klen=None, chunk=0, left=-1, p=None, ldp=0, hsp=0, bias_u=None, bias_v=None, ws=None):
-    """ws: optional uint8 scratch of attention_ws_bytes(B, Hkv, Sk, d) — K / V are then converted to bf16 planes once per call."""
+              causal=False, q_off=0, klen=None, chunk=0, left=-1, p=None, ldp=0, hsp=0, bias_u=None, bias_v=None):
     _dev(q, k, v, out)
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (p, "p")):
         _c(t, nm)
@@ -134,14 +133,8 @@ def attention(q, k, v, out, *, B, Hq, Hkv, Sq, Sk, d, ldq, hsq, ldk, hsk, ldv, h
     a.klen = Sk if klen is None else int(klen)
     a.chunk, a.left = int(chunk), int(left)
     a.scale = float(scale)
-    if ws is not None:
-        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     check(lib.vh_attention(C.byref(a), _stream()), "vh_attention")
     return out
-
-
-def attention_ws_bytes(B, Hkv, Sk, d):
-    return B * Hkv * ((Sk + 31) // 32 * 32) * d * 8
 
 
 class EncoderScratch:
@@ -153,7 +146,6 @@ class EncoderScratch:
         self.qkv, self.attn, self.hmid, self.mid = f(M, 3 * Cw), f(M, Cw), f(M, Cw), f(M, F)
         self.h = [f(M, Cw), f(M, Cw)]                       # LayerNorm outputs, ping-pong between layers
         self.ws = _scratch(device, min(8 * 4 * M * max(3 * Cw, F), 96 << 20))
-        self.attn_ws = None                                   # set by the caller: attention_ws_bytes(B, heads, S, d) bytes
 
 
 def encoder_layer(x, h_in, h_out, L, sc, *, heads, B, act, eps, next_norm=None, p=None, bias_u=None, bias_v=None, klen=-1, chunk=0,
@@ -180,8 +172,6 @@ def encoder_layer(x, h_in, h_out, L, sc, *, heads, B, act, eps, next_norm=None, 
     a.klen, a.chunk, a.left = int(klen), int(chunk), int(left)
     a.qkv, a.attn, a.hmid, a.mid = sc.qkv.data_ptr(), sc.attn.data_ptr(), sc.hmid.data_ptr(), sc.mid.data_ptr()
     a.ws, a.ws_bytes = sc.ws.data_ptr(), sc.ws.numel()
-    if sc.attn_ws is not None and p is None:
-        a.attn_ws, a.attn_ws_bytes = sc.attn_ws.data_ptr(), sc.attn_ws.numel()
     check(_lib.load().vh_encoder_layer(C.byref(a), _stream()), "vh_encoder_layer")
 
 
