@@ -125,7 +125,11 @@ int vh_attention(const vh_attn_args* args, void* stream);
  * P = linear_pos(pos_emb), pos_bias_u / pos_bias_v, pad / chunk mask; ReLU).  h_in is LN(x; this layer's norm1): from
  * vh_layernorm for the first layer, from the previous call's h_out afterwards.  Attention runs inside each of the B
  * sequences of M / B rows; keys >= klen are masked (klen < 0: none).  Scratch (caller-owned): qkv [M, 3C], attn [M, C], hmid [M, C], mid [M, F], ws (split-K slabs,
- * >= 32 M max(C, F) bytes recommended; 0 disables the split). */
+ * >= 32 M max(C, F) bytes recommended; 0 disables the split).
+ * planes = 1 (r04; no rel-pos, ws >= 4 M C bytes): the rows that only feed the next Linear travel as the bf16 hi/lo planes vh_gemm_ps consumes — h_in / h_out,
+ * attn and hmid then hold two planes each, hi [M][C] followed by lo [M][C] (mid: [M][F] twice), in the same M C 4 (M F 4) bytes — and the four Linears run on the
+ * weight-streaming GEMM with one-round tilings (qkv / fc1 one pass; proj / fc2 K-split into ws, summed by the reducer that also applies bias, layer scale,
+ * residual and the next LayerNorm).  Same arithmetic as planes = 0 (the general GEMM splits its fp32 operand into the same planes per block). */
 typedef struct {
     float* x; const float* h_in; float* h_out;
     int M, C, F, heads, B;
@@ -138,6 +142,7 @@ typedef struct {
     int act; float eps;
     const float* P; long ldp; const float* bias_u; const float* bias_v; int klen, chunk, left;
     float* qkv; float* attn; float* hmid; float* mid; float* ws; size_t ws_bytes;
+    int planes;
 } vh_encoder_layer_args;
 int vh_encoder_layer(const vh_encoder_layer_args* args, void* stream);
 

@@ -68,6 +68,7 @@ class EncoderLayerArgs(C.Structure):
         ("act", c_int), ("eps", c_float),
         ("P", c_void_p), ("ldp", c_long), ("bias_u", c_void_p), ("bias_v", c_void_p), ("klen", c_int), ("chunk", c_int), ("left", c_int),
         ("qkv", c_void_p), ("attn", c_void_p), ("hmid", c_void_p), ("mid", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t),
+        ("planes", c_int),
     ]
 
 

@@ -874,6 +874,15 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     return VH_OK;
 }
 
+static int api_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+}
+
 int vh_encoder_layer(const vh_encoder_layer_args* a, void* stream) {
     if (!a || !a->x || !a->h_in || !a->qkv_w || !a->proj_w || !a->n2_w || !a->fc1_w || !a->fc2_w || !a->qkv || !a->attn ||
         !a->hmid || !a->mid)
@@ -896,18 +905,66 @@ int vh_encoder_layer(const vh_encoder_layer_args* a, void* stream) {
         g.ln_w = lw; g.ln_b = lb; g.ln_eps = a->eps; g.ln_out = lout; g.ld_ln = N;
         return vhk_gemm(st, g);
     };
+    // ---- planes = 1: the four Linears on the streaming GEMM, operands as bf16 hi/lo planes (see include/vita_hip.h) -------------------
+    const bool planes = a->planes != 0;
+    if (planes && (a->P || !a->ws || a->ws_bytes < (size_t)M * Cw * sizeof(float)))
+        return fail(VH_E_ARG, "vh_encoder_layer: planes = 1 needs ws >= 4 M C bytes and no rel-pos operand");
+    auto pl_hi = [&](const void* base) { return reinterpret_cast<uint16_t*>(const_cast<void*>(base)); };
+    auto pl_lo = [&](const void* base, long cols) { return reinterpret_cast<uint16_t*>(const_cast<void*>(base)) + (size_t)M * cols; };
+    // K split of a Linear whose one-pass tiling cannot fill half the chip (N = C: 4 n-tiles): 2 .. 4 by depth, bounded by ws
+    auto ks_for = [&](int N, int K) {
+        const long nrt = (M + 15) >> 4, NT = (N + 255) / 256;
+        if (((nrt + 2) / 3) * NT * 2 >= api_num_cus()) return 1;
+        int ks = K / 1024 + 1;
+        ks = ks < 2 ? 2 : (ks > 4 ? 4 : ks);
+        while (ks > 1 && ((size_t)ks * M * N * sizeof(float) > a->ws_bytes || ks > (K >> 6))) --ks;
+        return ks;
+    };
+    // out = A W^T on planes: raw partial sums into ws (ks slabs), or the finished rows (bias, act) as fp32 / as planes
+    auto lin_ps = [&](const void* A, int K, const uint16_t* W, int N, const float* bias, int act, float* Cout, void* Cplanes, int ks) {
+        VhGemmPsArgs g{};
+        g.A_hi = pl_hi(A); g.A_lo = pl_lo(A, K); g.lda = K;
+        g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
+        if (ks >= 1 && !Cout && !Cplanes) { g.C = a->ws; g.ldc = N; g.ksplit = ks; g.c_split_stride = (long)M * N; }
+        else { g.C = Cout; g.ldc = N; g.bias = bias; g.act = act; g.ksplit = 1;
+               if (Cplanes) { g.C_hi = pl_hi(Cplanes); g.C_lo = pl_lo(Cplanes, N); g.ldc_split = N; } }
+        return vhk_gemm_ps(st, g);
+    };
+    // x += scale * (sum of the ks slabs + bias); then LN(x; lw, lb) as planes into lout (nullable)
+    auto reduce_into_x = [&](int N, int ks, const float* bias, const float* scale, const float* lw, const float* lb, void* lout) {
+        VhGemmArgs g{};
+        g.ws = a->ws; g.ws_bytes = a->ws_bytes; g.M = M; g.N = N; g.C = a->x; g.ldc = N;
+        g.bias = bias; g.scale = scale; g.resid = a->x; g.ldr = N; g.act = VH_ACT_NONE;
+        if (lout) { g.ln_w = lw; g.ln_b = lb; g.ln_eps = a->eps; g.ln_hi = pl_hi(lout); g.ln_lo = pl_lo(lout, N); g.ld_ln_split = N; }
+        return vhk_gemm_reduce(st, g, ks);
+    };
+    if (planes) VH_TRY(lin_ps(a->h_in, Cw, a->qkv_w, 3 * Cw, a->qkv_b, VH_ACT_NONE, a->qkv, nullptr, 1), "encoder qkv (planes)");
+    else
     VH_TRY(lin(a->h_in, Cw, a->qkv_w, 3 * Cw, a->qkv_b, VH_ACT_NONE, nullptr, nullptr, a->qkv, nullptr, nullptr, nullptr), "encoder qkv");
     {
         VhAttnArgs g{};
         g.Q = a->qkv; g.K = a->qkv + Cw; g.V = a->qkv + 2 * Cw;
         g.ldq = g.ldk = g.ldv = 3L * Cw; g.hsq = g.hsk = g.hsv = d;
         g.bsq = g.bsk = (long)Sq * 3 * Cw; g.bso = (long)Sq * Cw;
-        g.O = a->attn; g.ldo = Cw;
+        if (planes) { g.O = nullptr; g.O_hi = pl_hi(a->attn); g.O_lo = pl_lo(a->attn, Cw); g.ldo_split = Cw; }
+        else g.O = a->attn;
+        g.ldo = Cw;
         g.B = a->B; g.Hq = g.Hkv = a->heads; g.Sq = g.Sk = Sq; g.d = d;
         g.klen = (a->klen >= 0 && a->klen < Sq) ? a->klen : Sq; g.chunk = a->chunk; g.left = a->left;
         g.scale = 1.0f / sqrtf((float)d);
         g.P = a->P; g.ldp = a->ldp; g.hsp = d; g.bias_u = a->bias_u; g.bias_v = a->bias_v;
         VH_TRY(vhk_attn(st, g), "encoder attention");
+    }
+    if (planes) {
+        const int ks1 = ks_for(Cw, Cw), ks2 = ks_for(Cw, F);
+        VH_TRY(lin_ps(a->attn, Cw, a->proj_w, Cw, nullptr, VH_ACT_NONE, nullptr, nullptr, ks1), "encoder proj (planes)");
+        VH_TRY(reduce_into_x(Cw, ks1, a->proj_b, a->ls1, a->n2_w, a->n2_b, a->hmid), "encoder proj reducer");
+        VH_TRY(lin_ps(a->hmid, Cw, a->fc1_w, F, a->fc1_b, a->act, nullptr, a->mid, 1), "encoder fc1 (planes)");
+        VH_TRY(lin_ps(a->mid, F, a->fc2_w, Cw, nullptr, VH_ACT_NONE, nullptr, nullptr, ks2), "encoder fc2 (planes)");
+        VH_TRY(reduce_into_x(Cw, ks2, a->fc2_b, a->ls2, a->next_w, a->next_b, a->h_out), "encoder fc2 reducer");
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return fail(VH_E_HIP, "vh_encoder_layer: %s", hipGetErrorString(e2));
+        return VH_OK;
     }
     VH_TRY(lin(a->attn, Cw, a->proj_w, Cw, a->proj_b, VH_ACT_NONE, a->ls1, a->x, a->x, a->n2_w, a->n2_b, a->hmid), "encoder proj");
     VH_TRY(lin(a->hmid, Cw, a->fc1_w, F, a->fc1_b, a->act, nullptr, nullptr, a->mid, nullptr, nullptr, nullptr), "encoder fc1");

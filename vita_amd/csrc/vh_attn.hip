@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 uint32_t hi[4], lo[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) split_bf16(v[i], hi[i], lo[i]);
-                const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                const size_t at = ((size_t)b * p.Sq + q) * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
                 *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
                 *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
             }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     uint32_t hi[2], lo[2];
                     at_split2(v[0], v[1], hi[0], lo[0]);
                     at_split2(v[2], v[3], hi[1], lo[1]);
-                    const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                    const size_t at = ((size_t)b * p.Sq + q) * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
                     *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0], hi[1]);
                     *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0], lo[1]);
                 }
@@ -792,7 +792,7 @@ void k_attn_fa(const VhAttnArgs p) {
                 uint32_t hi[2], lo[2];
                 at_split2(v[0], v[1], hi[0], lo[0]);
                 at_split2(v[2], v[3], hi[1], lo[1]);
-                const size_t at = (size_t)q * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
+                const size_t at = ((size_t)b * p.Sq + q) * p.ldo_split + (size_t)h * D + lr * NC + 4 * j;
                 *reinterpret_cast<uint2*>(p.O_hi + at) = make_uint2(hi[0], hi[1]);
                 *reinterpret_cast<uint2*>(p.O_lo + at) = make_uint2(lo[0], lo[1]);
             }
@@ -810,7 +810,7 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
     // direct-operand kernel (default): every operand row must allow 16-byte loads / stores
     auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     if (!a.O && !a.O_hi) return -1;
-    if (a.O_hi && (!a.O_lo || a.B != 1 || (a.ldo_split % 4) != 0 || !al16(a.O_hi) || !al16(a.O_lo))) return -1;
+    if (a.O_hi && (!a.O_lo || (a.ldo_split % 4) != 0 || !al16(a.O_hi) || !al16(a.O_lo))) return -1;
     const bool direct_ok = al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O) && (!rel || al16(a.P)) &&
                            (!rel || (al16(a.bias_u) && al16(a.bias_v) && (a.ldp % 4) == 0 && (a.hsp % 4) == 0)) &&
                            ((a.ldq | a.hsq | a.bsq | a.ldk | a.hsk | a.bsk | a.ldv | a.hsv | a.ldo | a.bso) % 4) == 0;

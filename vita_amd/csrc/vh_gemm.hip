@@ -337,16 +337,50 @@ __global__ __launch_bounds__(256) void k_gemm_reduce_ln(const VhGemmArgs p, int 
         const f32x4 ww = reinterpret_cast<const f32x4*>(p.ln_w)[c];
         f32x4 r = (v[j] - mean) * inv * ww;
         if (p.ln_b) r += reinterpret_cast<const f32x4*>(p.ln_b)[c];
-        *reinterpret_cast<f32x4*>(p.ln_out + m * p.ld_ln + c * 4) = r;
+        if (p.ln_out) *reinterpret_cast<f32x4*>(p.ln_out + m * p.ld_ln + c * 4) = r;
+        if (p.ln_hi) {
+            uint32_t h0, l0, h1, l1;
+            split_bf16_pair(r[0], r[1], h0, l0);
+            split_bf16_pair(r[2], r[3], h1, l1);
+            *reinterpret_cast<uint2*>(p.ln_hi + m * p.ld_ln_split + c * 4) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(p.ln_lo + m * p.ld_ln_split + c * 4) = make_uint2(l0, l1);
+        }
     }
 }
 
 }  // namespace
 
+static void launch_reduce_ln(hipStream_t st, const VhGemmArgs& g, int ksp) {
+    switch (ksp) {
+        case 2: hipLaunchKernelGGL(k_gemm_reduce_ln<2>, dim3(g.M), dim3(256), 0, st, g, ksp); break;
+        case 3: hipLaunchKernelGGL(k_gemm_reduce_ln<3>, dim3(g.M), dim3(256), 0, st, g, ksp); break;
+        case 4: hipLaunchKernelGGL(k_gemm_reduce_ln<4>, dim3(g.M), dim3(256), 0, st, g, ksp); break;
+        case 6: hipLaunchKernelGGL(k_gemm_reduce_ln<6>, dim3(g.M), dim3(256), 0, st, g, ksp); break;
+        case 8: hipLaunchKernelGGL(k_gemm_reduce_ln<8>, dim3(g.M), dim3(256), 0, st, g, ksp); break;
+        default: hipLaunchKernelGGL(k_gemm_reduce_ln<0>, dim3(g.M), dim3(256), 0, st, g, ksp); break;
+    }
+}
+
+int vhk_gemm_reduce(hipStream_t st, const VhGemmArgs& a, int ksp) {
+    if (!a.ws || !a.C || ksp < 1 || ksp > 8 || a.M < 0 || a.N <= 0 || (a.N % 4) != 0 || (a.ldc % 4) != 0) return -1;
+    if ((size_t)ksp * a.M * a.N * sizeof(float) > a.ws_bytes) return -1;
+    if (a.M == 0) return 0;
+    const bool ln = a.ln_w != nullptr;
+    if (ln && ((!a.ln_out && !a.ln_hi) || (a.ln_hi && (!a.ln_lo || (a.ld_ln_split % 4) != 0)) || (a.ln_out && (a.ld_ln % 4) != 0))) return -1;
+    if (ln && a.N <= GR_MAXJ * 1024) { launch_reduce_ln(st, a, ksp); return 0; }
+    if (ln && a.ln_hi) return -1;                      // planes come from the fused reducer only
+    long rg = ((long)a.M * (a.N / 4) + 255) / 256;
+    if (rg > 2048) rg = 2048;
+    hipLaunchKernelGGL(k_gemm_reduce, dim3((int)rg), dim3(256), 0, st, a, ksp);
+    if (ln) return vhk_layernorm(st, a.C, a.ldc, a.ln_out, a.ld_ln, a.ln_w, a.ln_b, a.M, a.N, a.ln_eps, VH_ACT_NONE, 1.0f);
+    return 0;
+}
+
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
     if (a.K <= 0 || a.K % GM_BK != 0 || a.nseg < 1 || a.nseg > 16 || a.seglen % GM_BK != 0 ||
         a.nseg * a.seglen != a.K || a.M < 0 || a.N <= 0 || a.A == nullptr)
         return -1;
+    if (a.ln_hi) return -1;                        // plane outputs: vhk_gemm_reduce only
     if (a.ln_out && (!a.ln_w || a.W_up || a.c_rowidx || a.group_off || (a.N % 4) != 0 || (a.ldc % 4) != 0 || (a.ld_ln % 4) != 0)) return -1;
     if (a.M == 0) return 0;
     VhGemmArgs g = a;
@@ -377,14 +411,7 @@ int vhk_gemm(hipStream_t st, const VhGemmArgs& a) {
         else hipLaunchKernelGGL((k_gemm<false, 1, 4>), grid, dim3(256), 0, st, g);
         const bool ln_fused = a.ln_out && ksp > 1 && a.N <= GR_MAXJ * 1024 && (a.ldc % 4) == 0 && (a.ld_ln % 4) == 0;
         if (ksp > 1 && ln_fused) {
-            switch (ksp) {
-                case 2: hipLaunchKernelGGL(k_gemm_reduce_ln<2>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
-                case 3: hipLaunchKernelGGL(k_gemm_reduce_ln<3>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
-                case 4: hipLaunchKernelGGL(k_gemm_reduce_ln<4>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
-                case 6: hipLaunchKernelGGL(k_gemm_reduce_ln<6>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
-                case 8: hipLaunchKernelGGL(k_gemm_reduce_ln<8>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
-                default: hipLaunchKernelGGL(k_gemm_reduce_ln<0>, dim3(a.M), dim3(256), 0, st, g, ksp); break;
-            }
+            launch_reduce_ln(st, g, ksp);
             return 0;
         }
         if (ksp > 1) {

@@ -380,6 +380,15 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     int grid = num_cus();   // persistent: one 8-wave block per CU
     grid &= ~7;
     if (grid < 8) grid = 8;
+    // Plain GEMMs with a host-known K split (the encoders' Linears, M ~ 250 .. 8000): a K = 1024 tile costs 25-30 us whatever its rows (16
+    // stages of ~1.5 us + prologue / epilogue), so the launch is its number of ROUNDS: take the smallest m-tiles (>= 48 rows) whose tile
+    // count still fits ONE round; problems that need several rounds anyway keep the 192-row tiles (fewest weight re-reads).
+    // profiles/r04_enc_sp_sweep.jsonl: ViT qkv 34.3 -> 29.4 us (64-row tiles), fc1 36.0 -> 32.1 (80), 8-image batches unchanged.
+    if (!a.group_off && a.ksplit >= 1 && a.rt_cap == 0) {
+        const int nrt = (a.M + 15) >> 4, NT = (a.N + (a.W_up ? 127 : 255)) / (a.W_up ? 128 : 256);
+        for (int c = 3; c < 12; ++c)
+            if ((long)((nrt + c - 1) / c) * NT * a.ksplit <= grid) { a.rt_cap = c; break; }
+    }
     if (cfg == 2) return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt != 0);   // specialised waves (vh_gemm_sp.hip)
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
     // round is M-split relies on L2 for the second reader of each weight tile (gate|up: +5 % with nt)

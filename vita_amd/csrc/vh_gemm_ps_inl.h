@@ -206,7 +206,8 @@ __device__ __forceinline__ void for_each_tile(const VhGemmPsArgs& p, F&& f) {
     const int NT = (p.N + NOUT - 1) / NOUT;
     const int nk_total = p.K >> 6;
     auto rows_of = [&](int e) { return p.group_off ? (p.group_off[e + 1] - p.group_off[e]) : p.M; };
-    auto mtiles_of = [&](int rows) { return (((rows + 15) >> 4) + RTMAX - 1) / RTMAX; };
+    const int cap = (p.rt_cap > 0 && p.rt_cap < RTMAX) ? p.rt_cap : RTMAX;
+    auto mtiles_of = [&](int rows) { return (((rows + 15) >> 4) + cap - 1) / cap; };
 
     // ---- tile list and its partition ---------------------------------------------------------------------
     int ord[8], n_exp = 0;

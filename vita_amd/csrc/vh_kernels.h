@@ -121,8 +121,12 @@ struct VhGemmArgs {
     // (r03) the LayerNorm that consumes C, in the same call: ln_out[m, :] = LN(C[m, :]) * ln_w + ln_b (nullable ln_b).  With
     // split-K the reducer already holds whole rows, so the norm costs no launch of its own; otherwise a norm launch follows.
     const float* ln_w; const float* ln_b; float ln_eps; float* ln_out; long ld_ln;
+    uint16_t* ln_hi; uint16_t* ln_lo; long ld_ln_split;   // (r04) the normed rows as bf16 hi/lo planes (what the streaming GEMM consumes); ln_out may then be null
 };
 int vhk_gemm(hipStream_t st, const VhGemmArgs& a);
+// the split-K reducer of vh_gemm.hip on slabs some OTHER kernel wrote: ws = [ksp][M][N] fp32 partial sums; applies bias / act / scale /
+// resid into C and, with ln_w, the LayerNorm of the row into ln_out and / or the ln_hi / ln_lo planes (N <= 4096 for the fused norm)
+int vhk_gemm_reduce(hipStream_t st, const VhGemmArgs& a, int ksp);
 
 // ---- weight-streaming GEMM on pre-split activations (vh_gemm_ps.hip) -------------------
 // C[orow(m), n] = epilogue( sum_k (A_hi + A_lo)[arow(m), k] * W[n, k] ), A as bf16 hi/lo planes.  K % 64 == 0.
@@ -139,6 +143,7 @@ struct VhGemmPsArgs {
     int ksplit; long c_split_stride;                         // K split: partial sums go to C + ks * c_split_stride (plain fp32 output only);
                                                              // ksplit < 0: the kernel picks 1 .. -ksplit from the group sizes
     int* nslab_out;                                          // device int: the split the kernel used (required when ksplit < 0)
+    int rt_cap;                                              // 0 = tile rows up to the kernel's maximum (192); n: m-tiles of at most 16 n rows (plain GEMMs at M ~ 1000: more, smaller tiles fill the chip)
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
 int vhk_gemm_sp(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt);   // vh_gemm_sp.hip: 12-wave specialised form (arguments already checked)
@@ -153,7 +158,7 @@ struct VhAttnArgs {
     const float* P; long ldp; long hsp;   // rel-pos keys (audio), nullable
     const float* bias_u; const float* bias_v;  // [H][d], nullable (rel-pos)
     float* O; long ldo;                   // O[(b*Sq + q)*ldo + h*d + dd]
-    uint16_t* O_hi; uint16_t* O_lo; long ldo_split;   // optional bf16 hi/lo planes of O (same indexing, B = 1; direct kernel only); O may then be null
+    uint16_t* O_hi; uint16_t* O_lo; long ldo_split;   // optional bf16 hi/lo planes of O: row b * Sq + q, column h * d + dd; O may then be null
     long bsq, bsk, bso;                   // batch strides in elements for Q / K,V / O
     int B, Hq, Hkv, Sq, Sk, d;
     int causal; int q_off;                // causal: key <= q + q_off visible

@@ -35,6 +35,9 @@ def _f32(x, device):
     return x.to(device=device, dtype=torch.float32).contiguous()
 
 
+# VITA_AMD_VIT_PLANES=0: the ViT blocks on the general GEMM with fp32 rows between the operators (the r01-r03 form; A/B and bisecting)
+_VIT_PLANES = os.environ.get("VITA_AMD_VIT_PLANES", "1") != "0"
+
 class _HipModule(nn.Module):
     """Container base: weights are plain tensors kept out of nn.Parameter bookkeeping (they are in
     kernel layout, not the checkpoint's), so .to(dtype=...) from the demo is a no-op by design."""
@@ -144,10 +147,15 @@ class InternViTVisionTower(_HipModule):
         if not self.per_operator and w["layers"]:
             # one library call per block (vh_encoder_layer): 24 host calls per pass instead of ~170
             sc = ops.EncoderScratch(n * N, C, w["layers"][0]["fc1_w"].shape[0], self._device)
+            # planes mode (r04): LayerNorm / attention / GELU outputs travel as the bf16 hi/lo planes the weight-streaming GEMM consumes
+            # (one-round tilings: qkv / fc1 25 % faster at one tile, 30-36 % on 8-image batches; profiles/r04_enc_sp_sweep.jsonl)
+            planes = _VIT_PLANES and C % 64 == 0 and sc.ws.numel() * sc.ws.element_size() >= 4 * n * N * C
+            if planes:
+                h = ops.split_planes_into(h, sc.h[1])
             for li, L in enumerate(w["layers"]):
                 nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
                 ops.encoder_layer(x, h, sc.h[li & 1], L, sc, heads=nh, B=n, act="gelu", eps=v.layer_norm_eps,
-                                  next_norm=(nxt["n1w"], nxt["n1b"]) if nxt is not None else None)
+                                  next_norm=(nxt["n1w"], nxt["n1b"]) if nxt is not None else None, planes=planes)
                 h = sc.h[li & 1]
                 if want_layers:
                     layers.append(x.clone().view(n, N, C))

@@ -149,10 +149,11 @@ class EncoderScratch:
 
 
 def encoder_layer(x, h_in, h_out, L, sc, *, heads, B, act, eps, next_norm=None, p=None, bias_u=None, bias_v=None, klen=-1, chunk=0,
-                  left=-1):
+                  left=-1, planes=False):
     """One pre-norm transformer block in ONE library call (vh_encoder_layer): x [M, C] updated in place, h_in = LN(x; norm1),
     h_out = LN(x_out; next_norm) when next_norm = (w, b) is given.  L: dict of this layer's weights (qkv_w, qkv_b, proj_w,
-    proj_b, ls1?, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, ls2?)."""
+    proj_b, ls1?, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, ls2?).  planes=True: h_in / h_out hold bf16 hi/lo planes (split_planes_into) in
+    their M * C * 4 bytes and the Linears run on the weight-streaming GEMM (vita_hip.h: vh_encoder_layer_args.planes)."""
     _dev(x, h_in)
     a = _lib.EncoderLayerArgs()
     a.x, a.h_in, a.h_out = x.data_ptr(), h_in.data_ptr(), (h_out.data_ptr() if next_norm is not None else None)
@@ -171,7 +172,8 @@ def encoder_layer(x, h_in, h_out, L, sc, *, heads, B, act, eps, next_norm=None, 
         a.P, a.ldp, a.bias_u, a.bias_v = p.data_ptr(), int(p.stride(0)), bias_u.data_ptr(), bias_v.data_ptr()
     a.klen, a.chunk, a.left = int(klen), int(chunk), int(left)
     a.qkv, a.attn, a.hmid, a.mid = sc.qkv.data_ptr(), sc.attn.data_ptr(), sc.hmid.data_ptr(), sc.mid.data_ptr()
-    a.ws, a.ws_bytes = sc.ws.data_ptr(), sc.ws.numel()
+    a.ws, a.ws_bytes = sc.ws.data_ptr(), sc.ws.numel() * sc.ws.element_size()
+    a.planes = int(bool(planes))
     check(_lib.load().vh_encoder_layer(C.byref(a), _stream()), "vh_encoder_layer")
 
 
@@ -249,6 +251,19 @@ def split_planes(x):
     check(_lib.load().vh_split_planes(_p(x), x.stride(0), _p(hi), _p(lo), cols, rows, cols, _stream()),
           "vh_split_planes")
     return hi, lo
+
+
+def split_planes_into(x, buf):
+    """fp32 x [rows, cols] -> bf16 hi plane then lo plane inside `buf` (any dense tensor of rows * cols * 4 bytes): the operand layout of
+    vh_encoder_layer's planes mode."""
+    _dev(x, buf)
+    _f32(_c(x, "x"), "x")
+    rows, cols = x.shape
+    if buf.numel() * buf.element_size() < rows * cols * 4 or not buf.is_contiguous():
+        raise ValueError("split_planes_into: buf must be a dense tensor of at least rows * cols * 4 bytes")
+    base = buf.data_ptr()
+    check(_lib.load().vh_split_planes(_p(x), x.stride(0), base, base + rows * cols * 2, cols, rows, cols, _stream()), "vh_split_planes")
+    return buf
 
 
 def gemm_ps(a_hi, a_lo, w, *, w_up=None, bias=None, act=None, scale=None, resid=None, out=None, out_split=False,
