@@ -31,7 +31,7 @@ def test_prefill_kernel_roofline_field():
     import bench
     S, E, I, H, L = 552, 8, 14336, 4096, 32
     r = bench.prefill_kernel_roofline(S, E, I, H, L, total_ms=96 * 0.6, samples=96)
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS and "k_gemm_ps" in r["kernel"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS and "k_gemm_sp" in r["kernel"]
     assert r["bytes_per_launch"] == 2 * E * I * H * 2 + S * H * 4 + 2 * S * I * 4 and r["launches_per_prefill"] == L
     assert abs(r["avg_launch_us"] - 600.0) < 1e-6 and r["samples"] == 96
     assert abs(r["achieved"] - r["bytes_per_launch"] / 600e-6 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
