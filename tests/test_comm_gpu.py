@@ -107,8 +107,11 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1):
     from vita_amd.engine import MixtralEngine
     from vita_amd.parallel import setup_tensor_parallel
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("VITA_AMD_TP_TRIAL", None)
     if fuse < 0:
         os.environ.pop("VITA_AMD_TP_FUSE", None)      # the ranks choose the exchange form themselves (shared device -> "kernel")
+        if fuse == -2:
+            os.environ["VITA_AMD_TP_TRIAL"] = "1"     # ... after the TIMED trial a real node runs (both forms, 6 steps each), forced here on one device
     else:
         os.environ["VITA_AMD_TP_FUSE"] = str(int(fuse))   # force: 1 = the exchange fused into the decode kernels
     torch.cuda.set_device(0)
@@ -180,7 +183,7 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     assert float(np.abs(ret[0][2] - ref_lg).max()) < 1e-3
 
 
-@pytest.mark.parametrize("overlap,fuse", [(1, 1), (0, 1), (1, 0), (1, -1)])
+@pytest.mark.parametrize("overlap,fuse", [(1, 1), (0, 1), (1, 0), (1, -1), (1, -2)])
 def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
     """two engine processes (TP = 2, one GPU) with the IPC all-reduce installed by setup_tensor_parallel: greedy ids
     equal the unsharded fp32 oracle's, logits within 1e-3, both ranks identical.  overlap = 1: the prefill's
@@ -201,7 +204,10 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
     ref_ids, ref_lg = om.MixtralOracle(sd, cfg.text).greedy(sd["model.embed_tokens.weight"][ids], 10)
     assert ret[0][0] == ret[1][0] == "ipc"
     # forced forms report themselves; left to the vote (fuse = -1) two ranks on ONE device must get the kernel form
-    assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
+    if fuse == -2:      # the timed trial decides (whichever form was faster here); what matters: both ranks agree and the engine is clean after it
+        assert ret[0][5] == ret[1][5] and ret[0][5] in ("fused", "kernel"), (ret[0][5], ret[1][5])
+    else:
+        assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
     assert ret[0][1] == ret[1][1] == ref_ids

@@ -160,7 +160,8 @@ def choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same_d
     """Times `steps` greedy decode steps of THIS engine under both exchange forms (tp_fuse 0 / 1) and lets the ranks vote
     (no environment variable on a real node).  Ranks sharing a device skip the timing — the fused form's
     waiting blocks starve the other ranks there (profiles/r03_tp_fuse_latency_*.json) — and get "kernel".
-    VITA_AMD_TP_FUSE=0/1 still forces a form (debugging).  Leaves the engine reset for the caller's first prefill."""
+    VITA_AMD_TP_FUSE=0/1 still forces a form (debugging); VITA_AMD_TP_TRIAL=1 runs the timed trial even when the ranks share a device
+    (tests: the trial is the code a real node executes at bring-up).  Leaves the engine reset for the caller's first prefill."""
     from . import _lib
     forced = os.environ.get("VITA_AMD_TP_FUSE", "")
     if forced in ("0", "1"):
@@ -169,7 +170,8 @@ def choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same_d
     tk = tf = 0.0
     ok = True
     steps = min(steps, max(0, (eng.max_new - 4) // 2))
-    can_time = (not same_device) and steps >= 4 and eng.max_prefill >= 8 and eng.max_ctx > 8 + 2 * steps + 4
+    force_trial = os.environ.get("VITA_AMD_TP_TRIAL", "") == "1"
+    can_time = (force_trial or not same_device) and steps >= 4 and eng.max_prefill >= 8 and eng.max_ctx > 8 + 2 * steps + 4
     if can_time:
         try:
             emb = eng.packed["embed"][:8].float().contiguous()          # any 8 rows: only the timing matters
@@ -195,7 +197,7 @@ def choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same_d
         except Exception as e:
             print(f"[vita_amd.parallel] rank {rank}: decode-exchange trial failed: {e}", file=sys.stderr)
             ok = False
-    choice, tk_all, tf_all = vote_decode_exchange(dist, same_device or not can_time, tk, tf, ok, device, backend)
+    choice, tk_all, tf_all = vote_decode_exchange(dist, (same_device and not force_trial) or not can_time, tk, tf, ok, device, backend)
     _lib.tune("tp_fuse", 1 if choice == "fused" else 0)
     if rank == 0 and can_time:
         print(f"[vita_amd.parallel] decode exchange: {choice} (kernel {tk_all / max(steps, 1):.3f} ms/token, fused "
