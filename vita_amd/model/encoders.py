@@ -139,14 +139,13 @@ class InternViTVisionTower(_HipModule):
         patches = ops.vit_patchify(pix, v.patch_size, w["kpad"])
         pe = ops.gemm(patches, w["patch_w"], bias=w["patch_b"])
         x = ops.vit_assemble(pe, w["cls"], w["pos"], n, N, C)                    # [n*N, C]
-        attn = torch.empty((n * N, C), dtype=torch.float32, device=self._device)
         layers = []
         # every LayerNorm after the first rides on the Linear that produces its input (ops.gemm(ln=...): the split-K reducer
         # holds whole rows, so the norm costs no launch of its own at one tile)
         h = ops.layernorm(x, w["layers"][0]["n1w"], w["layers"][0]["n1b"], v.layer_norm_eps) if w["layers"] else None
         if not self.per_operator and w["layers"]:
             # one library call per block (vh_encoder_layer): 24 host calls per pass instead of ~170
-            sc = ops.EncoderScratch(n * N, C, w["layers"][0]["fc1_w"].shape[0], self._device)
+            sc = ops.encoder_scratch(n * N, C, w["layers"][0]["fc1_w"].shape[0], self._device)
             # planes mode (r04): LayerNorm / attention / GELU outputs travel as the bf16 hi/lo planes the weight-streaming GEMM consumes
             # (one-round tilings: qkv / fc1 25 % faster at one tile, 30-36 % on 8-image batches; profiles/r04_enc_sp_sweep.jsonl)
             planes = _VIT_PLANES and C % 64 == 0 and sc.ws.numel() * sc.ws.element_size() >= 4 * n * N * C
@@ -161,6 +160,7 @@ class InternViTVisionTower(_HipModule):
                     layers.append(x.clone().view(n, N, C))
             out = ops.vit_pixel_shuffle(x, n, g, C, self.scale_pix_shuffle)
             return (out, layers) if want_layers else out
+        attn = torch.empty((n * N, C), dtype=torch.float32, device=self._device)
         for li, L in enumerate(w["layers"]):
             qkv = ops.gemm(h, L["qkv_w"], bias=L["qkv_b"])                        # [n*N, 3C] = (three, head, d)
             ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], attn, B=n, Hq=nh, Hkv=nh, Sq=N, Sk=N, d=d, ldq=3 * C,
@@ -374,7 +374,7 @@ class WhaleAudioEncoder(_HipModule):
         h = ops.layernorm(y, w["layers"][0]["n1w"], w["layers"][0]["n1b"], a.layer_norm_eps) if w["layers"] else None
         block_calls = not self.per_operator and bool(w["layers"])
         if block_calls:
-            sc = ops.EncoderScratch(T2, C, w["layers"][0]["fc1_w"].shape[0], self._device)
+            sc = ops.encoder_scratch(T2, C, w["layers"][0]["fc1_w"].shape[0], self._device)
             for li, L in enumerate(w["layers"]):
                 nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
                 nn_ = (nxt["n1w"], nxt["n1b"]) if nxt is not None else (w["an_w"], w["an_b"])

@@ -148,6 +148,23 @@ class EncoderScratch:
         self.ws = _scratch(device, min(8 * 4 * M * max(3 * Cw, F), 96 << 20))
 
 
+_ENC_SCRATCH = {}
+
+
+def encoder_scratch(M, Cw, F, device):
+    """EncoderScratch for (M, C, F), kept per (device, current stream) across passes: building it costs six allocations (~0.1 ms of host
+    time in front of a tower pass, r04 trace); reuse is stream-ordered like _scratch.  The last four shapes are kept."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, int(M), int(Cw), int(F))
+    sc = _ENC_SCRATCH.pop(key, None)
+    if sc is None:
+        sc = EncoderScratch(M, Cw, F, device)
+        while len(_ENC_SCRATCH) >= 4:
+            _ENC_SCRATCH.pop(next(iter(_ENC_SCRATCH)))
+    sc.ws = _scratch(device, min(8 * 4 * M * max(3 * Cw, F), 96 << 20))     # (the shared split-K scratch may have been regrown)
+    _ENC_SCRATCH[key] = sc
+    return sc
+
+
 def encoder_layer(x, h_in, h_out, L, sc, *, heads, B, act, eps, next_norm=None, p=None, bias_u=None, bias_v=None, klen=-1, chunk=0,
                   left=-1, planes=False):
     """One pre-norm transformer block in ONE library call (vh_encoder_layer): x [M, C] updated in place, h_in = LN(x; norm1),
