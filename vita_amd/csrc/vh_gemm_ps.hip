@@ -389,7 +389,9 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
         for (int c = 3; c < 12; ++c)
             if ((long)((nrt + c - 1) / c) * NT * a.ksplit <= grid) { a.rt_cap = c; break; }
     }
-    if (cfg == 2) return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt != 0);   // specialised waves (vh_gemm_sp.hip)
+    // specialised waves (vh_gemm_sp.hip).  Weight loads WITHOUT the non-temporal hint unless forced (ps_nt = 1): same time (527 vs 530 us gate|up,
+    // prefill 8.64-8.71 ms per 8 layers either way) and 6 % fewer fabric-side fetches (2.35 vs 2.49 GB: profiles/r04_fetch_nt_ab.txt)
+    if (cfg == 2) return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt > 0);
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
     // round is M-split relies on L2 for the second reader of each weight tile (gate|up: +5 % with nt)
     bool nt = vh_tuning()->ps_nt > 0;

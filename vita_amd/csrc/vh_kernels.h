@@ -21,7 +21,7 @@ struct VhTuning {
     int prefill_fuse_rows = 1; // single-rank prefill: K-split slabs summed by the consuming norm kernel (VhRowUpdate); 0 = separate slab-sum / combine launches
     int ps_cfg = -1;           // vh_gemm_ps variant: -1 = by rows per group (0 up to 64 rows, else 2), 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights,
                                // 2 = 192 rows, 12 specialised waves (8 MFMA-only + 2 weight stagers + 2 activation DMA: vh_gemm_sp.hip)
-    int ps_nt = -1;            // vh_gemm_ps non-temporal weight loads: -1 = unless the last round is M-split (default), 0 = never, 1 = always
+    int ps_nt = -1;            // vh_gemm_ps non-temporal weight loads: -1 = default (8-wave kernels: unless the last round is M-split; specialised kernel: off), 0 = never, 1 = always
     int tp_overlap = 1;        // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
     int moe_ksplit = -4;       // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
     int force_allreduce = 0;   // tests: run the collective hook even when tp_world == 1
