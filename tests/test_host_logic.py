@@ -242,13 +242,14 @@ def test_removed_knobs_are_rejected():
     """vh_tune refuses keys of variants that no longer exist (a script that still sets them must fail loudly)."""
     import pytest
     from vita_amd import _lib
-    for key in ("gateup_variant", "down_grid", "dec_prefetch", "batch_moe", "fuse_attn_oproj", "prefill_moe_gemm"):
+    for key in ("gateup_variant", "down_grid", "dec_prefetch", "batch_moe", "fuse_attn_oproj", "prefill_moe_gemm", "attn_presplit", "gemm_tall",
+                "ps_rtcap", "reduce_wave"):
         with pytest.raises(_lib.VitaHipError):
             _lib.tune(key, 1)
     _lib.tune("attn_rows", 0)      # a live key is accepted (no GPU needed)
     assert len(KNOBS_R04) <= 15
     for key in KNOBS_R04:
-        _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4}.get(key, 0))
+        _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4, "attn_fa": 1}.get(key, 0))    # (every key back at its default)
 
 
 KNOBS_R04 = ("batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
