@@ -11,8 +11,8 @@ S = 1 + 139 + 1280 + 32 + 44 = 1496 prompt rows through the Mixtral backbone at 
 layer-streamed fp32 oracle: encoder outputs, spliced embeddings, router top-2 sets of every layer and prompt row, hidden
 states, the logits of 8 greedy steps (< 1e-3) and the greedy ids (==).
 
-The backbone runs VITA_ASSETS_LAYERS layers (default 8: the oracle streams 5.7 GB of fp32 weights per layer over 1500 rows;
-tests/test_realgeom_gpu.py runs all 32 on the S = 552 request)."""
+The backbone runs all 32 layers (r05; VITA_ASSETS_LAYERS=n shortens it for a quick run: the oracle streams 5.7 GB of fp32
+weights per layer over 1500 rows, ~160 s at full depth)."""
 import os
 import time
 
@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 T_NEW = 8
 SEED = 0
-LAYERS = int(os.environ.get("VITA_ASSETS_LAYERS", "8"))
+LAYERS = int(os.environ.get("VITA_ASSETS_LAYERS", "32"))
 
 
 def assets_request(cfg):

@@ -99,7 +99,7 @@ def _tp_cfg(world):
     return cfg
 
 
-def _tp_worker(rank, world, port, overlap, ret, fuse=1):
+def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
     import torch.distributed as dist
     from vita_amd import _lib
     from vita_amd.checkpoint import pack_mixtral, synth_state_dict
@@ -126,7 +126,7 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1):
         assert eng.c.n_q_heads == t.num_attention_heads // world and eng.c.n_kv_heads == t.num_key_value_heads // world
         assert eng.c.inter == t.intermediate_size // world
         _lib.tune("tp_overlap", overlap)
-        name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
+        name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective=collective)
         rng = np.random.default_rng(5)
         ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
         emb = packed["embed"][torch.as_tensor(ids, device=dev)].float()
@@ -142,6 +142,18 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def _require_ipc(names, what):
+    """The sharded-engine tests are ABOUT the library's IPC transport: a run whose ranks agreed on another collective FAILS
+    (VERDICT r04 #1d; it used to xfail, i.e. a box where the IPC bring-up loses kept the suite green).  VITA_ALLOW_GLOO_FALLBACK=1
+    turns the failure back into an xfail for a box that is known not to support same-device IPC mapping."""
+    if names == {"ipc"}:
+        return
+    msg = f"{what}: the ranks agreed on {names} instead of the IPC all-reduce: the IPC transport was NOT exercised"
+    if os.environ.get("VITA_ALLOW_GLOO_FALLBACK", "") == "1":
+        pytest.xfail(msg)
+    pytest.fail(msg)
 
 
 def comm_status(eng):
@@ -169,9 +181,7 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     # torch.distributed (gloo) proves nothing about vh_comm under the sharded engine (VERDICT r03 "What's weak" #3)
     names = {ret[r][0] for r in range(world)}
     assert len(names) == 1, {r: ret[r][0] for r in range(world)}
-    if names != {"ipc"}:
-        pytest.xfail(f"world {world}: the ranks agreed on {names} instead of the IPC all-reduce (bring-up lost on this box): "
-                     "the sharded engine ran over gloo, the IPC transport was NOT exercised")
+    _require_ipc(names, f"world {world}")
     assert all(ret[r][4] in (0, None) for r in range(world)), {r: ret[r][4] for r in range(world)}
     print("collective at world", world, ":", names)
     shards = [ret[r][3] for r in range(world)]
@@ -210,6 +220,28 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
         assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
+    assert ret[0][1] == ret[1][1] == ref_ids
+    assert np.array_equal(ret[0][2], ret[1][2])
+    assert np.abs(ret[0][2] - ref_lg).max() < 1e-3
+
+
+def test_tp2_engine_over_torch_allreduce_fallback(dev):
+    """the LAST choice of setup_tensor_parallel (collective = "torch": torch.distributed.all_reduce called back from the C layer
+    loop through vh_mixtral_set_allreduce — what a job gets when both the IPC transport and native RCCL lose their bring-up):
+    two engine processes over gloo, ids == the unsharded fp32 oracle, both ranks bit-identical (no test referenced
+    use_torch_allreduce after the r04 prune, yet every failed bring-up lands there)."""
+    import torch.multiprocessing as mp
+    from oracle import mixtral as om
+    from vita_amd.checkpoint import synth_state_dict
+    from vita_amd.config import VitaConfig
+    ret = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(2, _free_port(), 0, ret, 0, "torch"), nprocs=2, join=True)
+    cfg = VitaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=3, parts=("text",))
+    ids = np.random.default_rng(5).integers(3, cfg.text.vocab_size, size=37).tolist()
+    ref_ids, ref_lg = om.MixtralOracle(sd, cfg.text).greedy(sd["model.embed_tokens.weight"][ids], 10)
+    assert ret[0][0] == ret[1][0] == "torch"
+    assert ret[0][4] is None and ret[1][4] is None            # no IPC communicator was attached
     assert ret[0][1] == ret[1][1] == ref_ids
     assert np.array_equal(ret[0][2], ret[1][2])
     assert np.abs(ret[0][2] - ref_lg).max() < 1e-3
@@ -269,8 +301,7 @@ def test_tp8_released_shard_shapes_match_oracle(dev):
     mp.spawn(_tp_real_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     names = {ret[r][0] for r in range(world)}
     assert len(names) == 1, dict((r, ret[r][0]) for r in range(world))
-    if names != {"ipc"}:
-        pytest.xfail(f"the ranks agreed on {names}, not on the IPC all-reduce: released-shape TP ran over gloo on this box")
+    _require_ipc(names, "released-shape TP = 8")
     assert all(ret[r][3] == 0 for r in range(world)) and all(ret[r][4] == "kernel" for r in range(world))
     cfg = VitaConfig()
     t = cfg.text

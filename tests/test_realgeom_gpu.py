@@ -84,7 +84,23 @@ def test_encoders_full_depth(run, oracle_embeds):
     assert_close("spliced inputs_embeds", run["emb"], o["emb"], atol=2e-3, rtol=1e-3)
 
 
-def test_backbone_32_layers_prefill_and_greedy(run, oracle_embeds):
+@pytest.fixture(scope="module")
+def oracle_ref(run, oracle_embeds):
+    """ONE teacher-forced pass of the layer-streamed fp32 oracle over prompt + the device's generated tokens; shared by the
+    single-GPU test and the TP = 8 test below (the same request, and — when both are right — the same tokens)."""
+    cfg = run["cfg"]
+    t, L = cfg.text, cfg.text.num_hidden_layers
+    S = run["emb"].shape[0]
+    toks = run["toks"]
+    cap = sorted(run["hidden"])
+    full = np.concatenate([oracle_embeds["emb"], stream.embed_rows(t, toks[:-1], SEED)], 0)
+    t0 = time.time()
+    ref = stream.forward(t, SEED, full, n_layers=L, capture=cap, logits_from=S - 1, verbose=True)
+    print(f"[realgeom] oracle backbone ({L} layers, {full.shape[0]} rows) in {time.time() - t0:.1f}s")
+    return ref
+
+
+def test_backbone_32_layers_prefill_and_greedy(run, oracle_embeds, oracle_ref):
     """A11-A14: one teacher-forced oracle forward over prompt + generated tokens vs the device's prefill + 15 decode steps."""
     cfg = run["cfg"]
     t, L = cfg.text, cfg.text.num_hidden_layers
@@ -92,10 +108,7 @@ def test_backbone_32_layers_prefill_and_greedy(run, oracle_embeds):
     toks = run["toks"]
     assert S == 552 and len(toks) == T_NEW
     cap = sorted(run["hidden"])
-    full = np.concatenate([oracle_embeds["emb"], stream.embed_rows(t, toks[:-1], SEED)], 0)
-    t0 = time.time()
-    ref = stream.forward(t, SEED, full, n_layers=L, capture=cap, logits_from=S - 1, verbose=True)
-    print(f"[realgeom] oracle backbone ({L} layers, {full.shape[0]} rows) in {time.time() - t0:.1f}s")
+    ref = oracle_ref
     # router decisions of every layer over the prompt rows
     r_dev, r_ref = np.sort(run["route"], -1), np.sort(ref["route"][:, :S], -1)
     mism = np.argwhere((r_dev != r_ref).any(-1))
@@ -106,9 +119,113 @@ def test_backbone_32_layers_prefill_and_greedy(run, oracle_embeds):
         # (|x| grows to ~40 by layer 31), 3e-4 of the tensor's largest magnitude + 1e-3 relative
         h_ref = ref["hidden"][l][:S]
         assert_close(f"hidden after layer {l}", run["hidden"][l], h_ref, atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
+    # the drift is linear in depth (one fp32 re-association per layer): its SLOPE is asserted, not only its end point
+    # (the 3e-4 * max|ref| bound is 1.4e-2 absolute at layer 31 against 5.3e-3 measured)
+    if L >= 32:
+        errs = {l: float(np.abs(run["hidden"][l] - ref["hidden"][l][:S]).max()) for l in cap}
+        print("hidden-state error by depth:", {l: f"{e:.2e}" for l, e in errs.items()})
+        assert errs[L - 1] <= 2.5e-4 * L, f"layer {L - 1}: {errs[L - 1]:.2e} exceeds 2.5e-4 per layer"
+        assert errs[15] <= 2.5e-4 * 16, f"layer 15: {errs[15]:.2e} exceeds 2.5e-4 per layer"
     ref_ids = ref["logits"].argmax(-1).tolist()
     print("device ids", toks)
     print("oracle ids", ref_ids)
     print(report("logits of the 16 steps", run["logits"], ref["logits"]))
     assert toks == ref_ids                                               # greedy ids bit-exact
     assert np.abs(run["logits"] - ref["logits"]).max() < 1e-3            # north-star: logits within 1e-3 (fp32)
+
+
+# ---- BASELINE configs[3]: the same omni request under TP = 8 at FULL depth ------------------------------------------------------
+TP8_NEW = 8
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
+    """one rank of the released TP = 8 partition (4 q heads + 1 KV head, 1792 columns of every expert, 6470 vocabulary rows;
+    web_demo/vllm_tools/vllm_file/mixtral.py:375-414,441-476,939-951) running the WHOLE omni request: replicated encoders +
+    projector, splice, sharded prefill (64 bulk all-reduces of 9 MB) and greedy decode (65 exchanges per token) over the
+    library's IPC all-reduce, eight processes on one GPU."""
+    import torch.distributed as dist
+    from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
+    from vita_amd.parallel import setup_tensor_parallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("VITA_AMD_TP_FUSE", None)
+    os.environ.pop("VITA_AMD_TP_TRIAL", None)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = VitaConfig()
+        cfg.text.num_hidden_layers = layers
+        packed = synth_mixtral_device(cfg, dev, seed=SEED, rank=rank, world=world)
+        # the replicated encoder weights: the parent's state dict, memory-mapped (generating 0.7 B values takes ~45 s per process)
+        sd_enc = {k: v.numpy() for k, v in torch.load(enc_path, mmap=True, weights_only=True).items()}
+        model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=TP8_NEW + 8, max_prefill=640,
+                                       rank=rank, world=world, keep_scores=True)
+        eng = model.engine
+        assert (eng.c.n_q_heads, eng.c.n_kv_heads, eng.c.inter, eng.c.vocab_n) == (4, 1, 1792, 6470)
+        name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
+        model.get_vision_tower().load_model()
+        req = make_request(cfg)
+        pix = torch.from_numpy(req["pixel_values"]).to(dev)
+        feats = torch.from_numpy(req["fbank"]).to(dev)
+        ids = torch.tensor([req["input_ids"]], dtype=torch.long, device=dev)
+        audios = {"audios": feats[None], "lengths": torch.tensor([feats.shape[0]], device=dev)}
+        _, _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix, audios)
+        eng.prefill(emb[0])
+        eng.decode(TP8_NEW - 1)
+        torch.cuda.synchronize()
+        lg = eng.logits_all[:TP8_NEW].cpu()
+        dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
+        c = getattr(eng, "_comm", None)
+        ret[rank] = (name, eng.generated(), lg.numpy() if rank == 0 else None, c.status() if c is not None else None,
+                     eng.decode_exchange, int(emb.shape[1]), lg.numpy().tobytes() if rank > 0 else None)
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_tp8_full_depth_omni_matches_oracle(run, oracle_ref, tmp_path):
+    """BASELINE configs[3] (VERDICT r04 #1a): world 8 — eight engine processes on ONE GPU — at the released shard shapes, ALL
+    layers, the omni request of make_request() (encoders + splice + prefill S = 552 + 8 greedy steps) over the IPC all-reduce:
+    64 all-reduces per forward of re-ordered fp32 sums in front of a discontinuous router.  Greedy ids == the streamed fp32
+    oracle's and logits within 1e-3 (the oracle pass is the one test_backbone_32_layers_prefill_and_greedy paid for: same
+    request, and the tokens must agree), every rank bit-identical, no spin time-out."""
+    import torch.multiprocessing as mp
+    cfg = run["cfg"]
+    L = cfg.text.num_hidden_layers
+    world = 8
+    t0 = time.time()
+    enc_path = str(tmp_path / "encoders.pt")
+    torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in run["sd_enc"].items()}, enc_path)
+    ret = mp.Manager().dict()
+    mp.spawn(_tp8_omni_worker, args=(world, _free_port(), L, enc_path, ret), nprocs=world, join=True)
+    print(f"[realgeom] TP = 8 ranks done in {time.time() - t0:.1f}s")
+    names = {ret[r][0] for r in range(world)}
+    assert len(names) == 1, {r: ret[r][0] for r in range(world)}
+    if names != {"ipc"}:
+        msg = f"the ranks agreed on {names}, not on the IPC all-reduce: configs[3] ran over gloo on this box"
+        if os.environ.get("VITA_ALLOW_GLOO_FALLBACK", "") == "1":
+            pytest.xfail(msg)
+        pytest.fail(msg)
+    assert all(ret[r][3] == 0 for r in range(world)), {r: ret[r][3] for r in range(world)}
+    assert all(ret[r][5] == 552 for r in range(world))
+    toks = ret[0][1]
+    lg0 = ret[0][2]
+    for r in range(1, world):
+        assert ret[r][1] == toks, f"rank {r}: {ret[r][1]} vs rank 0 {toks}"
+        assert ret[r][6] == lg0.tobytes(), f"rank {r} logits differ from rank 0's"
+    ref_lg = oracle_ref["logits"][:TP8_NEW]
+    ref_ids = ref_lg.argmax(-1).tolist()
+    err = float(np.abs(lg0 - ref_lg).max())
+    print(f"TP = 8, {L} layers, S = 552 omni request: ids {toks}, oracle {ref_ids}, TP = 1 device {run['toks'][:TP8_NEW]}, "
+          f"max |logit diff| {err:.2e}, exchange form {ret[0][4]}")
+    assert toks == ref_ids
+    assert err < 1e-3

@@ -190,3 +190,98 @@ def test_decode_exchange_vote_is_rank_consistent():
         assert a["shared_device"][0] == "kernel" and a["shared_on_one_rank_only"][0] == "kernel"
         assert a["no_timing"][0] == "kernel"
         assert ret["label0"] == ret["label1"] == ("ipc+fused", "rccl")
+
+
+class _ScriptedEngine:
+    """host-only stand-in for MixtralEngine inside choose_decode_exchange: counts calls, can fail a chosen leg on a chosen rank."""
+
+    def __init__(self, rank, fail_at=None):
+        self.max_new, self.max_prefill, self.max_ctx = 80, 64, 256
+        self.packed = {"embed": torch.zeros(16, 8)}
+        self.counters = torch.zeros(4, dtype=torch.int32)
+        self.rank, self.fail_at = rank, fail_at          # fail_at = (rank, leg): prefill of that leg raises there
+        self.legs, self.resets, self.decodes = 0, 0, 0
+
+    def prefill(self, emb):
+        leg = self.legs
+        self.legs += 1
+        if self.fail_at == (self.rank, leg):
+            raise RuntimeError("scripted failure")
+        dist.barrier()                                   # the real engine's per-layer exchange: a collective
+
+    def decode(self, n):
+        self.decodes += 1
+        dist.barrier()
+
+    def reset(self):
+        self.resets += 1
+
+
+class _ScriptedComm:
+    def status(self):
+        return 0
+
+
+def _trial_worker(rank, world, port, ret):
+    import vita_amd.parallel as par
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par._device_sync = lambda: None
+    tuned = []
+    import vita_amd._lib as lib
+    lib_tune, lib.tune = lib.tune, (lambda k, v: tuned.append((k, v)))
+    try:
+        out = {}
+        # 1. a healthy trial: both legs run on both ranks, the engine is reset, the ranks agree
+        os.environ.pop("VITA_AMD_TP_FUSE", None)
+        os.environ["VITA_AMD_TP_TRIAL"] = "1"
+        e = _ScriptedEngine(rank)
+        out["healthy"] = (par.choose_decode_exchange(e, _ScriptedComm(), rank, world, dist, "cpu", "gloo", True), e.legs, e.resets)
+        # 2. rank 1 fails in the FIRST leg: rank 0 must not be left inside a collective; nobody runs the second leg
+        e = _ScriptedEngine(rank, fail_at=(1, 0))
+        if rank == 1:
+            orig = e.prefill
+
+            def failing(emb, orig=orig):
+                try:
+                    orig(emb)
+                except RuntimeError:
+                    for _ in range(3):                   # rank 0's prefill / decode(2) / decode(steps) of this leg: on the device its
+                        dist.barrier()                   # bounded spins time out and the calls return; here: join its barriers
+                    raise
+            e.prefill = failing
+        out["one_rank_fails"] = (par.choose_decode_exchange(e, _ScriptedComm(), rank, world, dist, "cpu", "gloo", True), e.legs, e.resets)
+        # 3. the forced form must be the same on every rank
+        os.environ["VITA_AMD_TP_FUSE"] = "1" if rank == 0 else "0"
+        try:
+            par.choose_decode_exchange(_ScriptedEngine(rank), _ScriptedComm(), rank, world, dist, "cpu", "gloo", True)
+            out["mismatch"] = "no error"
+        except Exception as ex:
+            out["mismatch"] = type(ex).__name__
+        os.environ["VITA_AMD_TP_FUSE"] = "1"
+        out["forced"] = par.choose_decode_exchange(_ScriptedEngine(rank), _ScriptedComm(), rank, world, dist, "cpu", "gloo", True)
+        ret[rank] = out
+    finally:
+        lib.tune = lib_tune
+        os.environ.pop("VITA_AMD_TP_FUSE", None)
+        os.environ.pop("VITA_AMD_TP_TRIAL", None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_decode_exchange_trial_is_all_or_none():
+    """every leg of the timed trial is entered by all ranks or by none, a failing rank takes its peers to the vote
+    instead of leaving them in a collective, a forced form is checked across the ranks, and the engine is reset afterwards."""
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_trial_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        a, b = ret[0], ret[1]
+        assert a["healthy"][0] == b["healthy"][0] and a["healthy"][0] in ("kernel", "fused")
+        assert a["healthy"][1:] == b["healthy"][1:] == (2, 1)                 # two legs, one reset
+        assert a["one_rank_fails"][0] == b["one_rank_fails"][0] == "kernel"
+        assert a["one_rank_fails"][1] == b["one_rank_fails"][1] == 1          # the second leg was entered by nobody
+        assert a["one_rank_fails"][2] == b["one_rank_fails"][2] == 1
+        assert a["mismatch"] == b["mismatch"] == "VitaHipError"
+        assert a["forced"] == b["forced"] == "fused"

@@ -184,6 +184,12 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_decode(self.h, int(n_steps), self._stream()), "vh_mixtral_decode")
         self.n_gen += int(n_steps)
 
+    def reset(self):
+        """forget the current request: position and generated-token counters to zero, every KV page back to the pool
+        (vh_mixtral_reset); weights, workspace and collective stay."""
+        check(self.lib.vh_mixtral_reset(self.h, self._stream()), "vh_mixtral_reset")
+        self.n_gen = 0
+
     @property
     def logits(self):
         """scores of the most recent step (row n_gen-1 of the history, or the single row) as the engine keeps them: under a

@@ -14,6 +14,7 @@ import ctypes
 import os
 import sys
 import threading
+import time
 
 import torch
 
@@ -156,49 +157,83 @@ def vote_decode_exchange(dist, same_device, t_kernel_ms, t_fused_ms, fused_ok, d
     return ("fused" if tf < (1.0 - margin) * tk else "kernel"), tk, tf
 
 
+def _device_sync():
+    torch.cuda.synchronize()
+
+
+def _minmax(dist, value, device, backend):
+    """(min, max) of an integer over the ranks (collective)."""
+    t = torch.tensor([-int(value), int(value)], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lo, hi = t.tolist()
+    return -int(lo), int(hi)
+
+
 def choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same_device, steps=32):
     """Times `steps` greedy decode steps of THIS engine under both exchange forms (tp_fuse 0 / 1) and lets the ranks vote
     (no environment variable on a real node).  Ranks sharing a device skip the timing — the fused form's
     waiting blocks starve the other ranks there (profiles/r03_tp_fuse_latency_*.json) — and get "kernel".
-    VITA_AMD_TP_FUSE=0/1 still forces a form (debugging); VITA_AMD_TP_TRIAL=1 runs the timed trial even when the ranks share a device
-    (tests: the trial is the code a real node executes at bring-up).  Leaves the engine reset for the caller's first prefill."""
+    VITA_AMD_TP_FUSE=0/1 still forces a form (debugging) — the ranks CHECK that they were all given the same value: the two
+    forms are different kernels on the two sides of one exchange; VITA_AMD_TP_TRIAL=1 runs the timed trial even when the ranks
+    share a device (tests: the trial is the code a real node executes at bring-up).
+
+    Every step of the trial that contains a collective (the engine's per-layer exchanges) is entered by ALL ranks or by none:
+    the ranks all-reduce an "ok so far" flag in front of each leg and behind it (a rank that failed used to walk
+    to the vote while its peers sat in a barrier or inside a device-side exchange until the spin time-out).  Leaves the engine
+    reset (vh_mixtral_reset) for the caller's first prefill."""
     from . import _lib
-    forced = os.environ.get("VITA_AMD_TP_FUSE", "")
-    if forced in ("0", "1"):
-        _lib.tune("tp_fuse", int(forced))
-        return "fused" if forced == "1" else "kernel"
+    forced = {"0": 0, "1": 1}.get(os.environ.get("VITA_AMD_TP_FUSE", ""), -1)
+    lo, hi = _minmax(dist, forced, device, backend)
+    if lo != hi:
+        raise _lib.VitaHipError(f"VITA_AMD_TP_FUSE differs between the ranks (min {lo}, max {hi}; -1 = unset): every rank "
+                                "must run the same form of the decode exchange")
+    if forced >= 0:
+        _lib.tune("tp_fuse", forced)
+        return "fused" if forced == 1 else "kernel"
     tk = tf = 0.0
     ok = True
     steps = min(steps, max(0, (eng.max_new - 4) // 2))
     force_trial = os.environ.get("VITA_AMD_TP_TRIAL", "") == "1"
     can_time = (force_trial or not same_device) and steps >= 4 and eng.max_prefill >= 8 and eng.max_ctx > 8 + 2 * steps + 4
+    can_time = _agree(dist, can_time, device, backend)          # engines are built alike, but the trial is all-or-none
     if can_time:
+        emb = None
         try:
             emb = eng.packed["embed"][:8].float().contiguous()          # any 8 rows: only the timing matters
-            for fuse in (0, 1):
+        except Exception as e:
+            print(f"[vita_amd.parallel] rank {rank}: decode-exchange trial could not start: {e}", file=sys.stderr)
+            ok = False
+        for fuse in (0, 1):
+            if not _agree(dist, ok, device, backend):                    # nobody enters a leg unless every rank can
+                ok = False
+                break
+            ms = 0.0
+            try:
                 _lib.tune("tp_fuse", fuse)
                 eng.prefill(emb)
                 eng.decode(2)                                            # first launches of these kernels
-                torch.cuda.synchronize()
-                dist.barrier()
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                ev[0].record()
+                _device_sync()
+                t0 = time.perf_counter()                                 # 32 steps are tens of ms: wall time between two syncs
                 eng.decode(steps)
-                ev[1].record()
-                torch.cuda.synchronize()
-                ms = ev[0].elapsed_time(ev[1])
-                if fuse:
-                    tf = ms
-                else:
-                    tk = ms
+                _device_sync()
+                ms = (time.perf_counter() - t0) * 1e3
                 if comm.status() != 0 or int(eng.counters[3].item()) != 0:
                     ok = False
-                    break
-        except Exception as e:
-            print(f"[vita_amd.parallel] rank {rank}: decode-exchange trial failed: {e}", file=sys.stderr)
-            ok = False
+            except Exception as e:
+                # the peers' kernels of this leg run into their bounded spins (sticky error word) and arrive at the flag below
+                print(f"[vita_amd.parallel] rank {rank}: decode-exchange trial failed: {e}", file=sys.stderr)
+                ok = False
+            if fuse:
+                tf = ms
+            else:
+                tk = ms
+        ok = _agree(dist, ok, device, backend)                          # behind the last leg: one verdict for all ranks
     choice, tk_all, tf_all = vote_decode_exchange(dist, (same_device and not force_trial) or not can_time, tk, tf, ok, device, backend)
     _lib.tune("tp_fuse", 1 if choice == "fused" else 0)
+    try:
+        eng.reset()                                                      # host_pos / n_gen back to zero: the trial leaves no state
+    except Exception as e:
+        print(f"[vita_amd.parallel] rank {rank}: engine reset after the trial failed: {e}", file=sys.stderr)
     if rank == 0 and can_time:
         print(f"[vita_amd.parallel] decode exchange: {choice} (kernel {tk_all / max(steps, 1):.3f} ms/token, fused "
               f"{tf_all / max(steps, 1):.3f} ms/token over {steps} steps, slowest rank)", file=sys.stderr)
