@@ -37,9 +37,9 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
-/* Kernel-variant knobs (15 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
+/* Kernel-variant knobs (16 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
  * "prefill_attn_gemm", "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse",
- * "comm_allow_coarse"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
+ * "comm_allow_coarse", "dec_overlap"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
  * measured-best variants, ids are identical across variants.  Unknown keys (e.g. of variants removed in r04) return VH_E_ARG. */
 int vh_tune(const char* key, int value);
 
@@ -253,8 +253,17 @@ int vh_mixtral_cancel_rccl(vh_mixtral_t* m);
 int vh_mixtral_route_debug(vh_mixtral_t* m, int* ids_out);
 int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, float* logits_out, float* hidden_dbg,
                        void* stream);
-/* Run n_steps greedy decode steps back to back with no host interaction. */
+/* Run n_steps greedy decode steps back to back with no host interaction.  On one rank the step runs the OVERLAPPED schedule
+ * (vh_tune("dec_overlap", 1), the default): the attention and O-projection kernels of a layer are enqueued on two side streams
+ * of the engine so that their launch, K / V-tile and weight loads and prologue run under the kernel before them; their inputs
+ * and outputs travel as tagged granules.  `stream` still brackets the call: the side streams start behind everything queued on
+ * it and it ends behind them.  The first call probes once whether streams of this process really run concurrently; if not,
+ * the one-stream schedule is used (same kernels, same results bit for bit).
+ * Replaces the per-token forward of HF MixtralDecoderLayer x L as reached from vita/model/language_model/vita_mixtral.py:158-173. */
 int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
+/* -1: not probed yet (no decode call so far), 0: the overlapped schedule is unavailable here (streams do not run concurrently,
+ * tensor parallel engine, or switched off), 1: in use. */
+int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m);
 /* Device pointers into the engine state (for the host loop and the tests). */
 const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */
 const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[4]: {pos, n_generated, attn hand-off counter, device error flag (0 = ok)} */

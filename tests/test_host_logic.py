@@ -247,13 +247,15 @@ def test_removed_knobs_are_rejected():
         with pytest.raises(_lib.VitaHipError):
             _lib.tune(key, 1)
     _lib.tune("attn_rows", 0)      # a live key is accepted (no GPU needed)
-    assert len(KNOBS_R04) <= 15
-    for key in KNOBS_R04:
-        _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4, "attn_fa": 1}.get(key, 0))    # (every key back at its default)
+    assert len(KNOBS) <= 16
+    for key in KNOBS:
+        _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4, "attn_fa": 1,
+                        "dec_overlap": 1}.get(key, 0))    # (every key back at its default)
 
 
-KNOBS_R04 = ("batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
-             "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse", "comm_allow_coarse")
+# r04's 15 keys + r05's dec_overlap (the overlapped decode schedule; 0 = the one-stream schedule every earlier round ran)
+KNOBS = ("batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
+         "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse", "comm_allow_coarse", "dec_overlap")
 
 
 def test_ctypes_structs_match_the_header(tmp_path):

@@ -148,6 +148,7 @@ SIGNATURES = {
     "vh_mixtral_counters": (c_void_p, [c_void_p]),
     "vh_mixtral_logits": (c_void_p, [c_void_p]),
     "vh_mixtral_reset": (c_int, [c_void_p, c_void_p]),
+    "vh_mixtral_decode_overlap_state": (c_int, [c_void_p]),
     "vh_mixtral_seq_alloc": (c_int, [c_void_p]),
     "vh_mixtral_seq_free": (c_int, [c_void_p, c_int]),
     "vh_mixtral_seq_prefill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -56,6 +56,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     if (!strcmp(key, "tp_fuse")) { g_tuning.tp_fuse = value; return VH_OK; }
     if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
+    if (!strcmp(key, "dec_overlap")) { g_tuning.dec_overlap = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -386,6 +387,10 @@ struct vh_mixtral {
         cand = cv.take<float>(2 * (c.tp_world > 0 ? c.tp_world : 1));
         route = cv.take<int>(4);
         counters = cv.take<int>(4);  // {pos, n_generated, attn_done (monotonic), device error flag}
+        g_qkv = cv.take<unsigned long long>(nqkv);
+        g_attn = cv.take<unsigned long long>(vh_gran_gemv_len(nq * hd));
+        g_dattn = cv.take<unsigned long long>(vh_gran_gemv_len(H));
+        probe = cv.take<int>(4);
         // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
         part_o = cv.take<float>((size_t)nq * max_splits * hd);
@@ -428,6 +433,16 @@ struct vh_mixtral {
         if (lm_grid > 1024) lm_grid = 1024;
         if (lm_grid < c.tp_world) lm_grid = c.tp_world;   // blk_val / blk_idx also hold the gathered candidates
     }
+    // ---- overlapped decode schedule: attention on sA, O projection on sC, the rest on the caller's stream ----
+    hipStream_t sA = nullptr, sC = nullptr;
+    std::vector<hipEvent_t> ev_pre, ev_q, ev_o;      // per layer: before / after the fused QKV (caller's stream), after the O projection (sC)
+    hipEvent_t ev_fork = nullptr, ev_joinA = nullptr, ev_joinC = nullptr;
+    unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr;   // granule vectors (VhGranVec)
+    int* probe = nullptr;                            // 4 words of the stream-concurrency probe
+    unsigned gran_epoch = 0;                         // last granule tag handed out (0 = never written)
+    int overlap_state = -1;                          // -1 not probed yet, 0 the streams do not run concurrently here, 1 verified
+    unsigned next_tag() { if (++gran_epoch == 0) ++gran_epoch; return gran_epoch; }
+    int ensure_overlap_streams(hipStream_t st);
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
     hipStream_t cs = nullptr;    // communication stream of the overlapped tensor-parallel prefill
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // half computed / half reduced
@@ -516,6 +531,12 @@ void vh_mixtral_destroy(vh_mixtral_t* m) {
     for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) hipEventDestroy(m->ev_r[i]); }
     if (m->cs) hipStreamDestroy(m->cs);
+    for (hipEvent_t e : m->ev_pre) hipEventDestroy(e);
+    for (hipEvent_t e : m->ev_q) hipEventDestroy(e);
+    for (hipEvent_t e : m->ev_o) hipEventDestroy(e);
+    for (hipEvent_t e : {m->ev_fork, m->ev_joinA, m->ev_joinC}) if (e) hipEventDestroy(e);
+    if (m->sA) hipStreamDestroy(m->sA);
+    if (m->sC) hipStreamDestroy(m->sC);
     if (m->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->rccl_comm);
     delete m;
 }
@@ -1002,9 +1023,69 @@ static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, con
     return VH_OK;
 }
 
+// ---- overlapped decode schedule ----------------------------------------------------------------------------------------------
+// A batch-1 decode layer is five dependent launches; QKV (50 MB), attention and the O projection (34 MB) are short enough that the
+// head and tail of each launch — dispatch, first-byte latency of the weight / K-V loads, prologue, drain, the boundary — cost as
+// much as their bytes (r04: 28.5 us per layer for 84 MB that the stream moves in 14).  The schedule below keeps the five kernels
+// and takes the attention and the O projection OFF the stream order: attention(l) is enqueued on sA behind "everything before
+// QKV(l)", the O projection on sC behind QKV(l), so both are resident — K / V tiles and O weights in flight or landed, prologues
+// done — while their predecessor still runs; gate|up (caller's stream, behind QKV) likewise has its router weights in registers
+// when the O projection finishes.  The data dependency travels with the data: qkv, attn_out and delta_attn are tagged granules
+// (VhGranVec) that the consumer waves poll.  Everything else (xb, route, hbuf, delta_moe, xa, the KV cache) stays plain memory
+// ordered by a stream.  Deadlock freedom: a waiting kernel never holds what its producer needs — attention is <= nkv * splits blocks,
+// the O projection 2 and gate|up 1.5 resident blocks per CU of 88 / 120 registers against 512 per SIMD, and the producer of every
+// wait was enqueued before its consumer; every wait is bounded (error word, counters[3]) in case the streams do not overlap after
+// all.  One rank only: under tensor parallelism the exchange kernels / VhXchg own these edges.
+int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
+    if (overlap_state >= 0) return overlap_state;
+    overlap_state = 0;
+    if (hipStreamCreateWithFlags(&sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sC, hipStreamNonBlocking) != hipSuccess)
+        return 0;
+    auto mk = [](hipEvent_t* e) { return hipEventCreate(e) == hipSuccess; };   // (kernel completion events of mode 2 "track the stop time")
+    ev_pre.assign(c.n_layers, nullptr); ev_q.assign(c.n_layers, nullptr); ev_o.assign(c.n_layers, nullptr);
+    for (int l = 0; l < c.n_layers; ++l)
+        if (!mk(&ev_pre[l]) || !mk(&ev_q[l]) || !mk(&ev_o[l])) return 0;
+    if (!mk(&ev_fork) || !mk(&ev_joinA) || !mk(&ev_joinC)) return 0;
+    // probe every PAIR of the three streams (HIP may multiplex streams onto fewer hardware queues: two streams of one queue run
+    // in enqueue order, and a consumer enqueued first would wait for a producer queued behind it): two kernels, one per stream,
+    // each raises its flag and waits (bounded) for the other's
+    hipStream_t pair[3][2] = {{st, sA}, {st, sC}, {sA, sC}};
+    for (int i = 0; i < 3; ++i) {
+        if (hipMemsetAsync(probe, 0, 4 * sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+        vhk_dec_probe(pair[i][0], probe + 0, probe + 1, probe + 2);
+        vhk_dec_probe(pair[i][1], probe + 1, probe + 0, probe + 3);
+        int h[4] = {0, 0, 0, 0};
+        if (hipStreamSynchronize(pair[i][0]) != hipSuccess || hipStreamSynchronize(pair[i][1]) != hipSuccess ||
+            hipMemcpy(h, probe, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (h[2] != 1 || h[3] != 1) return 0;
+    }
+    overlap_state = 1;
+    return overlap_state;
+}
+static bool overlap_wanted(const vh_mixtral* m) {
+    return vh_tuning()->dec_overlap != 0 && m->c.tp_world <= 1 && !vh_tuning()->force_allreduce && m->nq * m->hd <= 14336;
+}
+// the side streams start behind everything already queued on st (prefill: KV cache, residual stream) ...
+static bool overlap_begin(vh_mixtral* m, hipStream_t st) {
+    if (!overlap_wanted(m) || m->ensure_overlap_streams(st) != 1) return false;
+    hipEventRecord(m->ev_fork, st);
+    hipStreamWaitEvent(m->sA, m->ev_fork, 0);
+    hipStreamWaitEvent(m->sC, m->ev_fork, 0);
+    return true;
+}
+// ... and st ends behind them: a caller that synchronises st has the whole step
+static void overlap_end(vh_mixtral* m, hipStream_t st) {
+    hipEventRecord(m->ev_joinA, m->sA);
+    hipEventRecord(m->ev_joinC, m->sC);
+    hipStreamWaitEvent(st, m->ev_joinA, 0);
+    hipStreamWaitEvent(st, m->ev_joinC, 0);
+}
+int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m) { return m ? m->overlap_state : -1; }
+
 // One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
 // mirror of the position (host_pos) is advanced by the CALLER only after the step was enqueued without error.
-static int decode_one_step(vh_mixtral* m, hipStream_t st) {
+// ov: the overlapped schedule (the caller ran overlap_begin and runs overlap_end after its last step).
+static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
@@ -1017,10 +1098,40 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
     bool have_xm = false;
+    const bool ext = ov && vh_tuning()->dec_overlap == 2;
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
+        const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+        if (ov) {
+            int* err = m->counters + 3;
+            const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
+            // attention(l) becomes eligible when everything before QKV(l) has completed: the previous layer's down projection carries
+            // ev_pre[l] as its own completion event (mode 2), else (first layer of a step, mode 1) a marker is recorded here
+            if (!(ext && l > 0)) hipEventRecord(m->ev_pre[l], st);
+            hipStreamWaitEvent(m->sA, m->ev_pre[l], 0);
+            VH_TRY(vhk_dec_attn(m->sA, nullptr, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                                m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
+                                &gq, &ga), "dec attn");
+            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
+                               nullptr, nullptr, &gq, ext ? m->ev_q[l] : nullptr), "dec qkv");
+            if (!ext) hipEventRecord(m->ev_q[l], st);
+            hipStreamWaitEvent(m->sC, m->ev_q[l], 0);
+            VH_TRY(vhk_dec_oproj(m->sC, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, &gd), "dec oproj");
+            if (prof) {
+                // a sampled layer times gate|up ALONE: it starts behind the finished O projection instead of waiting inside the launch
+                hipEventRecord(m->ev_o[l], m->sC);
+                hipStreamWaitEvent(st, m->ev_o[l], 0);
+                hipEventRecord(m->prof_ev[m->prof_used], st);
+            }
+            VH_TRY(vhk_dec_gateup(st, m->xb, nullptr, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
+                                  nullptr, &gd), "dec gateup");
+            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr,
+                                ext && l + 1 < m->c.n_layers ? m->ev_pre[l + 1] : nullptr), "dec down");
+            continue;
+        }
         VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                            m->qkv, have_xm ? &xm : nullptr), "dec qkv");
         VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
@@ -1030,7 +1141,6 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
             return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
         VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
         if (!fuse && m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
-        const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
         if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
         VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
                               m->route, m->hbuf, 0, fuse ? &xa : nullptr), "dec gateup");
@@ -1059,18 +1169,22 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     hipStream_t st = S(stream);
     if (m->poisoned) return fail(VH_E_ARG, "decode: a previous step failed; prefill or reset first");
     if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_decode: sequences own pages of the KV pool (use vh_mixtral_seq_decode)");
+    if (n_steps <= 0) return VH_OK;
+    const bool ov = overlap_begin(m, st);
+    int rc = VH_OK;
     for (int step = 0; step < n_steps; ++step) {
-        if (m->host_pos + 1 >= m->c.max_ctx) return fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx);
-        const int rc = decode_one_step(m, st);
+        if (m->host_pos + 1 >= m->c.max_ctx) { rc = fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx); break; }
+        rc = decode_one_step(m, st, ov);
         if (rc != VH_OK) {
             // the step was not (fully) enqueued: host_pos keeps its value, i.e. it describes the
             // last COMPLETE step; the device state of the partial step is discarded by the next prefill / reset
             m->poisoned = 1;
-            return rc;
+            break;
         }
         m->host_pos += 1;
     }
-    return VH_OK;
+    if (ov) overlap_end(m, st);
+    return rc;
 }
 
 // ---- concurrent sequences (paged KV cache) ---------------------------------------------------------------------------
@@ -1294,19 +1408,23 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
             return VH_OK;
         }
     }
+    if (n <= 0) return VH_OK;
+    const bool ov = overlap_begin(m, st);
+    int rc = VH_OK;
     for (int i = 0; i < n; ++i) {
         const int s = ids[i];
         const int pr = m->ensure_pages(s, m->seqs[s].host_pos + 1, st);   // the step writes K/V of position host_pos
-        if (pr == -1) return fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", s, i);
-        if (pr != 0) return fail(VH_E_HIP, "page table upload failed");
+        if (pr == -1) { rc = fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", s, i); break; }
+        if (pr != 0) { rc = fail(VH_E_HIP, "page table upload failed"); break; }
         m->bind(s);
-        const int rc = decode_one_step(m, st);
+        rc = decode_one_step(m, st, ov);
         if (rc != VH_OK) m->poisoned = 1;
         else m->host_pos += 1;
         m->unbind();
-        if (rc != VH_OK) return rc;
+        if (rc != VH_OK) break;
     }
-    return VH_OK;
+    if (ov) overlap_end(m, st);
+    return rc;
 }
 
 }  // extern "C"

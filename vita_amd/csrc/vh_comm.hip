@@ -49,6 +49,7 @@ struct vh_comm {
     uint32_t generation;                     // tag wraps survived (barrier tags)
     bool connected;
     bool fine_grained;                       // the receive buffer is uncached / coherent for peer stores
+    bool same_device;                        // declared at creation (vh_tune("comm_allow_coarse", 1)): every rank drives THIS device (tests)
     // exchanges fused into the decode kernels (VhXchg): two result vectors (attention / MoE sub-block), the reducers' arrival counter
     float* reduced[2];
     int* counter;
@@ -250,6 +251,7 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     }
     vh_comm* c = new vh_comm{};
     c->rank = rank; c->world = world; c->cap = cap_elems;
+    c->same_device = vh_tuning()->comm_allow_coarse != 0;
     // one-shot needs world * cap granules; bulk (8-byte units): A and B of world * slice_pad fp32 each + two flag arrays
     c->oneshot_units = ((size_t)world * (cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX) + 1) & ~size_t(1);
     c->maxchunk = (int)(cap_elems / ((size_t)world * VH_COMM_CHUNK)) + 2;
@@ -349,8 +351,21 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
         g.offB = g.offA + ((size_t)c->world * g.slice_pad) / 2;            // fp32 pairs per 8-byte unit
         if (g.nchunk > g.maxchunk || g.offB + ((size_t)c->world * g.slice_pad) / 2 > c->region)
             return cfail(VH_E_SHAPE, "vh_comm_allreduce: bulk layout above the region");
+        // Residency.  A block of this kernel SPINS on its peers' flags (phase 2 on every rank's phase 1, phase 3 on the
+        // owners' phase 2; no wait is circular, whatever the grid), so its blocks hold CU slots until every rank has contributed.
+        // One rank per device: <= 128 four-wave blocks sit next to the compute stream's GEMM (whose 12-wave blocks take a CU's whole
+        // register file, one per CU: the second half's GEMM needs CUs WITHOUT a spinning block — 128 blocks leave at least half of
+        // the 256 free).  Ranks SHARING a device (tests: up to 8 processes on one GPU) must leave that half free TOGETHER, or the
+        // slowest rank's GEMM finds no empty CU while the other ranks' blocks spin on its contribution (r05: world 8 at 32 layers,
+        // S = 552, timed out in phase 3 with 8 x 128 spinning blocks): the cap is divided by the ranks on the device.
+        int cap_blocks = 128;
+        if (c->same_device) {
+            cap_blocks = vh_num_cus() / 2 / c->world;
+            if (cap_blocks < 1) cap_blocks = 1;
+            if (cap_blocks > 128) cap_blocks = 128;
+        }
         int grid = c->world * g.nchunk;
-        if (grid > 128) grid = 128;                        // fully resident next to the compute stream's kernels
+        if (grid > cap_blocks) grid = cap_blocks;
         const int vec = (reinterpret_cast<uintptr_t>(buf) & 15) == 0 ? 1 : 0;
         hipLaunchKernelGGL(k_ar_bulk, dim3(grid), dim3(256), 0, st, buf, count, peers, local, g, c->rank, c->world, tag, c->err, vec);
     }

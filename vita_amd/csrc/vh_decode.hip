@@ -28,6 +28,8 @@
 // Reference semantics restated: transformers/models/mixtral/modeling_mixtral.py
 // (MixtralRMSNorm, MixtralAttention + apply_rotary_pos_emb, MixtralTopKRouter,
 // MixtralExperts) as called from vita/model/language_model/vita_mixtral.py:158-173.
+#include <hip/hip_ext.h>
+
 #include "vh_common.h"
 #include "vh_kernels.h"
 
@@ -102,6 +104,72 @@ __device__ __forceinline__ f32x4 xchg_ld4(const float* p) {
     return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
 }
 
+// ---- granule vectors between concurrently resident kernels (VhGranVec, vh_kernels.h) -----------------------------------------
+// Every wait below is WAVE-collective (all 64 lanes run the same number of polls; exits are decided with __all) and bounded: a
+// producer that never publishes ends in the engine's error word (code 7), not in a hang.
+__device__ __forceinline__ size_t gran_pos_gemv(int n) { return (size_t)(((n >> 11) << 3) + (n & 7)) * 256 + ((n >> 3) & 255); }
+__device__ __forceinline__ void gran_put(const VhGranVec& gv, size_t pos, float v) {
+    __hip_atomic_store(reinterpret_cast<xu64*>(gv.g) + pos, ((xu64)gv.tag << 32) | (xu64)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ xu64 gran_ld(const VhGranVec& gv, size_t pos) {
+    return __hip_atomic_load(reinterpret_cast<const xu64*>(gv.g) + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one more unsuccessful poll: true = give up (wave-uniform: spins is, and the error word is one address)
+__device__ __forceinline__ bool gran_spin_fail(unsigned& spins, int* err) {
+    if ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;   // someone else failed
+    if (++spins > VH_GRAN_SPIN_LIMIT) {
+        __hip_atomic_store(err, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    __builtin_amdgcn_s_sleep(8);
+    return false;
+}
+// N granules per lane (positions idx[]), e.g. the two halves of a head's q row for the rotate-half RoPE
+template <int N>
+__device__ __forceinline__ void gran_getn(const VhGranVec& gv, const int (&idx)[N], float (&out)[N]) {
+    unsigned spins = 0;
+    for (;;) {
+        xu64 x[N];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = gran_ld(gv, (size_t)idx[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { ok = ok && ((unsigned)(x[i] >> 32) == gv.tag); out[i] = __uint_as_float((unsigned)x[i]); }
+        if (__all(ok)) return;
+        if (gran_spin_fail(spins, gv.err)) return;
+    }
+}
+// a GEMV block's slice of a layout-1 vector: thread t gets elements [8 (t + 256 j), + 8), j < NJ (zeros past K)
+template <int NJ>
+__device__ __forceinline__ void gran_read_gemv(const VhGranVec& gv, int K, float (&v)[NJ][8]) {
+    const int t = threadIdx.x;
+    unsigned spins = 0;
+    // 1. ONE granule (element 0: a single 8-byte request per wave) until the producer kernel has begun to publish: the sweep
+    //    below moves NJ * 4 KB per wave and must not be repeated for the microseconds a consumer is resident early
+    for (;;) {
+        if ((unsigned)(gran_ld(gv, 0) >> 32) == gv.tag) break;
+        if (gran_spin_fail(spins, gv.err)) break;
+    }
+    // 2. this thread's granules, re-read until every tag of the wave matches
+    for (;;) {
+        bool ok = true;
+        xu64 x[NJ][8];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool in = (t + j * 256) * 8 < K;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[j][e] = in ? gran_ld(gv, (size_t)(j * 8 + e) * 256 + t) : ((xu64)gv.tag << 32);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ok = ok && ((unsigned)(x[j][e] >> 32) == gv.tag); v[j][e] = __uint_as_float((unsigned)x[j][e]); }
+        if (__all(ok)) return;
+        if (gran_spin_fail(spins, gv.err)) return;
+    }
+}
+
 // ---- activation slice handling ------------------------------------------------------
 template <int NJ>
 __device__ __forceinline__ void load_x(const float* __restrict__ x, int K, float (&xr)[NJ][8]) {
@@ -168,6 +236,44 @@ __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, c
     return ss;
 }
 
+// load_add_norm with the delta vector arriving as granules from a kernel that may still be running (the O projection under the
+// overlapped schedule): x_in / norm_w loads go out first, then the wave waits for its granules.  Same arithmetic as above.
+template <int NJ>
+__device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in, const VhGranVec& gd,
+                                                 const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
+                                                 float (&xr)[NJ][8]) {
+    f32x4 xa[NJ][2], na[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const int cc = (c * 8 < K) ? c : 0;
+        xa[j][0] = reinterpret_cast<const f32x4*>(x_in)[cc * 2];
+        xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
+        na[j][0] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2];
+        na[j][1] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + 1];
+    }
+    float dv[NJ][8];
+    gran_read_gemv<NJ>(gd, K, dv);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = threadIdx.x + j * 256;
+        const bool ok = c * 8 < K;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 v = xa[j][hh] + f32x4{dv[j][hh * 4], dv[j][hh * 4 + 1], dv[j][hh * 4 + 2], dv[j][hh * 4 + 3]};
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (x_out && blockIdx.x == 0 && ok) reinterpret_cast<f32x4*>(x_out)[c * 2 + hh] = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ss = fmaf(v[i], v[i], ss);
+                xr[j][hh * 4 + i] = v[i] * na[j][hh][i];
+            }
+        }
+    }
+    return ss;
+}
+
 // R rows of W (bf16) against the register-resident x, in two phases so the weight loads are in
 // flight BEFORE the (L2-resident) activation loads and prologue math.  rows[r] must be valid
 // pointers (callers clamp out-of-range rows and drop the result).
@@ -200,8 +306,11 @@ template <int NJ, int R, bool NORM>
 __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                   float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                   float eps, const uint16_t* __restrict__ W, int N, int K,
-                                                  float* __restrict__ out, const VhXchg xc) {
+                                                  float* __restrict__ out, const VhXchg xc, const VhGranVec gin,
+                                                  const VhGranVec gout) {
     // xc: NORM = true: consumer of a fused exchange (delta = xc.reduced); NORM = false: producer (outputs are pushed)
+    // gin / gout (overlapped schedule, world 1): NORM = true: delta arrives as GEMV-layout granules, outputs leave as LINEAR granules
+    // (fused QKV -> attention); NORM = false: x_in arrives and the outputs leave as GEMV-layout granules (attention -> O -> gate|up)
     __shared__ float red[4 * (R + 1)];
     if (NORM) xchg_reduce(xc);
     const int n0 = blockIdx.x * R;
@@ -215,9 +324,11 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
     float vals[R + 1];
     if (NORM) {
         xchg_wait(xc);
-        vals[R] = load_add_norm<NJ>(x_in, xc.world ? xc.reduced : delta, norm_w, x_out, K, xr, xc.world != 0);
+        if (gin.g) vals[R] = load_add_norm_g<NJ>(x_in, gin, norm_w, x_out, K, xr);
+        else vals[R] = load_add_norm<NJ>(x_in, xc.world ? xc.reduced : delta, norm_w, x_out, K, xr, xc.world != 0);
     } else {
-        load_x<NJ>(x_in, K, xr);
+        if (gin.g) gran_read_gemv<NJ>(gin, K, xr);
+        else load_x<NJ>(x_in, K, xr);
         vals[R] = 0.f;
     }
     float acc[R];
@@ -231,6 +342,7 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
 #pragma unroll
         for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = vals[r];
         if (!NORM && xc.world) xchg_put(xc, n0 + threadIdx.x, v * inv);
+        else if (gout.g) gran_put(gout, NORM ? (size_t)(n0 + threadIdx.x) : gran_pos_gemv(n0 + threadIdx.x), v * inv);
         else out[n0 + threadIdx.x] = v * inv;
     }
 }
@@ -256,7 +368,9 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
                                                const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                float* __restrict__ part_ml, int* __restrict__ cnt,
                                                float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
-                                               int max_splits, float scale) {
+                                               int max_splits, float scale, const VhGranVec gq, const VhGranVec gout) {
+    // gq.g: qkv arrives as LINEAR granules from a fused-QKV kernel that may still be running (this block's K / V tile loads are
+    // already in flight when it starts to wait); gout.g: the merged output leaves as GEMV-layout granules for the O projection
     __shared__ __attribute__((aligned(16))) float q_s[4][128];
     __shared__ __attribute__((aligned(16))) float kn_s[128];
     __shared__ __attribute__((aligned(16))) float vn_s[128];
@@ -289,17 +403,32 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     // 2. rotate-half RoPE (modeling_mixtral.py:203-241): out = x*cos + rotate_half(x)*sin
     const float c = rope_cos[(size_t)pos * 64 + lane], s = rope_sin[(size_t)pos * 64 + lane];
     if (wid < G) {
-        const float a = qkv[head * 128 + lane], b = qkv[head * 128 + 64 + lane];
+        float ab[2];
+        if (gq.g) {
+            const int idx[2] = {head * 128 + lane, head * 128 + 64 + lane};
+            gran_getn<2>(gq, idx, ab);
+        } else {
+            ab[0] = qkv[head * 128 + lane]; ab[1] = qkv[head * 128 + 64 + lane];
+        }
+        const float a = ab[0], b = ab[1];
         q_s[wid][lane] = a * c - b * s;
         q_s[wid][lane + 64] = b * c + a * s;
     }
     const bool has_new = (pos >= k0) && (pos < k1);
     if (has_new && wid == 3) {  // wave 3 is idle for G<4 and cheap otherwise
-        const float* kp = qkv + (size_t)nq * 128 + h * 128;
-        const float* vp = qkv + (size_t)(nq + nkv) * 128 + h * 128;
-        const float a = kp[lane], b = kp[lane + 64];
+        float kv4[4];
+        if (gq.g) {
+            const int kb0 = nq * 128 + h * 128, vb0 = (nq + nkv) * 128 + h * 128;
+            const int idx[4] = {kb0 + lane, kb0 + 64 + lane, vb0 + lane, vb0 + 64 + lane};
+            gran_getn<4>(gq, idx, kv4);
+        } else {
+            const float* kp = qkv + (size_t)nq * 128 + h * 128;
+            const float* vp = qkv + (size_t)(nq + nkv) * 128 + h * 128;
+            kv4[0] = kp[lane]; kv4[1] = kp[lane + 64]; kv4[2] = vp[lane]; kv4[3] = vp[lane + 64];
+        }
+        const float a = kv4[0], b = kv4[1];
         const float ka = a * c - b * s, kb = b * c + a * s;
-        const float va = vp[lane], vb = vp[lane + 64];
+        const float va = kv4[2], vb = kv4[3];
         kn_s[lane] = ka; kn_s[lane + 64] = kb;
         vn_s[lane] = va; vn_s[lane + 64] = vb;
         float* kc = kcache + ((size_t)h * max_ctx + p0 + (pos - k0)) * 128;   // has_new: pos lies in this tile
@@ -393,7 +522,12 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
             num.y = fmaf(wgt, ov.y, num.y);
         }
         const float inv = 1.0f / den;
-        reinterpret_cast<float2*>(attn_out + (size_t)head * 128)[lane] = make_float2(num.x * inv, num.y * inv);
+        if (gout.g) {
+            gran_put(gout, gran_pos_gemv(head * 128 + 2 * lane), num.x * inv);
+            gran_put(gout, gran_pos_gemv(head * 128 + 2 * lane + 1), num.y * inv);
+        } else {
+            reinterpret_cast<float2*>(attn_out + (size_t)head * 128)[lane] = make_float2(num.x * inv, num.y * inv);
+        }
     }
     return true;
 }
@@ -404,9 +538,9 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
-                                                  int max_splits, float scale) {
+                                                  int max_splits, float scale, const VhGranVec gq, const VhGranVec gout) {
     dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
-                   part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
+                   part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, gq, gout);
 }
 
 // ---- K_D: residual add + RMSNorm + router + gate|up GEMV + SiLU*up ------------------
@@ -422,7 +556,7 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
                                                     float eps, const uint16_t* __restrict__ Wg, int E,
                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
                                                     int I, int K, int* __restrict__ route_out,
-                                                    float* __restrict__ hbuf, const VhXchg cx) {
+                                                    float* __restrict__ hbuf, const VhXchg cx, const VhGranVec gd) {
     __shared__ float red[4 * 9];
     float xr[NJ][8];
     float inv;
@@ -436,7 +570,8 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
         gemv_issue<NJ, 8>(rrows, K, wr);
         float vals[9];
         xchg_wait(cx);
-        vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
+        if (gd.g) vals[8] = load_add_norm_g<NJ>(x_in, gd, norm_w, x_out, K, xr);     // overlapped schedule: the O projection may still be running
+        else vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
 #pragma unroll
@@ -655,6 +790,18 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ bl
     }
 }
 
+// ---- do two streams of this process really run at the same time?  Each side raises its own flag and waits (bounded, ~50 ms) for
+// the other's: both succeed only when the two kernels were resident together (the overlapped decode schedule relies on it)
+__global__ void k_dec_probe(int* mine, int* theirs, int* ok) {
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 0; spins < (1u << 17); ++spins) {
+        if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { *ok = 1; return; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    *ok = 0;
+}
+
 // ---- the global argmax alone (per-operator entry vh_lmhead_argmax): lowest index on ties, as torch.argmax ------------
 __global__ __launch_bounds__(256) void k_dec_pick(const float* __restrict__ blk_val, const int* __restrict__ blk_idx, int nblk,
                                                   int vocab, int* __restrict__ token_out, float* __restrict__ value_out) {
@@ -771,7 +918,7 @@ __global__ __launch_bounds__(256) void k_decb_attn(const VhDecBatchAttn bt, floa
     const int nsplit = (bt.pos[b] + 1 + DA_KT - 1) / DA_KT;
     if ((int)blockIdx.y >= nsplit) return;
     dec_attn_block(blockIdx.x, blockIdx.y, nsplit, bt.qkv[b], kcache, vcache, bt.pos[b], bt.table[b], rope_cos, rope_sin,
-                   bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale);
+                   bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
 }
 
 // final RMSNorm + LM head + per-block argmax for every sequence of the batch (the 424 MB table is read once)
@@ -860,13 +1007,24 @@ static inline VhXchg xchg_or_none(const VhXchg* x) {
     VhXchg z{};
     return x ? *x : z;            // world == 0: no exchange
 }
+static inline VhGranVec gran_or_none(const VhGranVec* g) {
+    VhGranVec z{};
+    return g ? *g : z;            // g == nullptr: plain buffers
+}
 
 template <int R, bool NORM>
 static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w,
-                           float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc) {
+                           float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc, const VhGranVec* gin,
+                           const VhGranVec* gout, hipEvent_t stop = nullptr) {
     return pick_nj(K, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
-                           delta, x_out, norm_w, eps, W, N, K, out, xchg_or_none(xc));
+        // stop: an event that completes WITH this kernel (its dispatch packet's own completion signal: no marker packet between
+        // this kernel and the next one of the stream, which hipEventRecord would add on the critical path)
+        if (stop)
+            hipExtLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, nullptr, stop, 0,
+                                  x_in, delta, x_out, norm_w, eps, W, N, K, out, xchg_or_none(xc), gran_or_none(gin), gran_or_none(gout));
+        else
+            hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
+                               delta, x_out, norm_w, eps, W, N, K, out, xchg_or_none(xc), gran_or_none(gin), gran_or_none(gout));
         return 0;
     });
 }
@@ -890,30 +1048,31 @@ int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
 }
 
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out, const VhXchg* cx) {
-    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx, const VhGranVec* gout, hipEvent_t stop) {
+    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, stop);
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table) {
+                 const int* table, const VhGranVec* gq, const VhGranVec* gout) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits || nsplit > 65535) return -1;
     hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
-                       rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
+                       rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, gran_or_none(gq), gran_or_none(gout));
     return 0;
 }
 
-int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px) {
-    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px,
+                  const VhGranVec* gin, const VhGranVec* gout) {
+    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px, gin, gout);
 }
 
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cxp) {
+                   float* hbuf, int grid, const VhXchg* cxp, const VhGranVec* gdelta) {
     if (E > 8 || E < 2 || I % 4 != 0) return -1;
     const int n_iter = 2 * (I / 4);
     const VhXchg cx = xchg_or_none(cxp);
@@ -922,20 +1081,24 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
         hipLaunchKernelGGL((k_dec_gateup<NJ, 4>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                           eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx);
+                           eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx, gran_or_none(gdelta));
         return 0;
     });
 }
 
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
-                 const VhXchg* pxp) {
+                 const VhXchg* pxp, hipEvent_t stop) {
     // one block per row pair (a persistent form that keeps both intermediate vectors in registers measured slower: 204.6-208.8
     // against 211.5 tok/s, r02, git history)
     constexpr int R = 2;
     const VhXchg px = xchg_or_none(pxp);
     return pick_nj(I, [&](auto nj) {
-        hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
-                           W2, N, I, out, px);
+        if (stop)
+            hipExtLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, nullptr, stop, 0, hbuf,
+                                  route, W2, N, I, out, px);
+        else
+            hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
+                               W2, N, I, out, px);
         return 0;
     });
 }
@@ -962,6 +1125,11 @@ int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val
 int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out) {
     if (nblk < 1) return -1;
     hipLaunchKernelGGL(k_dec_pick, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, vocab, token_out, value_out);
+    return 0;
+}
+
+int vhk_dec_probe(hipStream_t st, int* mine, int* theirs, int* ok) {
+    hipLaunchKernelGGL(k_dec_probe, dim3(1), dim3(64), 0, st, mine, theirs, ok);
     return 0;
 }
 

@@ -28,6 +28,10 @@ struct VhTuning {
     int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange,
                                // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Chosen at bring-up by
                                // vita_amd.parallel (timed on the ranks' own devices; "kernel" whenever ranks share a device)
+    int dec_overlap = 1;       // batch-1 decode on one rank: 1 / 2 = overlapped schedule (1: cross-stream events recorded by hipEventRecord, 2: as
+                               // completion events of the QKV / down kernels themselves, hipExtLaunchKernel) (attention and O projection on side streams, their inputs
+                               // and outputs as tagged granules: a kernel's launch, weight / K-V loads and prologue run under its
+                               // predecessor; needs streams that really run concurrently — probed once per engine), 0 = one stream
     int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
                                // fine-grained allocation fails (same-device tests); 0 = fail loudly instead
 };
@@ -55,19 +59,41 @@ struct VhXchg {
     int target, nred, count;
 };
 
+// ---- decode activation vectors handed between kernels that are RESIDENT AT THE SAME TIME (overlapped launches) ----
+// The batch-1 decode step runs its attention and O-projection kernels on side streams so that a kernel's launch, its weight /
+// K-V-tile loads and its prologue sit under its predecessor's execution instead of behind a kernel boundary.  The stream order no
+// longer carries the data dependency; the data does: every element of the vector travels as ONE naturally aligned 8-byte
+// {tag, fp32 bits} granule written and read with agent-scope atomics (guide G16 R2: the data is the flag — no fence, no flag word;
+// the same form VhXchg uses across devices).  tag = a per-engine counter that is different for every (step, layer, vector); 0 is
+// never used (the buffers start zeroed).  g == nullptr: the plain fp32 buffer of the serial schedule.
+//   layout 0 (VH_GRAN_LINEAR): element n in granule n (attention reads q / k / v of a head by lane)
+//   layout 1 (VH_GRAN_GEMV):   the consumer is a GEMV block whose thread t owns the 16-byte weight chunks t + 256 j, i.e. elements
+//                              [8 (t + 256 j), + 8): element n = 8 (t + 256 j) + e sits in granule (8 j + e) * 256 + t, so that the
+//                              64 lanes of a wave read 512 contiguous bytes per load instruction
+struct VhGranVec {
+    unsigned long long* g;
+    unsigned tag;
+    int* err;                       // device error word (engine counters[3]): set when a bounded wait gives up
+};
+#define VH_GRAN_SPIN_LIMIT (1u << 21)      // polls of ~0.2-0.4 us: a producer that never publishes ends in the error word after ~0.5 s
+__host__ __device__ inline size_t vh_gran_gemv_len(int K) { return (size_t)((K + 2047) / 2048) * 2048; }   // granules of a layout-1 vector
+
 struct vh_comm;
 int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, VhXchg* out, void* stream);   // vh_comm.hip
 
 // ---- decode (vh_decode.hip) ---------------------------------------------------------
 // cx (nullable): the delta is the result of a fused exchange (then `delta` is ignored); px (nullable): push the outputs
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr);
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr, const VhGranVec* gout = nullptr,   // gout: linear granules instead of `out`
+                hipEvent_t stop = nullptr);   // stop: event completing with the kernel (hipExtLaunchKernel), no marker packet
 int vhk_dec_consumer_blocks(int which, int N, int K, int I);   // grid of a consumer launch (0 qkv, 1 gate|up, 2 lm head): bounds nred
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table);   // table: nullable page table of a paged KV cache (64-token pages)
-int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr);
+                 const int* table,    // table: nullable page table of a paged KV cache (64-token pages)
+                 const VhGranVec* gq = nullptr, const VhGranVec* gout = nullptr);   // gq: qkv as linear granules; gout: attn_out as GEMV-layout granules
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr,
+                  const VhGranVec* gin = nullptr, const VhGranVec* gout = nullptr);   // both in the GEMV layout (of K resp. of the consumer's K = N)
 // ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
 #define VH_BMAX 4
 struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
@@ -88,15 +114,16 @@ int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w
                     const VhDecBatchHead& hd, int grid, int v0);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cx = nullptr);
+                   float* hbuf, int grid, const VhXchg* cx = nullptr, const VhGranVec* gdelta = nullptr);   // gdelta: `delta` as GEMV-layout granules
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
-                 const VhXchg* px = nullptr);
+                 const VhXchg* px = nullptr, hipEvent_t stop = nullptr);
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
                    const int* ngen_ptr, int hist_rows, int v0, int Vfull, const VhXchg* cx = nullptr);
 int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, float* cand, int rank, int world);
 int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx);
 int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out);
+int vhk_dec_probe(hipStream_t st, int* mine, int* theirs, int* ok);   // stream-concurrency probe: raises *mine, waits (bounded) for *theirs
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
                    int vocab, float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
 

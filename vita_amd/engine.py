@@ -184,6 +184,11 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_decode(self.h, int(n_steps), self._stream()), "vh_mixtral_decode")
         self.n_gen += int(n_steps)
 
+    def overlap_state(self):
+        """-1: no decode call yet, 0: the one-stream decode schedule is in use (streams of this process do not run concurrently,
+        tensor-parallel engine, or vh_tune("dec_overlap", 0)), 1: the overlapped schedule (attention / O projection on side streams)."""
+        return int(self.lib.vh_mixtral_decode_overlap_state(self.h))
+
     def reset(self):
         """forget the current request: position and generated-token counters to zero, every KV page back to the pool
         (vh_mixtral_reset); weights, workspace and collective stay."""
