@@ -159,6 +159,25 @@ int vh_cast_bf16_f32(const uint16_t* in, float* out, long n, void* stream);
  * at any size (no checkpoint exists offline: SURVEY 8(d)). */
 int vh_fill_hash_bf16(uint16_t* dst, long rows, long cols, long ld_dst, long ld_src, long idx0, uint64_t seed, void* stream);
 
+/* InternVisionEmbeddings + the first block's norm1 in ONE call (modeling_intern_vit.py:68-122, :243): patchify -> patch Linear
+ * (+ bias) -> [cls | patches] + position table -> LayerNorm (-> bf16 hi / lo planes for vh_encoder_layer's planes mode).  Five
+ * operator calls from Python left 177 us of host gaps in front of the first block of every tower pass (r04 trace); the pieces
+ * stay available one by one below.  pos: the table ALREADY at this tile grid (the bicubic interpolation of the checkpoint's
+ * table depends on the geometry only; the host does it once at load).  Scratch and outputs are caller-owned. */
+typedef struct {
+    const float* pix; int n, img, patch, kpad;            /* [n][3][img][img] fp32; kpad = padded 3 * patch^2 (multiple of 64) */
+    const uint16_t* patch_w; const float* patch_b;         /* bf16 [C][kpad], fp32 [C] */
+    const uint16_t* cls; const uint16_t* pos;              /* bf16 [C], bf16 [ntok][C] */
+    const float* ln_w; const float* ln_b; float eps;
+    int ntok, C;
+    float* patches; float* pe;                             /* scratch: [n (img/patch)^2][kpad], [n (img/patch)^2][C] */
+    float* x;                                              /* out: residual stream [n ntok][C] */
+    float* h;                                              /* out: LayerNorm(x) fp32 [n ntok][C] */
+    void* h_planes;                                        /* nullable out: the same rows as bf16 hi [n ntok][C] then lo [n ntok][C] */
+    float* ws; size_t ws_bytes;                            /* nullable split-K scratch of the patch Linear */
+} vh_vit_embed_args;
+int vh_vit_embed(const vh_vit_embed_args* args, void* stream);
+
 /* InternViT front/back (modeling_intern_vit.py:68-122; internvit_encoder.py:35-79). */
 int vh_vit_patchify(const float* pix, float* out, int n, int img, int patch, int kpad, void* stream);
 int vh_vit_assemble(const float* patches, const uint16_t* cls, const uint16_t* pos, float* x, int n, int ntok,
@@ -261,8 +280,8 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, fl
  * the one-stream schedule is used (same kernels, same results bit for bit).
  * Replaces the per-token forward of HF MixtralDecoderLayer x L as reached from vita/model/language_model/vita_mixtral.py:158-173. */
 int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
-/* -1: not probed yet (no decode call so far), 0: the overlapped schedule is unavailable here (streams do not run concurrently,
- * tensor parallel engine, or switched off), 1: in use. */
+/* schedule of the last decode call: -1 none yet, 0 one stream, five serial launches per layer (switched off, tensor-parallel engine,
+ * or the side streams do not run concurrently here), 1 overlapped on side streams, 3 overlapped on one stream (any-order launches). */
 int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m);
 /* Device pointers into the engine state (for the host loop and the tests). */
 const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */

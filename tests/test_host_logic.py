@@ -263,7 +263,8 @@ def test_ctypes_structs_match_the_header(tmp_path):
     the binding and the header are edited by hand in two places."""
     from vita_amd import _lib
     pairs = {"vh_gemm_args": _lib.GemmArgs, "vh_gemm_ps_args": _lib.GemmPsArgs, "vh_attn_args": _lib.AttnArgs,
-             "vh_encoder_layer_args": _lib.EncoderLayerArgs, "vh_mixtral_cfg": _lib.MixtralCfg, "vh_mixtral_layer": _lib.MixtralLayer}
+             "vh_encoder_layer_args": _lib.EncoderLayerArgs, "vh_mixtral_cfg": _lib.MixtralCfg, "vh_mixtral_layer": _lib.MixtralLayer,
+             "vh_vit_embed_args": _lib.VitEmbedArgs}
     lines = []
     for cname, cls in pairs.items():
         lines.append(f'printf("{cname} %zu", sizeof({cname}));')

@@ -418,6 +418,9 @@ def test_attention_flash_form(dev, nq, nkv, causal, Sq, pos0):
     vc = rng.standard_normal((nkv, max_ctx, d), dtype=np.float32)
     kc[:, Sk:] = np.nan
     vc[:, Sk:] = np.nan
+    if not causal:          # pad mask: rows in [klen, Sk) are caller memory too — masked keys must not be loaded from them
+        kc[:, klen:] = np.nan
+        vc[:, klen:] = np.nan
     out = torch.full((Sq, nq * d), float("nan"), dtype=torch.float32, device=dev)
     _lib.tune("attn_fa", 2)
     try:
@@ -427,7 +430,7 @@ def test_attention_flash_form(dev, nq, nkv, causal, Sq, pos0):
     finally:
         _lib.tune("attn_fa", 1)
     mask = (np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]) if causal else np.broadcast_to(np.arange(Sk)[None, :] < klen, (Sq, Sk))
-    ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), kc[:, :Sk], vc[:, :Sk], d ** -0.5, mask)
+    ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), np.nan_to_num(kc[:, :Sk]), np.nan_to_num(vc[:, :Sk]), d ** -0.5, mask)
     assert_close(f"flash form nq={nq} causal={causal} Sq={Sq} pos0={pos0}", to_np(out), ref, atol=ATTN_X3_ATOL)
 
 
@@ -477,7 +480,10 @@ def test_attention_relpos_masks(dev, klen, chunk, left):
     q, k, v, p = (rng.standard_normal((T, H * d), dtype=np.float32) for _ in range(4))
     bu, bv = rng.standard_normal((H, d), dtype=np.float32), rng.standard_normal((H, d), dtype=np.float32)
     out = torch.empty((T, H * d), dtype=torch.float32, device=dev)
-    ops.attention(_dev(q, dev), _dev(k, dev), _dev(v, dev), out, B=1, Hq=H, Hkv=H, Sq=T, Sk=T, d=d, ldq=H * d, hsq=d,
+    k_dev, v_dev = k.copy(), v.copy()
+    k_dev[klen:] = np.nan            # padded key rows are caller memory: masked keys must not be loaded from them
+    v_dev[klen:] = np.nan
+    ops.attention(_dev(q, dev), _dev(k_dev, dev), _dev(v_dev, dev), out, B=1, Hq=H, Hkv=H, Sq=T, Sk=T, d=d, ldq=H * d, hsq=d,
                   ldk=H * d, hsk=d, ldv=H * d, hsv=d, ldo=H * d, scale=d ** -0.5, klen=klen, chunk=chunk, left=left,
                   p=_dev(p, dev), ldp=H * d, hsp=d, bias_u=_dev(bu, dev), bias_v=_dev(bv, dev))
     mask = np.broadcast_to(np.arange(T)[None, :] < klen, (T, T)).copy()

@@ -160,16 +160,21 @@ def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        tw = [time.time()]
+        lap = lambda: (tw.append(time.time()), tw[-1] - tw[-2])[1]
         cfg = VitaConfig()
         cfg.text.num_hidden_layers = layers
         packed = synth_mixtral_device(cfg, dev, seed=SEED, rank=rank, world=world)
+        t_w = lap()
         # the replicated encoder weights: the parent's state dict, memory-mapped (generating 0.7 B values takes ~45 s per process)
         sd_enc = {k: v.numpy() for k, v in torch.load(enc_path, mmap=True, weights_only=True).items()}
         model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=TP8_NEW + 8, max_prefill=640,
                                        rank=rank, world=world, keep_scores=True)
         eng = model.engine
         assert (eng.c.n_q_heads, eng.c.n_kv_heads, eng.c.inter, eng.c.vocab_n) == (4, 1, 1792, 6470)
+        t_m = lap()
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
+        t_tp = lap()
         model.get_vision_tower().load_model()
         req = make_request(cfg)
         pix = torch.from_numpy(req["pixel_values"]).to(dev)
@@ -177,9 +182,17 @@ def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
         ids = torch.tensor([req["input_ids"]], dtype=torch.long, device=dev)
         audios = {"audios": feats[None], "lengths": torch.tensor([feats.shape[0]], device=dev)}
         _, _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix, audios)
+        torch.cuda.synchronize()
+        t_enc = lap()
         eng.prefill(emb[0])
+        torch.cuda.synchronize()
+        t_pf = lap()
         eng.decode(TP8_NEW - 1)
         torch.cuda.synchronize()
+        t_dec = lap()
+        if rank == 0:
+            print(f"[realgeom] TP = 8 rank 0: weights {t_w:.1f}s, model {t_m:.1f}s, collective bring-up {t_tp:.1f}s, encoders + splice "
+                  f"{t_enc:.1f}s, prefill {t_pf:.1f}s, {TP8_NEW - 1} decode steps {t_dec:.1f}s", flush=True)
         lg = eng.logits_all[:TP8_NEW].cpu()
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
         c = getattr(eng, "_comm", None)

@@ -72,6 +72,19 @@ class EncoderLayerArgs(C.Structure):
     ]
 
 
+class VitEmbedArgs(C.Structure):
+    _fields_ = [
+        ("pix", c_void_p), ("n", c_int), ("img", c_int), ("patch", c_int), ("kpad", c_int),
+        ("patch_w", c_void_p), ("patch_b", c_void_p),
+        ("cls", c_void_p), ("pos", c_void_p),
+        ("ln_w", c_void_p), ("ln_b", c_void_p), ("eps", c_float),
+        ("ntok", c_int), ("C", c_int),
+        ("patches", c_void_p), ("pe", c_void_p),
+        ("x", c_void_p), ("h", c_void_p), ("h_planes", c_void_p),
+        ("ws", c_void_p), ("ws_bytes", c_size_t),
+    ]
+
+
 class MixtralCfg(C.Structure):
     _fields_ = [
         ("hidden", c_int), ("n_layers", c_int), ("n_q_heads", c_int), ("n_kv_heads", c_int),
@@ -108,6 +121,7 @@ SIGNATURES = {
     "vh_add": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "vh_cast_bf16_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "vh_fill_hash_bf16": (c_int, [c_void_p, c_long, c_long, c_long, c_long, c_long, C.c_uint64, c_void_p]),
+    "vh_vit_embed": (c_int, [c_void_p, c_void_p]),
     "vh_vit_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vh_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vh_vit_pixel_shuffle": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

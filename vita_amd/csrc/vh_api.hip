@@ -140,6 +140,31 @@ int vh_fill_hash_bf16(uint16_t* dst, long rows, long cols, long ld_dst, long ld_
     if (!dst) return fail(VH_E_ARG, "vh_fill_hash_bf16: null pointer");
     return check_launch("vh_fill_hash_bf16", vhk_fill_hash_bf16(S(stream), dst, rows, cols, ld_dst, ld_src, idx0, seed));
 }
+int vh_vit_embed(const vh_vit_embed_args* a, void* stream) {
+    if (!a || !a->pix || !a->patch_w || !a->cls || !a->pos || !a->ln_w || !a->patches || !a->pe || !a->x || !a->h)
+        return fail(VH_E_ARG, "vh_vit_embed: null pointer");
+    if (a->n < 1 || a->patch < 1 || a->img % a->patch != 0 || a->kpad % 64 != 0 || a->kpad < 3 * a->patch * a->patch || a->C % 8 != 0)
+        return fail(VH_E_SHAPE, "vh_vit_embed: n %d img %d patch %d kpad %d C %d", a->n, a->img, a->patch, a->kpad, a->C);
+    const int g = a->img / a->patch, rows = a->n * g * g, M = a->n * a->ntok;
+    if (a->ntok != g * g + 1) return fail(VH_E_SHAPE, "vh_vit_embed: ntok %d is not grid^2 + 1 (%d)", a->ntok, g * g + 1);
+    hipStream_t st = S(stream);
+    int rc = check_launch("vh_vit_embed (patchify)", vhk_vit_patchify(st, a->pix, a->patches, a->n, a->img, a->patch, a->kpad));
+    if (rc != VH_OK) return rc;
+    VhGemmArgs gm{};
+    gm.A = a->patches; gm.lda = a->kpad; gm.a_rows = rows; gm.nseg = 1; gm.seglen = a->kpad;
+    gm.W = a->patch_w; gm.ldw = a->kpad; gm.C = a->pe; gm.ldc = a->C; gm.M = rows; gm.N = a->C; gm.K = a->kpad;
+    gm.bias = a->patch_b; gm.ws = a->ws; gm.ws_bytes = a->ws_bytes; gm.ksplit = a->ws ? 0 : 1;
+    if ((rc = check_launch("vh_vit_embed (patch Linear)", vhk_gemm(st, gm))) != VH_OK) return rc;
+    if ((rc = check_launch("vh_vit_embed (assemble)", vhk_vit_assemble(st, a->pe, a->cls, a->pos, a->x, a->n, a->ntok, a->C))) != VH_OK) return rc;
+    if ((rc = check_launch("vh_vit_embed (norm1)", vhk_layernorm(st, a->x, a->C, a->h, a->C, a->ln_w, a->ln_b, M, a->C, a->eps, VH_ACT_NONE, 1.0f))) != VH_OK)
+        return rc;
+    if (a->h_planes) {
+        uint16_t* hi = reinterpret_cast<uint16_t*>(a->h_planes);
+        rc = check_launch("vh_vit_embed (planes)", vhk_split_planes(st, a->h, a->C, hi, hi + (size_t)M * a->C, a->C, M, a->C));
+    }
+    return rc;
+}
+
 int vh_vit_patchify(const float* pix, float* out, int n, int img, int patch, int kpad, void* stream) {
     return check_launch("vh_vit_patchify", vhk_vit_patchify(S(stream), pix, out, n, img, patch, kpad));
 }
@@ -390,6 +415,7 @@ struct vh_mixtral {
         g_qkv = cv.take<unsigned long long>(nqkv);
         g_attn = cv.take<unsigned long long>(vh_gran_gemv_len(nq * hd));
         g_dattn = cv.take<unsigned long long>(vh_gran_gemv_len(H));
+        xc = cv.take<float>(H);
         probe = cv.take<int>(4);
         // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
@@ -438,9 +464,11 @@ struct vh_mixtral {
     std::vector<hipEvent_t> ev_pre, ev_q, ev_o;      // per layer: before / after the fused QKV (caller's stream), after the O projection (sC)
     hipEvent_t ev_fork = nullptr, ev_joinA = nullptr, ev_joinC = nullptr;
     unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr;   // granule vectors (VhGranVec)
+    float* xc = nullptr;                             // third residual-stream buffer of the any-order schedule (see decode_one_step)
     int* probe = nullptr;                            // 4 words of the stream-concurrency probe
     unsigned gran_epoch = 0;                         // last granule tag handed out (0 = never written)
-    int overlap_state = -1;                          // -1 not probed yet, 0 the streams do not run concurrently here, 1 verified
+    int streams_state = -1;                          // side streams: -1 not probed yet, 0 they do not run concurrently here, 1 verified
+    int overlap_state = -1;                          // schedule of the last decode call: -1 none yet, 0 serial, 1 side streams, 3 any-order launches
     unsigned next_tag() { if (++gran_epoch == 0) ++gran_epoch; return gran_epoch; }
     int ensure_overlap_streams(hipStream_t st);
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
@@ -1037,8 +1065,8 @@ static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, con
 // wait was enqueued before its consumer; every wait is bounded (error word, counters[3]) in case the streams do not overlap after
 // all.  One rank only: under tensor parallelism the exchange kernels / VhXchg own these edges.
 int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
-    if (overlap_state >= 0) return overlap_state;
-    overlap_state = 0;
+    if (streams_state >= 0) return streams_state;
+    streams_state = 0;
     if (hipStreamCreateWithFlags(&sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sC, hipStreamNonBlocking) != hipSuccess)
         return 0;
     auto mk = [](hipEvent_t* e) { return hipEventCreate(e) == hipSuccess; };   // (kernel completion events of mode 2 "track the stop time")
@@ -1059,19 +1087,23 @@ int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
             hipMemcpy(h, probe, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
         if (h[2] != 1 || h[3] != 1) return 0;
     }
-    overlap_state = 1;
-    return overlap_state;
+    streams_state = 1;
+    return streams_state;
 }
 static bool overlap_wanted(const vh_mixtral* m) {
-    return vh_tuning()->dec_overlap != 0 && m->c.tp_world <= 1 && !vh_tuning()->force_allreduce && m->nq * m->hd <= 14336;
+    return vh_tuning()->dec_overlap != 0 && m->c.tp_world <= 1 && !vh_tuning()->force_allreduce && m->nq * m->hd <= 4096 && m->H <= 4096;
 }
 // the side streams start behind everything already queued on st (prefill: KV cache, residual stream) ...
-static bool overlap_begin(vh_mixtral* m, hipStream_t st) {
-    if (!overlap_wanted(m) || m->ensure_overlap_streams(st) != 1) return false;
+// returns the schedule: 0 = one stream, serial; 1 = side streams; 3 = one stream, any-order launches (nothing to fork or join)
+static int overlap_begin(vh_mixtral* m, hipStream_t st) {
+    m->overlap_state = 0;
+    if (!overlap_wanted(m)) return 0;
+    if (vh_tuning()->dec_overlap == 3) return m->overlap_state = 3;
+    if (m->ensure_overlap_streams(st) != 1) return 0;
     hipEventRecord(m->ev_fork, st);
     hipStreamWaitEvent(m->sA, m->ev_fork, 0);
     hipStreamWaitEvent(m->sC, m->ev_fork, 0);
-    return true;
+    return m->overlap_state = 1;
 }
 // ... and st ends behind them: a caller that synchronises st has the whole step
 static void overlap_end(vh_mixtral* m, hipStream_t st) {
@@ -1085,7 +1117,7 @@ int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m) { return m ? m->overl
 // One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
 // mirror of the position (host_pos) is advanced by the CALLER only after the step was enqueued without error.
 // ov: the overlapped schedule (the caller ran overlap_begin and runs overlap_end after its last step).
-static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
+static int decode_one_step(vh_mixtral* m, hipStream_t st, int ov) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
@@ -1098,12 +1130,38 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
     bool have_xm = false;
-    const bool ext = ov && vh_tuning()->dec_overlap == 2;
+    const bool ext = ov == 1 && vh_tuning()->dec_overlap == 2;
+    float* cur = m->xa;                          // (any-order schedule) the buffer that holds the residual stream in front of this layer
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
         const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+        if (ov == 3) {
+            // ONE stream: QKV and the down projection are ordinary launches (barrier bit: they start when everything in front of them
+            // has completed); attention, the O projection and gate|up carry no barrier bit, so each is dispatched as soon as the
+            // kernel in front of it has been LAUNCHED and waits for its input granules inside.  Producers are always dispatched
+            // before their consumers (one queue, in-order packet processing): no wait can starve its producer.
+            // gate|up cannot take the QKV kernel's x_out through plain memory (no completed-kernel boundary between them): it
+            // repeats the add from the QKV kernel's own inputs, cur + delta_moe, which were final before that kernel started, and
+            // writes the new residual stream to the buffer nobody reads in this layer (cur alternates between xa and xc).
+            int* err = m->counters + 3;
+            const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
+            float* nxt = cur == m->xa ? m->xc : m->xa;
+            const float* dprev = l == 0 ? nullptr : m->delta_moe;
+            VH_TRY(vhk_dec_qkv(st, cur, dprev, nullptr, w.attn_norm, eps, w.wqkv, m->nqkv, H, nullptr, nullptr, &gq), "dec qkv");
+            VH_TRY(vhk_dec_attn(st, nullptr, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                                m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
+                                &gq, &ga, hipExtAnyOrderLaunch), "dec attn");
+            VH_TRY(vhk_dec_oproj(st, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, &gd, hipExtAnyOrderLaunch), "dec oproj");
+            if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);      // a sampled layer times gate|up alone: ordinary launch
+            VH_TRY(vhk_dec_gateup(st, cur, dprev, nxt, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
+                                  nullptr, &gd, prof ? 0u : (unsigned)hipExtAnyOrderLaunch), "dec gateup");
+            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr), "dec down");
+            cur = nxt;
+            continue;
+        }
         if (ov) {
             int* err = m->counters + 3;
             const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
@@ -1126,7 +1184,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
                 hipEventRecord(m->prof_ev[m->prof_used], st);
             }
             VH_TRY(vhk_dec_gateup(st, m->xb, nullptr, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
-                                  nullptr, &gd), "dec gateup");
+                                  nullptr, &gd, 0u), "dec gateup");
             if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr,
                                 ext && l + 1 < m->c.n_layers ? m->ev_pre[l + 1] : nullptr), "dec down");
@@ -1156,7 +1214,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
         if (!fuse && m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
     }
     {
-        const int rc = head_and_select(m, st, m->xa, m->delta_moe, /*mode=*/1, /*set_pos=*/0, have_xm ? &xm : nullptr);
+        const int rc = head_and_select(m, st, cur, m->delta_moe, /*mode=*/1, /*set_pos=*/0, have_xm ? &xm : nullptr);
         if (rc != VH_OK) return rc;
     }
     const hipError_t e = hipGetLastError();   // checked per step: the mirrors below must not run ahead of a failed launch
@@ -1170,7 +1228,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     if (m->poisoned) return fail(VH_E_ARG, "decode: a previous step failed; prefill or reset first");
     if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_decode: sequences own pages of the KV pool (use vh_mixtral_seq_decode)");
     if (n_steps <= 0) return VH_OK;
-    const bool ov = overlap_begin(m, st);
+    const int ov = overlap_begin(m, st);
     int rc = VH_OK;
     for (int step = 0; step < n_steps; ++step) {
         if (m->host_pos + 1 >= m->c.max_ctx) { rc = fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx); break; }
@@ -1183,7 +1241,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
         }
         m->host_pos += 1;
     }
-    if (ov) overlap_end(m, st);
+    if (ov == 1) overlap_end(m, st);
     return rc;
 }
 
@@ -1409,7 +1467,7 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         }
     }
     if (n <= 0) return VH_OK;
-    const bool ov = overlap_begin(m, st);
+    const int ov = overlap_begin(m, st);
     int rc = VH_OK;
     for (int i = 0; i < n; ++i) {
         const int s = ids[i];
@@ -1423,7 +1481,7 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         m->unbind();
         if (rc != VH_OK) break;
     }
-    if (ov) overlap_end(m, st);
+    if (ov == 1) overlap_end(m, st);
     return rc;
 }
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 
     f32x4 kf[2][NC], pf[REL ? 2 : 1][REL ? NC : 1], vf[AT_KT / 4][VQ];
     auto phys = [&](int key) __attribute__((always_inline)) {
-        key = min(key, p.Sk - 1);
+        key = min(key, max(kend, 1) - 1);        // masked keys re-read the last VISIBLE row (rows in [klen, Sk) may hold anything)
         return p.ktable ? p.ktable[key >> 6] * 64 + (key & 63) : key;
     };
     auto load_k = [&](int kt0) __attribute__((always_inline)) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     // fits): the first version spent 63 quarter-rate 32/64-bit multiplies and ~100 more VALU per tile on 64-bit row pointers,
     // a third of the loop's issue cycles in a kernel that is VALU-bound.
     const unsigned ldk = (unsigned)p.ldk, ldv = (unsigned)p.ldv;
-    const int klast = p.Sk - 1;
+    const int klast = max(kend, 1) - 1;   // masked keys re-read the last VISIBLE row: rows in [klen, Sk) are caller memory (NaN bits there would turn p = 0 into NaN in the PV products)
     auto row_bytes = [&](int key, unsigned ld, unsigned col) __attribute__((always_inline)) {
         key = min(key, klast);
         if (PAGED) key = p.ktable[key >> 6] * 64 + (key & 63);
@@ -589,7 +589,7 @@ void k_attn_fa(const VhAttnArgs p) {
     // ---- staging by role (wave-uniform): group 1 = K, 8 x 16-byte pieces per thread: piece i = row 8 i + ftid / 32, floats
     // 4 (ftid % 32) ..+4 (a wave instruction = two whole rows); group 0 = V, two 4-key x 4-column blocks per thread ----------------
     const unsigned ldk = (unsigned)p.ldk, ldv = (unsigned)p.ldv;
-    const int klast = p.Sk - 1;
+    const int klast = max(kend, 1) - 1;   // masked keys re-read the last VISIBLE row: rows in [klen, Sk) are caller memory (NaN bits there would turn p = 0 into NaN in the PV products)
     const int fk_key = ftid >> 5, fk_c = ftid & 31, fv_kg = ftid >> 4, fv_cg = ftid & 15;
     f32x4 st[8];
     auto row_of = [&](int key) __attribute__((always_inline)) {

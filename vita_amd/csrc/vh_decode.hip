@@ -140,31 +140,53 @@ __device__ __forceinline__ void gran_getn(const VhGranVec& gv, const int (&idx)[
         if (gran_spin_fail(spins, gv.err)) return;
     }
 }
-// a GEMV block's slice of a layout-1 vector: thread t gets elements [8 (t + 256 j), + 8), j < NJ (zeros past K)
+// a GEMV block's slice of a layout-1 vector: thread t gets elements [8 (t + 256 j), + 8), j < NJ (zeros past K).  Called by ALL
+// 256 threads of the block (block barrier inside).
+// Polling discipline (r05, first form measured 174 against 209 tok/s): a consumer kernel is resident for microseconds before its
+// producer publishes, and 2048 + 1536 waves re-reading ONE granule every 0.3 us queue up behind each other on that line's L2
+// channel — in front of the producer's own store to it.  So: (1) ONE wave per block polls, the other three wait at the barrier;
+// (2) it polls ONE granule per look (lane-uniform address: a single 8-byte request), a DIFFERENT element for every block
+// (spread over the channels), about every microsecond; (3) only then does every wave sweep its own granules.
 template <int NJ>
 __device__ __forceinline__ void gran_read_gemv(const VhGranVec& gv, int K, float (&v)[NJ][8]) {
     const int t = threadIdx.x;
     unsigned spins = 0;
-    // 1. ONE granule (element 0: a single 8-byte request per wave) until the producer kernel has begun to publish: the sweep
-    //    below moves NJ * 4 KB per wave and must not be repeated for the microseconds a consumer is resident early
-    for (;;) {
-        if ((unsigned)(gran_ld(gv, 0) >> 32) == gv.tag) break;
-        if (gran_spin_fail(spins, gv.err)) break;
+    if (t < 64) {
+        const size_t sent = gran_pos_gemv((int)((blockIdx.x * 1031u + 17u) % (unsigned)K));
+        for (;;) {
+            if ((unsigned)(gran_ld(gv, sent) >> 32) == gv.tag) break;
+            if (gran_spin_fail(spins, gv.err)) break;
+            __builtin_amdgcn_s_sleep(24);             // + the 8 of gran_spin_fail: ~1 us between looks
+        }
     }
-    // 2. this thread's granules, re-read until every tag of the wave matches
+    __syncthreads();
+    spins = 0;
+    // this thread's granules, re-read until every tag of the wave matches (the producers publish within ~1 us of each other).
+    // Addresses are a block-uniform base (scalar registers) + one per-lane offset: with per-lane 64-bit pointers the sixteen
+    // addresses alone took 32 vector registers and the capped instantiations spilled.
+    const int nj_in = (K + 2047) >> 11;                   // chunk slots j that hold data for at least one thread
+    const int tt = ((t + (nj_in - 1) * 256) * 8 < K) ? t : 0;   // threads past K in the LAST slot re-read lane 0's granule (discarded)
     for (;;) {
         bool ok = true;
-        xu64 x[NJ][8];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const bool in = (t + j * 256) * 8 < K;
+            if (j < nj_in) {                                  // block-uniform
+                const xu64* base = reinterpret_cast<const xu64*>(gv.g) + (size_t)(j * 8) * 256;
+                const int tj = (j == nj_in - 1) ? tt : t;
+                xu64 x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[j][e] = in ? gran_ld(gv, (size_t)(j * 8 + e) * 256 + t) : ((xu64)gv.tag << 32);
+                for (int e = 0; e < 8; ++e) x[e] = __hip_atomic_load(base + e * 256 + tj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool in = (t + j * 256) * 8 < K;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ok = ok && ((unsigned)(x[e] >> 32) == gv.tag);
+                    v[j][e] = in ? __uint_as_float((unsigned)x[e]) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+            }
         }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ok = ok && ((unsigned)(x[j][e] >> 32) == gv.tag); v[j][e] = __uint_as_float((unsigned)x[j][e]); }
         if (__all(ok)) return;
         if (gran_spin_fail(spins, gv.err)) return;
     }
@@ -237,37 +259,47 @@ __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, c
 }
 
 // load_add_norm with the delta vector arriving as granules from a kernel that may still be running (the O projection under the
-// overlapped schedule): x_in / norm_w loads go out first, then the wave waits for its granules.  Same arithmetic as above.
+// overlapped schedules): x_in / norm_w loads go out first, then the wave waits for its granules.  Same arithmetic as above.
+// dprev (any-order schedule only, nullable): x_in is the residual stream BEFORE the layer's fused-QKV kernel added its delta —
+// this kernel repeats that add (x = (x_in + dprev) + delta, the same two fp32 adds the serial schedule performs in two kernels)
+// because the QKV kernel, launched in front of this one without a completed-kernel boundary in between, cannot hand it its x_out
+// through plain memory.  x_in and dprev were final before the QKV kernel started.
 template <int NJ>
-__device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in, const VhGranVec& gd,
+__device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in, const float* __restrict__ dprev, const VhGranVec& gd,
                                                  const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
                                                  float (&xr)[NJ][8]) {
-    f32x4 xa[NJ][2], na[NJ][2];
+    // (x_in / dprev are read AFTER the wait: 16 KB that every block reads, L2-resident — holding them in registers across the wait,
+    // next to the router weights a gate|up block already holds, pushed the 128-register instantiation into scratch)
+    float dv[NJ][8];
+    gran_read_gemv<NJ>(gd, K, dv);
+    f32x4 xa[NJ][2];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = threadIdx.x + j * 256;
         const int cc = (c * 8 < K) ? c : 0;
         xa[j][0] = reinterpret_cast<const f32x4*>(x_in)[cc * 2];
         xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
-        na[j][0] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2];
-        na[j][1] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + 1];
+        if (dprev) {
+            xa[j][0] += reinterpret_cast<const f32x4*>(dprev)[cc * 2];
+            xa[j][1] += reinterpret_cast<const f32x4*>(dprev)[cc * 2 + 1];
+        }
     }
-    float dv[NJ][8];
-    gran_read_gemv<NJ>(gd, K, dv);
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = threadIdx.x + j * 256;
         const bool ok = c * 8 < K;
+        const int cc = ok ? c : 0;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 nw = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + hh];       // (L2-resident: loaded where it is used)
             f32x4 v = xa[j][hh] + f32x4{dv[j][hh * 4], dv[j][hh * 4 + 1], dv[j][hh * 4 + 2], dv[j][hh * 4 + 3]};
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (x_out && blockIdx.x == 0 && ok) reinterpret_cast<f32x4*>(x_out)[c * 2 + hh] = v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ss = fmaf(v[i], v[i], ss);
-                xr[j][hh * 4 + i] = v[i] * na[j][hh][i];
+                xr[j][hh * 4 + i] = v[i] * nw[i];
             }
         }
     }
@@ -302,17 +334,19 @@ __device__ __forceinline__ void gemv_fma(const uint4 (&w)[R][NJ], const float (&
 // ---- K_A / K_C: (residual add + RMSNorm +) row-parallel GEMV -------------------------------
 // NORM=true : out = rsqrt(mean(x^2)+eps) * W (x*w_norm), x = x_in + delta      (fused QKV)
 // NORM=false: out = W x_in                                                    (O projection)
-template <int NJ, int R, bool NORM>
-__global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
+// GR (overlapped schedules, one rank): granule I/O compiled in — NORM = true (fused QKV): outputs leave as LINEAR granules for the
+// attention kernel; NORM = false (O projection): x_in arrives and the outputs leave as GEMV-layout granules (attention -> O ->
+// gate|up).  A separate instantiation, so the serial schedule's kernels keep their r04 register counts (a run-time switch made the
+// O projection 252 VGPRs: one block per CU); capped at 128 registers so that its blocks sit beside the waiting gate|up blocks.
+template <int NJ, int R, bool NORM, bool GR>
+__global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                   float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                   float eps, const uint16_t* __restrict__ W, int N, int K,
                                                   float* __restrict__ out, const VhXchg xc, const VhGranVec gin,
                                                   const VhGranVec gout) {
     // xc: NORM = true: consumer of a fused exchange (delta = xc.reduced); NORM = false: producer (outputs are pushed)
-    // gin / gout (overlapped schedule, world 1): NORM = true: delta arrives as GEMV-layout granules, outputs leave as LINEAR granules
-    // (fused QKV -> attention); NORM = false: x_in arrives and the outputs leave as GEMV-layout granules (attention -> O -> gate|up)
     __shared__ float red[4 * (R + 1)];
-    if (NORM) xchg_reduce(xc);
+    if (NORM && !GR) xchg_reduce(xc);
     const int n0 = blockIdx.x * R;
     const uint16_t* rows[R];
 #pragma unroll
@@ -323,11 +357,10 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
     float xr[NJ][8];
     float vals[R + 1];
     if (NORM) {
-        xchg_wait(xc);
-        if (gin.g) vals[R] = load_add_norm_g<NJ>(x_in, gin, norm_w, x_out, K, xr);
-        else vals[R] = load_add_norm<NJ>(x_in, xc.world ? xc.reduced : delta, norm_w, x_out, K, xr, xc.world != 0);
+        if (!GR) xchg_wait(xc);
+        vals[R] = load_add_norm<NJ>(x_in, (!GR && xc.world) ? xc.reduced : delta, norm_w, x_out, K, xr, !GR && xc.world != 0);
     } else {
-        if (gin.g) gran_read_gemv<NJ>(gin, K, xr);
+        if (GR) gran_read_gemv<NJ>(gin, K, xr);
         else load_x<NJ>(x_in, K, xr);
         vals[R] = 0.f;
     }
@@ -341,8 +374,8 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = vals[r];
-        if (!NORM && xc.world) xchg_put(xc, n0 + threadIdx.x, v * inv);
-        else if (gout.g) gran_put(gout, NORM ? (size_t)(n0 + threadIdx.x) : gran_pos_gemv(n0 + threadIdx.x), v * inv);
+        if (GR) gran_put(gout, NORM ? (size_t)(n0 + threadIdx.x) : gran_pos_gemv(n0 + threadIdx.x), v * inv);
+        else if (!NORM && xc.world) xchg_put(xc, n0 + threadIdx.x, v * inv);
         else out[n0 + threadIdx.x] = v * inv;
     }
 }
@@ -361,6 +394,7 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
 // of its KV head and wrote attn_out rows [h*G*128, (h+1)*G*128) (block-uniform).
 // `table` (nullable): paged KV cache — logical 64-key block sp of this sequence lives in physical page table[sp] of the
 // pool (one page = one tile of this kernel); null = the contiguous single-sequence layout (page sp).
+template <bool GR>
 __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const int nsplit,
                                                const float* __restrict__ qkv, float* __restrict__ kcache,
                                                float* __restrict__ vcache, const int pos, const int* __restrict__ table,
@@ -404,7 +438,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     const float c = rope_cos[(size_t)pos * 64 + lane], s = rope_sin[(size_t)pos * 64 + lane];
     if (wid < G) {
         float ab[2];
-        if (gq.g) {
+        if (GR) {
             const int idx[2] = {head * 128 + lane, head * 128 + 64 + lane};
             gran_getn<2>(gq, idx, ab);
         } else {
@@ -417,7 +451,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     const bool has_new = (pos >= k0) && (pos < k1);
     if (has_new && wid == 3) {  // wave 3 is idle for G<4 and cheap otherwise
         float kv4[4];
-        if (gq.g) {
+        if (GR) {
             const int kb0 = nq * 128 + h * 128, vb0 = (nq + nkv) * 128 + h * 128;
             const int idx[4] = {kb0 + lane, kb0 + 64 + lane, vb0 + lane, vb0 + 64 + lane};
             gran_getn<4>(gq, idx, kv4);
@@ -522,7 +556,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
             num.y = fmaf(wgt, ov.y, num.y);
         }
         const float inv = 1.0f / den;
-        if (gout.g) {
+        if (GR) {
             gran_put(gout, gran_pos_gemv(head * 128 + 2 * lane), num.x * inv);
             gran_put(gout, gran_pos_gemv(head * 128 + 2 * lane + 1), num.y * inv);
         } else {
@@ -532,6 +566,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     return true;
 }
 
+template <bool GR>
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
                                                   float* __restrict__ vcache, const int pos, const int* __restrict__ table,
                                                   const float* __restrict__ rope_cos,
@@ -539,8 +574,8 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
                                                   int max_splits, float scale, const VhGranVec gq, const VhGranVec gout) {
-    dec_attn_block(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
-                   part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, gq, gout);
+    dec_attn_block<GR>(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
+                       part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, gq, gout);
 }
 
 // ---- K_D: residual add + RMSNorm + router + gate|up GEMV + SiLU*up ------------------
@@ -550,18 +585,20 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
 // loops over 2*RP-row groups (RP gate + RP up rows of one expert) and relies on the co-resident
 // blocks of its CU for the overlap of one block's reduction with another's loads (a second register
 // buffer per block measured slower, 91 vs 84 us: it costs two waves per SIMD of occupancy; r01, git history).
-template <int NJ, int RP>
-__global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_in, const float* __restrict__ delta,
+template <int NJ, int RP, bool GR>
+__global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gateup(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                     float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                     float eps, const uint16_t* __restrict__ Wg, int E,
                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
                                                     int I, int K, int* __restrict__ route_out,
                                                     float* __restrict__ hbuf, const VhXchg cx, const VhGranVec gd) {
+    // GR (overlapped schedules): the attention delta arrives as granules (gd) from an O projection that may still be running; `delta`
+    // is then the PREVIOUS sub-block's delta to be added to x_in first (any-order schedule, nullable: see load_add_norm_g)
     __shared__ float red[4 * 9];
     float xr[NJ][8];
     float inv;
     int e0 = 0, e1 = 0;
-    xchg_reduce(cx);
+    if (!GR) xchg_reduce(cx);
     {
         const uint16_t* rrows[8];
 #pragma unroll
@@ -569,8 +606,8 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
         uint4 wr[8][NJ];
         gemv_issue<NJ, 8>(rrows, K, wr);
         float vals[9];
-        xchg_wait(cx);
-        if (gd.g) vals[8] = load_add_norm_g<NJ>(x_in, gd, norm_w, x_out, K, xr);     // overlapped schedule: the O projection may still be running
+        if (!GR) xchg_wait(cx);
+        if (GR) vals[8] = load_add_norm_g<NJ>(x_in, delta, gd, norm_w, x_out, K, xr);
         else vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
@@ -917,8 +954,8 @@ __global__ __launch_bounds__(256) void k_decb_attn(const VhDecBatchAttn bt, floa
     const int b = blockIdx.z;
     const int nsplit = (bt.pos[b] + 1 + DA_KT - 1) / DA_KT;
     if ((int)blockIdx.y >= nsplit) return;
-    dec_attn_block(blockIdx.x, blockIdx.y, nsplit, bt.qkv[b], kcache, vcache, bt.pos[b], bt.table[b], rope_cos, rope_sin,
-                   bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
+    dec_attn_block<false>(blockIdx.x, blockIdx.y, nsplit, bt.qkv[b], kcache, vcache, bt.pos[b], bt.table[b], rope_cos, rope_sin,
+                          bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
 }
 
 // final RMSNorm + LM head + per-block argmax for every sequence of the batch (the 424 MB table is read once)
@@ -1012,19 +1049,35 @@ static inline VhGranVec gran_or_none(const VhGranVec* g) {
     return g ? *g : z;            // g == nullptr: plain buffers
 }
 
+// One launch helper for the decode kernels: `stop` = an event that completes WITH this kernel (its dispatch packet's own completion
+// signal — no marker packet between this kernel and the next one of the stream, which hipEventRecord would add on the critical
+// path); flags = hipExtAnyOrderLaunch: the packet carries no barrier bit — the kernel may start while the kernels in front of it in
+// the stream still run (its inputs arrive as granules).  Neither: the ordinary launch.
+template <typename Kern, typename... Args>
+static inline void dec_launch(Kern kern, dim3 grid, hipStream_t st, hipEvent_t stop, unsigned flags, Args... args) {
+    if (stop || flags) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, nullptr, stop, flags, args...);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, args...);
+}
+
 template <int R, bool NORM>
 static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w,
                            float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc, const VhGranVec* gin,
-                           const VhGranVec* gout, hipEvent_t stop = nullptr) {
+                           const VhGranVec* gout, hipEvent_t stop = nullptr, unsigned flags = 0) {
+    const bool gr = NORM ? (gout != nullptr) : (gin != nullptr && gout != nullptr);
+    if ((gin || gout) && !gr) return -1;                 // the O projection takes granules on both sides or on neither
     return pick_nj(K, [&](auto nj) {
-        // stop: an event that completes WITH this kernel (its dispatch packet's own completion signal: no marker packet between
-        // this kernel and the next one of the stream, which hipEventRecord would add on the critical path)
-        if (stop)
-            hipExtLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, nullptr, stop, 0,
-                                  x_in, delta, x_out, norm_w, eps, W, N, K, out, xchg_or_none(xc), gran_or_none(gin), gran_or_none(gout));
-        else
-            hipLaunchKernelGGL((k_dec_gemv<decltype(nj)::value, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in,
-                               delta, x_out, norm_w, eps, W, N, K, out, xchg_or_none(xc), gran_or_none(gin), gran_or_none(gout));
+        constexpr int NJ = decltype(nj)::value;
+        const dim3 grid((N + R - 1) / R);
+        if (gr) {
+            // the granule instantiations exist for K <= 4096 (two chunk slots per thread): beyond that the 128-register cap spills
+            if constexpr (NJ <= 2)
+                dec_launch(k_dec_gemv<NJ, R, NORM, true>, grid, st, stop, flags, x_in, delta, x_out, norm_w, eps, W, N, K, out, VhXchg{},
+                           gran_or_none(gin), gran_or_none(gout));
+            else return -1;
+        } else {
+            dec_launch(k_dec_gemv<NJ, R, NORM, false>, grid, st, stop, flags, x_in, delta, x_out, norm_w, eps, W, N, K, out,
+                       xchg_or_none(xc), VhGranVec{}, VhGranVec{});
+        }
         return 0;
     });
 }
@@ -1055,24 +1108,27 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table, const VhGranVec* gq, const VhGranVec* gout) {
+                 const int* table, const VhGranVec* gq, const VhGranVec* gout, unsigned flags) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits || nsplit > 65535) return -1;
-    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
-                       rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, gran_or_none(gq), gran_or_none(gout));
+    if ((gq != nullptr) != (gout != nullptr)) return -1;
+    if (gq) dec_launch(k_dec_attn<true>, dim3(nkv, nsplit), st, nullptr, flags, qkv, kcache, vcache, ctx_host - 1, table, rope_cos, rope_sin,
+                       part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, *gq, *gout);
+    else dec_launch(k_dec_attn<false>, dim3(nkv, nsplit), st, nullptr, flags, qkv, kcache, vcache, ctx_host - 1, table, rope_cos, rope_sin,
+                    part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
     return 0;
 }
 
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px,
-                  const VhGranVec* gin, const VhGranVec* gout) {
-    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px, gin, gout);
+                  const VhGranVec* gin, const VhGranVec* gout, unsigned flags) {
+    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px, gin, gout, nullptr, flags);
 }
 
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cxp, const VhGranVec* gdelta) {
+                   float* hbuf, int grid, const VhXchg* cxp, const VhGranVec* gdelta, unsigned flags) {
     if (E > 8 || E < 2 || I % 4 != 0) return -1;
     const int n_iter = 2 * (I / 4);
     const VhXchg cx = xchg_or_none(cxp);
@@ -1080,8 +1136,16 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
     if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        hipLaunchKernelGGL((k_dec_gateup<NJ, 4>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w,
-                           eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx, gran_or_none(gdelta));
+        // gdelta: the attention delta as granules; `delta` is then the previous sub-block's plain delta to add to x_in first (nullable)
+        if (gdelta) {
+            if constexpr (NJ <= 2)
+                dec_launch(k_dec_gateup<NJ, 4, true>, dim3(grid), st, nullptr, flags, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
+                           route_out, hbuf, VhXchg{}, *gdelta);
+            else return -1;
+        } else {
+            dec_launch(k_dec_gateup<NJ, 4, false>, dim3(grid), st, nullptr, flags, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
+                       route_out, hbuf, cx, VhGranVec{});
+        }
         return 0;
     });
 }

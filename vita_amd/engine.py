@@ -185,8 +185,9 @@ class MixtralEngine:
         self.n_gen += int(n_steps)
 
     def overlap_state(self):
-        """-1: no decode call yet, 0: the one-stream decode schedule is in use (streams of this process do not run concurrently,
-        tensor-parallel engine, or vh_tune("dec_overlap", 0)), 1: the overlapped schedule (attention / O projection on side streams)."""
+        """schedule of the last decode call: -1 none yet, 0 one stream with five serial launches per layer (vh_tune("dec_overlap", 0),
+        tensor-parallel engine, or side streams that do not run concurrently), 1 overlapped on side streams, 3 overlapped on one stream
+        (any-order launches)."""
         return int(self.lib.vh_mixtral_decode_overlap_state(self.h))
 
     def reset(self):

@@ -136,21 +136,20 @@ class InternViTVisionTower(_HipModule):
         N = v.num_tokens
         g = v.grid
         assert g * g == N - 1  # internvit_encoder.py:72
-        patches = ops.vit_patchify(pix, v.patch_size, w["kpad"])
-        pe = ops.gemm(patches, w["patch_w"], bias=w["patch_b"])
-        x = ops.vit_assemble(pe, w["cls"], w["pos"], n, N, C)                    # [n*N, C]
         layers = []
-        # every LayerNorm after the first rides on the Linear that produces its input (ops.gemm(ln=...): the split-K reducer
-        # holds whole rows, so the norm costs no launch of its own at one tile)
-        h = ops.layernorm(x, w["layers"][0]["n1w"], w["layers"][0]["n1b"], v.layer_norm_eps) if w["layers"] else None
         if not self.per_operator and w["layers"]:
-            # one library call per block (vh_encoder_layer): 24 host calls per pass instead of ~170
+            # one library call per block (vh_encoder_layer): 24 host calls per pass instead of ~170 — and (r05) ONE call for the
+            # embeddings + the first norm1 (vh_vit_embed; the five operator calls left 177 us of host gaps in front of block 0,
+            # profiles/r04_encoder_pass_trace.txt); the scratch is looked up BEFORE the first kernel is enqueued
             sc = ops.encoder_scratch(n * N, C, w["layers"][0]["fc1_w"].shape[0], self._device)
             # planes mode (r04): LayerNorm / attention / GELU outputs travel as the bf16 hi/lo planes the weight-streaming GEMM consumes
             # (one-round tilings: qkv / fc1 25 % faster at one tile, 30-36 % on 8-image batches; profiles/r04_enc_sp_sweep.jsonl)
             planes = _VIT_PLANES and C % 64 == 0 and sc.ws.numel() * sc.ws.element_size() >= 4 * n * N * C
-            if planes:
-                h = ops.split_planes_into(h, sc.h[1])
+            x = torch.empty((n * N, C), dtype=torch.float32, device=self._device)
+            L0 = w["layers"][0]
+            ops.vit_embed(pix, v.patch_size, w["kpad"], w["patch_w"], w["patch_b"], w["cls"], w["pos"], L0["n1w"], L0["n1b"],
+                          v.layer_norm_eps, N, x, sc.h[0] if planes else sc.h[1], sc.h[1] if planes else None)
+            h = sc.h[1]
             for li, L in enumerate(w["layers"]):
                 nxt = w["layers"][li + 1] if li + 1 < len(w["layers"]) else None
                 ops.encoder_layer(x, h, sc.h[li & 1], L, sc, heads=nh, B=n, act="gelu", eps=v.layer_norm_eps,
@@ -160,6 +159,12 @@ class InternViTVisionTower(_HipModule):
                     layers.append(x.clone().view(n, N, C))
             out = ops.vit_pixel_shuffle(x, n, g, C, self.scale_pix_shuffle)
             return (out, layers) if want_layers else out
+        patches = ops.vit_patchify(pix, v.patch_size, w["kpad"])
+        pe = ops.gemm(patches, w["patch_w"], bias=w["patch_b"])
+        x = ops.vit_assemble(pe, w["cls"], w["pos"], n, N, C)                    # [n*N, C]
+        # every LayerNorm after the first rides on the Linear that produces its input (ops.gemm(ln=...): the split-K reducer
+        # holds whole rows, so the norm costs no launch of its own at one tile)
+        h = ops.layernorm(x, w["layers"][0]["n1w"], w["layers"][0]["n1b"], v.layer_norm_eps) if w["layers"] else None
         attn = torch.empty((n * N, C), dtype=torch.float32, device=self._device)
         for li, L in enumerate(w["layers"]):
             qkv = ops.gemm(h, L["qkv_w"], bias=L["qkv_b"])                        # [n*N, 3C] = (three, head, d)

@@ -149,19 +149,28 @@ class EncoderScratch:
 
 
 _ENC_SCRATCH = {}
+ENC_SCRATCH_CAP_BYTES = 768 << 20      # all cached sets together (an 8-tile ViT batch is ~370 MB, 13 tiles ~600 MB)
+
+
+def _enc_scratch_bytes(sc):
+    return 4 * sc.M * (3 * sc.C + 2 * sc.C + sc.F + 2 * sc.C)
 
 
 def encoder_scratch(M, Cw, F, device):
     """EncoderScratch for (M, C, F), kept per (device, current stream) across passes: building it costs six allocations (~0.1 ms of host
-    time in front of a tower pass, r04 trace); reuse is stream-ordered like _scratch.  The last four shapes are kept."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, int(M), int(Cw), int(F))
+    time in front of a tower pass, r04 trace); reuse is stream-ordered like _scratch.  At most four shapes and at most
+    ENC_SCRATCH_CAP_BYTES in all are kept (dynamic tiling makes M vary per request, and four 13-tile sets would pin ~2 GB
+    behind a KV pool that was sized from free memory); the key holds the torch Stream OBJECT, so its handle cannot be handed to
+    another stream while an entry is alive."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.type, device.index, stream, int(M), int(Cw), int(F))
     sc = _ENC_SCRATCH.pop(key, None)
     if sc is None:
         sc = EncoderScratch(M, Cw, F, device)
-        while len(_ENC_SCRATCH) >= 4:
-            _ENC_SCRATCH.pop(next(iter(_ENC_SCRATCH)))
+    _ENC_SCRATCH[key] = sc                                                  # most recently used last
+    while len(_ENC_SCRATCH) > 1 and (len(_ENC_SCRATCH) > 4 or sum(_enc_scratch_bytes(v) for v in _ENC_SCRATCH.values()) > ENC_SCRATCH_CAP_BYTES):
+        _ENC_SCRATCH.pop(next(iter(_ENC_SCRATCH)))                          # evict the least recently used; the current one stays
     sc.ws = _scratch(device, min(8 * 4 * M * max(3 * Cw, F), 96 << 20))     # (the shared split-K scratch may have been regrown)
-    _ENC_SCRATCH[key] = sc
     return sc
 
 
@@ -222,6 +231,30 @@ def vit_patchify(pix, patch, kpad):
     out = torch.empty((n * g * g, kpad), dtype=torch.float32, device=pix.device)
     check(_lib.load().vh_vit_patchify(_p(pix), _p(out), n, img, patch, kpad, _stream()), "vh_vit_patchify")
     return out
+
+
+def vit_embed(pix, patch, kpad, patch_w, patch_b, cls, pos, ln_w, ln_b, eps, ntok, x, h, h_planes=None):
+    """InternVisionEmbeddings + the first block's norm1 in one library call (vh_vit_embed): pix [n,3,S,S] -> x [n*ntok, C] (residual
+    stream), h = LayerNorm(x) fp32 and, when h_planes (any dense buffer of n*ntok*C*4 bytes) is given, its bf16 hi/lo planes."""
+    _dev(pix, x, h)
+    pix = _dense(pix)
+    n, _, img, _ = pix.shape
+    g = img // patch
+    Cw = int(patch_w.shape[0])
+    patches = torch.empty((n * g * g, kpad), dtype=torch.float32, device=pix.device)
+    pe = torch.empty((n * g * g, Cw), dtype=torch.float32, device=pix.device)
+    M = n * g * g
+    ws = _scratch(pix.device, min(8 * 4 * M * Cw, 96 << 20))
+    a = _lib.VitEmbedArgs()
+    a.pix, a.n, a.img, a.patch, a.kpad = pix.data_ptr(), n, img, int(patch), int(kpad)
+    a.patch_w, a.patch_b, a.cls, a.pos = patch_w.data_ptr(), patch_b.data_ptr(), cls.data_ptr(), pos.data_ptr()
+    a.ln_w, a.ln_b, a.eps = ln_w.data_ptr(), _p(ln_b), float(eps)
+    a.ntok, a.C = int(ntok), Cw
+    a.patches, a.pe, a.x, a.h = patches.data_ptr(), pe.data_ptr(), x.data_ptr(), h.data_ptr()
+    a.h_planes = h_planes.data_ptr() if h_planes is not None else None
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    check(_lib.load().vh_vit_embed(C.byref(a), _stream()), "vh_vit_embed")
+    return x, h
 
 
 def vit_assemble(patches, cls, pos, n, ntok, hid):
