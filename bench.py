@@ -590,9 +590,9 @@ def main():
                                    "greedy decode, batch 1; VITA-Mixtral-8x7B geometry (32 layers, 8 experts top-2)",
                        "parallelism": f"tp{world}", "collective": collective, "prompt_tokens": int(S),
                        "layers": t.num_hidden_layers,
-                       # which decode schedule the timed steps ran: "overlapped" = attention / O projection on side streams with
+                       # which decode schedule the timed steps ran: "overlapped" = attention / O projection on gated side streams with
                        # tagged-granule hand-offs, "one-stream" = five serial launches per layer
-                       "decode_schedule": {1: "overlapped (side streams)", 3: "overlapped (any-order launches)", 0: "one-stream"}.get(eng.overlap_state(), "unknown")},
+                       "decode_schedule": {1: "overlapped", 0: "one-stream"}.get(eng.overlap_state(), "unknown")},
             "prefill_ms": round(phase["prefill_ms"], 3), "vit_projector_ms": round(phase["vit_proj_ms"], 3),
             "audio_encoder_ms": round(phase["audio_ms"], 3),
             "ttft_ms": round(phase["prefill_ms"] + phase["vit_proj_ms"] + phase["audio_ms"], 3),

@@ -274,14 +274,15 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, fl
                        void* stream);
 /* Run n_steps greedy decode steps back to back with no host interaction.  On one rank the step runs the OVERLAPPED schedule
  * (vh_tune("dec_overlap", 1), the default): the attention and O-projection kernels of a layer are enqueued on two side streams
- * of the engine so that their launch, K / V-tile and weight loads and prologue run under the kernel before them; their inputs
- * and outputs travel as tagged granules.  `stream` still brackets the call: the side streams start behind everything queued on
- * it and it ends behind them.  The first call probes once whether streams of this process really run concurrently; if not,
- * the one-stream schedule is used (same kernels, same results bit for bit).
+ * of the engine, each behind a one-wave gate kernel that ends when the layer's fused-QKV kernel has started, so that their
+ * launch, K / V-tile and weight loads and prologue run under the QKV kernel; their inputs and outputs travel as tagged granules.
+ * `stream` still brackets the call: the side streams start behind everything queued on it and it ends behind them.  The first
+ * call probes once whether streams of this process really run concurrently; if not, the one-stream schedule is used (same
+ * arithmetic, same results bit for bit).
  * Replaces the per-token forward of HF MixtralDecoderLayer x L as reached from vita/model/language_model/vita_mixtral.py:158-173. */
 int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
 /* schedule of the last decode call: -1 none yet, 0 one stream, five serial launches per layer (switched off, tensor-parallel engine,
- * or the side streams do not run concurrently here), 1 overlapped on side streams, 3 overlapped on one stream (any-order launches). */
+ * or the side streams do not run concurrently here), 1 overlapped. */
 int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m);
 /* Device pointers into the engine state (for the host loop and the tests). */
 const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */

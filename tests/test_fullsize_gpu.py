@@ -131,7 +131,7 @@ def test_overlapped_decode_schedule_equals_one_stream(full, dev):
     emb = _emb(packed, rng.integers(3, cfg.text.vocab_size, size=150).tolist(), dev)
     runs = []
     try:
-        for ov in (1, 0, 3, 2, 3):
+        for ov in (1, 0, 1, 1):
             _lib.tune("dec_overlap", ov)
             eng.prefill(emb)
             eng.decode(3)
@@ -141,7 +141,7 @@ def test_overlapped_decode_schedule_equals_one_stream(full, dev):
             runs.append((eng.generated(), eng.logits_all[:25].clone(), eng.overlap_state()))
     finally:
         _lib.tune("dec_overlap", 1)
-    assert [r[2] for r in runs] == [1, 0, 3, 1, 3], f"schedules that ran: {[r[2] for r in runs]} (1 missing: the side streams are not concurrent on this box?)"
+    assert [r[2] for r in runs] == [1, 0, 1, 1], f"schedules that ran: {[r[2] for r in runs]} (1 missing: the side streams are not concurrent on this box?)"
     assert len(runs[0][0]) == 25
     for toks, lg, _ in runs[1:]:
         assert toks == runs[0][0]

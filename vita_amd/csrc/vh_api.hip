@@ -415,7 +415,7 @@ struct vh_mixtral {
         g_qkv = cv.take<unsigned long long>(nqkv);
         g_attn = cv.take<unsigned long long>(vh_gran_gemv_len(nq * hd));
         g_dattn = cv.take<unsigned long long>(vh_gran_gemv_len(H));
-        xc = cv.take<float>(H);
+        g_gate = cv.take<unsigned long long>(2);
         probe = cv.take<int>(4);
         // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
@@ -461,14 +461,14 @@ struct vh_mixtral {
     }
     // ---- overlapped decode schedule: attention on sA, O projection on sC, the rest on the caller's stream ----
     hipStream_t sA = nullptr, sC = nullptr;
-    std::vector<hipEvent_t> ev_pre, ev_q, ev_o;      // per layer: before / after the fused QKV (caller's stream), after the O projection (sC)
+    std::vector<hipEvent_t> ev_o;                    // per layer: after the O projection (sC); only the profiled layers use it
     hipEvent_t ev_fork = nullptr, ev_joinA = nullptr, ev_joinC = nullptr;
     unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr;   // granule vectors (VhGranVec)
-    float* xc = nullptr;                             // third residual-stream buffer of the any-order schedule (see decode_one_step)
+    unsigned long long* g_gate = nullptr;            // "this layer's fused-QKV kernel has started" (opens the side streams' gate kernels)
     int* probe = nullptr;                            // 4 words of the stream-concurrency probe
     unsigned gran_epoch = 0;                         // last granule tag handed out (0 = never written)
     int streams_state = -1;                          // side streams: -1 not probed yet, 0 they do not run concurrently here, 1 verified
-    int overlap_state = -1;                          // schedule of the last decode call: -1 none yet, 0 serial, 1 side streams, 3 any-order launches
+    int overlap_state = -1;                          // schedule of the last decode call: -1 none yet, 0 one stream, 1 overlapped
     unsigned next_tag() { if (++gran_epoch == 0) ++gran_epoch; return gran_epoch; }
     int ensure_overlap_streams(hipStream_t st);
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
@@ -559,8 +559,6 @@ void vh_mixtral_destroy(vh_mixtral_t* m) {
     for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) hipEventDestroy(m->ev_r[i]); }
     if (m->cs) hipStreamDestroy(m->cs);
-    for (hipEvent_t e : m->ev_pre) hipEventDestroy(e);
-    for (hipEvent_t e : m->ev_q) hipEventDestroy(e);
     for (hipEvent_t e : m->ev_o) hipEventDestroy(e);
     for (hipEvent_t e : {m->ev_fork, m->ev_joinA, m->ev_joinC}) if (e) hipEventDestroy(e);
     if (m->sA) hipStreamDestroy(m->sA);
@@ -1055,24 +1053,28 @@ static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, con
 // A batch-1 decode layer is five dependent launches; QKV (50 MB), attention and the O projection (34 MB) are short enough that the
 // head and tail of each launch — dispatch, first-byte latency of the weight / K-V loads, prologue, drain, the boundary — cost as
 // much as their bytes (r04: 28.5 us per layer for 84 MB that the stream moves in 14).  The schedule below keeps the five kernels
-// and takes the attention and the O projection OFF the stream order: attention(l) is enqueued on sA behind "everything before
-// QKV(l)", the O projection on sC behind QKV(l), so both are resident — K / V tiles and O weights in flight or landed, prologues
-// done — while their predecessor still runs; gate|up (caller's stream, behind QKV) likewise has its router weights in registers
-// when the O projection finishes.  The data dependency travels with the data: qkv, attn_out and delta_attn are tagged granules
-// (VhGranVec) that the consumer waves poll.  Everything else (xb, route, hbuf, delta_moe, xa, the KV cache) stays plain memory
-// ordered by a stream.  Deadlock freedom: a waiting kernel never holds what its producer needs — attention is <= nkv * splits blocks,
-// the O projection 2 and gate|up 1.5 resident blocks per CU of 88 / 120 registers against 512 per SIMD, and the producer of every
-// wait was enqueued before its consumer; every wait is bounded (error word, counters[3]) in case the streams do not overlap after
-// all.  One rank only: under tensor parallelism the exchange kernels / VhXchg own these edges.
+// and takes the attention and the O projection OFF the stream order: they run on two side streams, each behind a one-wave GATE
+// kernel that ends when this layer's fused-QKV kernel has started, so both are resident — K / V tiles and O weights in flight or
+// landed, prologues done — while QKV still streams; gate|up (caller's stream, right behind QKV) likewise has its router weights in
+// registers when the O projection finishes.  The data dependency travels with the data: qkv, attn_out and delta_attn are tagged
+// granules (VhGranVec) that the consumer waves poll.  Everything else (xb, route, hbuf, delta_moe, xa, the KV cache) stays plain
+// memory ordered by a stream.  What was measured on the way (profiles/EXPERIMENTS.md r05): cross-stream EVENTS release their
+// waiter 7-12 us late and cost 4-5 us per marker / completion event on the main stream (199 against 210 tok/s); launches
+// without the barrier bit (hipExtAnyOrderLaunch) are not honoured on gfx950 (they serialise); a run-time granule switch inside
+// the serial kernels doubled their registers (174 tok/s).
+// Deadlock freedom: a waiting kernel never holds what its producer needs — every producer is enqueued before its consumers and is
+// resident when they start (the gates open after QKV's blocks were dispatched); attention is <= nkv * splits blocks, the O
+// projection 2 and gate|up 1.5 blocks per CU of 120 / 128 registers against 512 per SIMD; every wait is bounded (error word,
+// counters[3]).  One rank only: under tensor parallelism the exchange kernels / VhXchg own these edges.
 int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
     if (streams_state >= 0) return streams_state;
     streams_state = 0;
     if (hipStreamCreateWithFlags(&sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sC, hipStreamNonBlocking) != hipSuccess)
         return 0;
-    auto mk = [](hipEvent_t* e) { return hipEventCreate(e) == hipSuccess; };   // (kernel completion events of mode 2 "track the stop time")
-    ev_pre.assign(c.n_layers, nullptr); ev_q.assign(c.n_layers, nullptr); ev_o.assign(c.n_layers, nullptr);
+    auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    ev_o.assign(c.n_layers, nullptr);
     for (int l = 0; l < c.n_layers; ++l)
-        if (!mk(&ev_pre[l]) || !mk(&ev_q[l]) || !mk(&ev_o[l])) return 0;
+        if (!mk(&ev_o[l])) return 0;
     if (!mk(&ev_fork) || !mk(&ev_joinA) || !mk(&ev_joinC)) return 0;
     // probe every PAIR of the three streams (HIP may multiplex streams onto fewer hardware queues: two streams of one queue run
     // in enqueue order, and a consumer enqueued first would wait for a producer queued behind it): two kernels, one per stream,
@@ -1094,16 +1096,14 @@ static bool overlap_wanted(const vh_mixtral* m) {
     return vh_tuning()->dec_overlap != 0 && m->c.tp_world <= 1 && !vh_tuning()->force_allreduce && m->nq * m->hd <= 4096 && m->H <= 4096;
 }
 // the side streams start behind everything already queued on st (prefill: KV cache, residual stream) ...
-// returns the schedule: 0 = one stream, serial; 1 = side streams; 3 = one stream, any-order launches (nothing to fork or join)
-static int overlap_begin(vh_mixtral* m, hipStream_t st) {
+static bool overlap_begin(vh_mixtral* m, hipStream_t st) {
     m->overlap_state = 0;
-    if (!overlap_wanted(m)) return 0;
-    if (vh_tuning()->dec_overlap == 3) return m->overlap_state = 3;
-    if (m->ensure_overlap_streams(st) != 1) return 0;
+    if (!overlap_wanted(m) || m->ensure_overlap_streams(st) != 1) return false;
     hipEventRecord(m->ev_fork, st);
     hipStreamWaitEvent(m->sA, m->ev_fork, 0);
     hipStreamWaitEvent(m->sC, m->ev_fork, 0);
-    return m->overlap_state = 1;
+    m->overlap_state = 1;
+    return true;
 }
 // ... and st ends behind them: a caller that synchronises st has the whole step
 static void overlap_end(vh_mixtral* m, hipStream_t st) {
@@ -1117,7 +1117,7 @@ int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m) { return m ? m->overl
 // One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
 // mirror of the position (host_pos) is advanced by the CALLER only after the step was enqueued without error.
 // ov: the overlapped schedule (the caller ran overlap_begin and runs overlap_end after its last step).
-static int decode_one_step(vh_mixtral* m, hipStream_t st, int ov) {
+static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
@@ -1130,53 +1130,25 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int ov) {
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
     bool have_xm = false;
-    const bool ext = ov == 1 && vh_tuning()->dec_overlap == 2;
-    float* cur = m->xa;                          // (any-order schedule) the buffer that holds the residual stream in front of this layer
     for (int l = 0; l < m->c.n_layers; ++l) {
         const vh_mixtral_layer& w = m->L[l];
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
         const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
-        if (ov == 3) {
-            // ONE stream: QKV and the down projection are ordinary launches (barrier bit: they start when everything in front of them
-            // has completed); attention, the O projection and gate|up carry no barrier bit, so each is dispatched as soon as the
-            // kernel in front of it has been LAUNCHED and waits for its input granules inside.  Producers are always dispatched
-            // before their consumers (one queue, in-order packet processing): no wait can starve its producer.
-            // gate|up cannot take the QKV kernel's x_out through plain memory (no completed-kernel boundary between them): it
-            // repeats the add from the QKV kernel's own inputs, cur + delta_moe, which were final before that kernel started, and
-            // writes the new residual stream to the buffer nobody reads in this layer (cur alternates between xa and xc).
-            int* err = m->counters + 3;
-            const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
-            float* nxt = cur == m->xa ? m->xc : m->xa;
-            const float* dprev = l == 0 ? nullptr : m->delta_moe;
-            VH_TRY(vhk_dec_qkv(st, cur, dprev, nullptr, w.attn_norm, eps, w.wqkv, m->nqkv, H, nullptr, nullptr, &gq), "dec qkv");
-            VH_TRY(vhk_dec_attn(st, nullptr, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
-                                m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
-                                &gq, &ga, hipExtAnyOrderLaunch), "dec attn");
-            VH_TRY(vhk_dec_oproj(st, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, &gd, hipExtAnyOrderLaunch), "dec oproj");
-            if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);      // a sampled layer times gate|up alone: ordinary launch
-            VH_TRY(vhk_dec_gateup(st, cur, dprev, nxt, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
-                                  nullptr, &gd, prof ? 0u : (unsigned)hipExtAnyOrderLaunch), "dec gateup");
-            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr), "dec down");
-            cur = nxt;
-            continue;
-        }
         if (ov) {
             int* err = m->counters + 3;
             const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
-            // attention(l) becomes eligible when everything before QKV(l) has completed: the previous layer's down projection carries
-            // ev_pre[l] as its own completion event (mode 2), else (first layer of a step, mode 1) a marker is recorded here
-            if (!(ext && l > 0)) hipEventRecord(m->ev_pre[l], st);
-            hipStreamWaitEvent(m->sA, m->ev_pre[l], 0);
+            // side streams first (host order is irrelevant to the device).  Attention's gate opens when QKV(l) STARTS (its K / V tiles
+            // are 5 MB: they load under the QKV stream); the O projection's gate opens when QKV block 0 has PUBLISHED (its 34 MB
+            // of weights would compete with the QKV stream; they load under the attention instead)
+            VH_TRY(vhk_dec_gate(m->sA, m->g_gate, gq.tag, err), "dec gate");
             VH_TRY(vhk_dec_attn(m->sA, nullptr, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
                                 m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
                                 &gq, &ga), "dec attn");
-            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
-                               nullptr, nullptr, &gq, ext ? m->ev_q[l] : nullptr), "dec qkv");
-            if (!ext) hipEventRecord(m->ev_q[l], st);
-            hipStreamWaitEvent(m->sC, m->ev_q[l], 0);
+            VH_TRY(vhk_dec_gate(m->sC, vh_tuning()->dec_overlap == 2 ? m->g_gate : m->g_qkv, gq.tag, err), "dec gate");   // (2: experiment, both gates on QKV start)
             VH_TRY(vhk_dec_oproj(m->sC, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, &gd), "dec oproj");
+            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
+                               nullptr, nullptr, &gq, m->g_gate), "dec qkv");
             if (prof) {
                 // a sampled layer times gate|up ALONE: it starts behind the finished O projection instead of waiting inside the launch
                 hipEventRecord(m->ev_o[l], m->sC);
@@ -1184,10 +1156,9 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int ov) {
                 hipEventRecord(m->prof_ev[m->prof_used], st);
             }
             VH_TRY(vhk_dec_gateup(st, m->xb, nullptr, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
-                                  nullptr, &gd, 0u), "dec gateup");
+                                  nullptr, &gd), "dec gateup");
             if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr,
-                                ext && l + 1 < m->c.n_layers ? m->ev_pre[l + 1] : nullptr), "dec down");
+            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr), "dec down");
             continue;
         }
         VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
@@ -1214,7 +1185,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, int ov) {
         if (!fuse && m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
     }
     {
-        const int rc = head_and_select(m, st, cur, m->delta_moe, /*mode=*/1, /*set_pos=*/0, have_xm ? &xm : nullptr);
+        const int rc = head_and_select(m, st, m->xa, m->delta_moe, /*mode=*/1, /*set_pos=*/0, have_xm ? &xm : nullptr);
         if (rc != VH_OK) return rc;
     }
     const hipError_t e = hipGetLastError();   // checked per step: the mirrors below must not run ahead of a failed launch
@@ -1228,7 +1199,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     if (m->poisoned) return fail(VH_E_ARG, "decode: a previous step failed; prefill or reset first");
     if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_decode: sequences own pages of the KV pool (use vh_mixtral_seq_decode)");
     if (n_steps <= 0) return VH_OK;
-    const int ov = overlap_begin(m, st);
+    const bool ov = overlap_begin(m, st);
     int rc = VH_OK;
     for (int step = 0; step < n_steps; ++step) {
         if (m->host_pos + 1 >= m->c.max_ctx) { rc = fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx); break; }
@@ -1241,7 +1212,7 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
         }
         m->host_pos += 1;
     }
-    if (ov == 1) overlap_end(m, st);
+    if (ov) overlap_end(m, st);
     return rc;
 }
 
@@ -1467,7 +1438,7 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         }
     }
     if (n <= 0) return VH_OK;
-    const int ov = overlap_begin(m, st);
+    const bool ov = overlap_begin(m, st);
     int rc = VH_OK;
     for (int i = 0; i < n; ++i) {
         const int s = ids[i];
@@ -1481,7 +1452,7 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         m->unbind();
         if (rc != VH_OK) break;
     }
-    if (ov == 1) overlap_end(m, st);
+    if (ov) overlap_end(m, st);
     return rc;
 }
 

@@ -28,8 +28,6 @@
 // Reference semantics restated: transformers/models/mixtral/modeling_mixtral.py
 // (MixtralRMSNorm, MixtralAttention + apply_rotary_pos_emb, MixtralTopKRouter,
 // MixtralExperts) as called from vita/model/language_model/vita_mixtral.py:158-173.
-#include <hip/hip_ext.h>
-
 #include "vh_common.h"
 #include "vh_kernels.h"
 
@@ -259,17 +257,13 @@ __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, c
 }
 
 // load_add_norm with the delta vector arriving as granules from a kernel that may still be running (the O projection under the
-// overlapped schedules): x_in / norm_w loads go out first, then the wave waits for its granules.  Same arithmetic as above.
-// dprev (any-order schedule only, nullable): x_in is the residual stream BEFORE the layer's fused-QKV kernel added its delta —
-// this kernel repeats that add (x = (x_in + dprev) + delta, the same two fp32 adds the serial schedule performs in two kernels)
-// because the QKV kernel, launched in front of this one without a completed-kernel boundary in between, cannot hand it its x_out
-// through plain memory.  x_in and dprev were final before the QKV kernel started.
+// overlapped schedule): the block waits for its granules, then reads x_in / norm_w.  Same arithmetic as above.
 template <int NJ>
-__device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in, const float* __restrict__ dprev, const VhGranVec& gd,
+__device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in, const VhGranVec& gd,
                                                  const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
                                                  float (&xr)[NJ][8]) {
-    // (x_in / dprev are read AFTER the wait: 16 KB that every block reads, L2-resident — holding them in registers across the wait,
-    // next to the router weights a gate|up block already holds, pushed the 128-register instantiation into scratch)
+    // (x_in is read AFTER the wait: 16 KB that every block reads, L2-resident — holding it in registers across the wait, next to the
+    // router weights a gate|up block already holds, pushed the 128-register instantiation into scratch)
     float dv[NJ][8];
     gran_read_gemv<NJ>(gd, K, dv);
     f32x4 xa[NJ][2];
@@ -279,10 +273,6 @@ __device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in,
         const int cc = (c * 8 < K) ? c : 0;
         xa[j][0] = reinterpret_cast<const f32x4*>(x_in)[cc * 2];
         xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
-        if (dprev) {
-            xa[j][0] += reinterpret_cast<const f32x4*>(dprev)[cc * 2];
-            xa[j][1] += reinterpret_cast<const f32x4*>(dprev)[cc * 2 + 1];
-        }
     }
     float ss = 0.f;
 #pragma unroll
@@ -343,9 +333,12 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gemv(const float* __res
                                                   float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                   float eps, const uint16_t* __restrict__ W, int N, int K,
                                                   float* __restrict__ out, const VhXchg xc, const VhGranVec gin,
-                                                  const VhGranVec gout) {
+                                                  const VhGranVec gout, unsigned long long* __restrict__ gate) {
     // xc: NORM = true: consumer of a fused exchange (delta = xc.reduced); NORM = false: producer (outputs are pushed)
+    // gate (GR, fused QKV): "this layer's QKV kernel has started" — opens the gate kernels in front of the side-stream kernels
     __shared__ float red[4 * (R + 1)];
+    if (GR && NORM && gate && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(gate, ((xu64)gout.tag << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (NORM && !GR) xchg_reduce(xc);
     const int n0 = blockIdx.x * R;
     const uint16_t* rows[R];
@@ -592,8 +585,7 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gateup(const float* __r
                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
                                                     int I, int K, int* __restrict__ route_out,
                                                     float* __restrict__ hbuf, const VhXchg cx, const VhGranVec gd) {
-    // GR (overlapped schedules): the attention delta arrives as granules (gd) from an O projection that may still be running; `delta`
-    // is then the PREVIOUS sub-block's delta to be added to x_in first (any-order schedule, nullable: see load_add_norm_g)
+    // GR (overlapped schedule): the attention delta arrives as granules (gd) from an O projection that may still be running
     __shared__ float red[4 * 9];
     float xr[NJ][8];
     float inv;
@@ -607,7 +599,7 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gateup(const float* __r
         gemv_issue<NJ, 8>(rrows, K, wr);
         float vals[9];
         if (!GR) xchg_wait(cx);
-        if (GR) vals[8] = load_add_norm_g<NJ>(x_in, delta, gd, norm_w, x_out, K, xr);
+        if (GR) vals[8] = load_add_norm_g<NJ>(x_in, gd, norm_w, x_out, K, xr);
         else vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
@@ -839,6 +831,20 @@ __global__ void k_dec_probe(int* mine, int* theirs, int* ok) {
     *ok = 0;
 }
 
+// ---- gate of a side stream (overlapped decode schedule): one wave that ends when `gate` carries `tag`, i.e. when this layer's
+// fused-QKV kernel has started.  The kernel BEHIND it in its stream (attention, O projection) then starts one in-queue kernel boundary
+// later (~2 us) — a cross-stream event takes 7-12 us to release its waiter on this platform (profiles/r05 timelines), and any
+// marker or completion event on the main stream costs 4-5 us of its critical path.  A gate only times the launch; the data
+// dependencies are the granule tags.  Bounded like every wait.
+__global__ void k_dec_gate(const unsigned long long* gate, unsigned tag, int* err) {
+    unsigned spins = 0;
+    for (;;) {
+        const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == tag) return;
+        if (gran_spin_fail(spins, err)) return;
+    }
+}
+
 // ---- the global argmax alone (per-operator entry vh_lmhead_argmax): lowest index on ties, as torch.argmax ------------
 __global__ __launch_bounds__(256) void k_dec_pick(const float* __restrict__ blk_val, const int* __restrict__ blk_idx, int nblk,
                                                   int vocab, int* __restrict__ token_out, float* __restrict__ value_out) {
@@ -1049,20 +1055,10 @@ static inline VhGranVec gran_or_none(const VhGranVec* g) {
     return g ? *g : z;            // g == nullptr: plain buffers
 }
 
-// One launch helper for the decode kernels: `stop` = an event that completes WITH this kernel (its dispatch packet's own completion
-// signal — no marker packet between this kernel and the next one of the stream, which hipEventRecord would add on the critical
-// path); flags = hipExtAnyOrderLaunch: the packet carries no barrier bit — the kernel may start while the kernels in front of it in
-// the stream still run (its inputs arrive as granules).  Neither: the ordinary launch.
-template <typename Kern, typename... Args>
-static inline void dec_launch(Kern kern, dim3 grid, hipStream_t st, hipEvent_t stop, unsigned flags, Args... args) {
-    if (stop || flags) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, nullptr, stop, flags, args...);
-    else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, args...);
-}
-
 template <int R, bool NORM>
 static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w,
                            float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc, const VhGranVec* gin,
-                           const VhGranVec* gout, hipEvent_t stop = nullptr, unsigned flags = 0) {
+                           const VhGranVec* gout, unsigned long long* gate = nullptr) {
     const bool gr = NORM ? (gout != nullptr) : (gin != nullptr && gout != nullptr);
     if ((gin || gout) && !gr) return -1;                 // the O projection takes granules on both sides or on neither
     return pick_nj(K, [&](auto nj) {
@@ -1071,12 +1067,12 @@ static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta
         if (gr) {
             // the granule instantiations exist for K <= 4096 (two chunk slots per thread): beyond that the 128-register cap spills
             if constexpr (NJ <= 2)
-                dec_launch(k_dec_gemv<NJ, R, NORM, true>, grid, st, stop, flags, x_in, delta, x_out, norm_w, eps, W, N, K, out, VhXchg{},
-                           gran_or_none(gin), gran_or_none(gout));
+                hipLaunchKernelGGL((k_dec_gemv<NJ, R, NORM, true>), grid, dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, W, N, K, out,
+                                   VhXchg{}, gran_or_none(gin), gran_or_none(gout), gate);
             else return -1;
         } else {
-            dec_launch(k_dec_gemv<NJ, R, NORM, false>, grid, st, stop, flags, x_in, delta, x_out, norm_w, eps, W, N, K, out,
-                       xchg_or_none(xc), VhGranVec{}, VhGranVec{});
+            hipLaunchKernelGGL((k_dec_gemv<NJ, R, NORM, false>), grid, dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, W, N, K, out,
+                               xchg_or_none(xc), VhGranVec{}, VhGranVec{}, (unsigned long long*)nullptr);
         }
         return 0;
     });
@@ -1101,34 +1097,34 @@ int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
 }
 
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out, const VhXchg* cx, const VhGranVec* gout, hipEvent_t stop) {
-    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, stop);
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx, const VhGranVec* gout, unsigned long long* gate) {
+    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, gate);
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table, const VhGranVec* gq, const VhGranVec* gout, unsigned flags) {
+                 const int* table, const VhGranVec* gq, const VhGranVec* gout) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits || nsplit > 65535) return -1;
     if ((gq != nullptr) != (gout != nullptr)) return -1;
-    if (gq) dec_launch(k_dec_attn<true>, dim3(nkv, nsplit), st, nullptr, flags, qkv, kcache, vcache, ctx_host - 1, table, rope_cos, rope_sin,
-                       part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, *gq, *gout);
-    else dec_launch(k_dec_attn<false>, dim3(nkv, nsplit), st, nullptr, flags, qkv, kcache, vcache, ctx_host - 1, table, rope_cos, rope_sin,
-                    part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
+    if (gq) hipLaunchKernelGGL(k_dec_attn<true>, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
+                               rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, *gq, *gout);
+    else hipLaunchKernelGGL(k_dec_attn<false>, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
+                            rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
     return 0;
 }
 
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px,
-                  const VhGranVec* gin, const VhGranVec* gout, unsigned flags) {
-    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px, gin, gout, nullptr, flags);
+                  const VhGranVec* gin, const VhGranVec* gout) {
+    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px, gin, gout);
 }
 
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cxp, const VhGranVec* gdelta, unsigned flags) {
+                   float* hbuf, int grid, const VhXchg* cxp, const VhGranVec* gdelta) {
     if (E > 8 || E < 2 || I % 4 != 0) return -1;
     const int n_iter = 2 * (I / 4);
     const VhXchg cx = xchg_or_none(cxp);
@@ -1136,33 +1132,28 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
     if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        // gdelta: the attention delta as granules; `delta` is then the previous sub-block's plain delta to add to x_in first (nullable)
-        if (gdelta) {
+        if (gdelta) {                                    // the attention delta as granules (`delta` is ignored)
             if constexpr (NJ <= 2)
-                dec_launch(k_dec_gateup<NJ, 4, true>, dim3(grid), st, nullptr, flags, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
-                           route_out, hbuf, VhXchg{}, *gdelta);
+                hipLaunchKernelGGL((k_dec_gateup<NJ, 4, true>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
+                                   route_out, hbuf, VhXchg{}, *gdelta);
             else return -1;
         } else {
-            dec_launch(k_dec_gateup<NJ, 4, false>, dim3(grid), st, nullptr, flags, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
-                       route_out, hbuf, cx, VhGranVec{});
+            hipLaunchKernelGGL((k_dec_gateup<NJ, 4, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
+                               route_out, hbuf, cx, VhGranVec{});
         }
         return 0;
     });
 }
 
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
-                 const VhXchg* pxp, hipEvent_t stop) {
+                 const VhXchg* pxp) {
     // one block per row pair (a persistent form that keeps both intermediate vectors in registers measured slower: 204.6-208.8
     // against 211.5 tok/s, r02, git history)
     constexpr int R = 2;
     const VhXchg px = xchg_or_none(pxp);
     return pick_nj(I, [&](auto nj) {
-        if (stop)
-            hipExtLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, nullptr, stop, 0, hbuf,
-                                  route, W2, N, I, out, px);
-        else
-            hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
-                               W2, N, I, out, px);
+        hipLaunchKernelGGL((k_dec_down<decltype(nj)::value, R>), dim3((N + R - 1) / R), dim3(256), 0, st, hbuf, route,
+                           W2, N, I, out, px);
         return 0;
     });
 }
@@ -1194,6 +1185,10 @@ int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int n
 
 int vhk_dec_probe(hipStream_t st, int* mine, int* theirs, int* ok) {
     hipLaunchKernelGGL(k_dec_probe, dim3(1), dim3(64), 0, st, mine, theirs, ok);
+    return 0;
+}
+int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err) {
+    hipLaunchKernelGGL(k_dec_gate, dim3(1), dim3(64), 0, st, gate, tag, err);
     return 0;
 }
 

@@ -28,9 +28,9 @@ struct VhTuning {
     int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange,
                                // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Chosen at bring-up by
                                // vita_amd.parallel (timed on the ranks' own devices; "kernel" whenever ranks share a device)
-    int dec_overlap = 1;       // batch-1 decode on one rank: 1 / 2 = overlapped schedule on side streams (1: cross-stream events recorded by
-                               // hipEventRecord, 2: as completion events of the QKV / down kernels themselves, hipExtLaunchKernel);
-                               // 3 = ONE stream, attention / O projection / gate|up launched without the barrier bit (hipExtAnyOrderLaunch) (attention and O projection on side streams, their inputs
+    int dec_overlap = 1;       // batch-1 decode on one rank: 1 = overlapped schedule (attention and O projection on side streams behind gate
+                               // kernels, their inputs and outputs as tagged granules; needs streams that really run concurrently —
+                               // probed once per engine), 0 = one stream, five serial launches per layer (attention and O projection on side streams, their inputs
                                // and outputs as tagged granules: a kernel's launch, weight / K-V loads and prologue run under its
                                // predecessor; needs streams that really run concurrently — probed once per engine), 0 = one stream
     int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
@@ -85,18 +85,17 @@ int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, Vh
 // ---- decode (vh_decode.hip) ---------------------------------------------------------
 // cx (nullable): the delta is the result of a fused exchange (then `delta` is ignored); px (nullable): push the outputs
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr, const VhGranVec* gout = nullptr,   // gout: linear granules instead of `out`
-                hipEvent_t stop = nullptr);   // stop: event completing with the kernel (hipExtLaunchKernel), no marker packet
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr, const VhGranVec* gout = nullptr,   // gout: LINEAR granules instead of `out`
+                unsigned long long* gate = nullptr);   // gate (with gout): word that block 0 sets to {gout->tag, 1} when the kernel starts
 int vhk_dec_consumer_blocks(int which, int N, int K, int I);   // grid of a consumer launch (0 qkv, 1 gate|up, 2 lm head): bounds nred
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
                  const int* table,    // table: nullable page table of a paged KV cache (64-token pages)
-                 const VhGranVec* gq = nullptr, const VhGranVec* gout = nullptr,    // gq: qkv as linear granules; gout: attn_out as GEMV-layout granules
-                 unsigned flags = 0);           // hipExtAnyOrderLaunch: no barrier bit on the dispatch packet
+                 const VhGranVec* gq = nullptr, const VhGranVec* gout = nullptr);   // gq: qkv as linear granules; gout: attn_out as GEMV-layout granules
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr,
-                  const VhGranVec* gin = nullptr, const VhGranVec* gout = nullptr,    // both in the GEMV layout (of K resp. of the consumer's K = N)
-                  unsigned flags = 0);
+                  const VhGranVec* gin = nullptr, const VhGranVec* gout = nullptr);   // both in the GEMV layout (of K resp. of the consumer's K = N)
+int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err);   // one wave that ends when *gate carries tag
 // ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
 #define VH_BMAX 4
 struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
@@ -117,10 +116,9 @@ int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w
                     const VhDecBatchHead& hd, int grid, int v0);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cx = nullptr, const VhGranVec* gdelta = nullptr,    // gdelta: the attention delta as GEMV-layout
-                   unsigned flags = 0);   // granules; `delta` then = the previous sub-block's plain delta, added to x_in first (nullable)
+                   float* hbuf, int grid, const VhXchg* cx = nullptr, const VhGranVec* gdelta = nullptr);   // gdelta: `delta` as GEMV-layout granules
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
-                 const VhXchg* px = nullptr, hipEvent_t stop = nullptr);
+                 const VhXchg* px = nullptr);
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
                    const uint16_t* W, int V, int K, float* logits, float* blk_val, int* blk_idx, int grid,
                    const int* ngen_ptr, int hist_rows, int v0, int Vfull, const VhXchg* cx = nullptr);

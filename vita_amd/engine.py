@@ -186,8 +186,7 @@ class MixtralEngine:
 
     def overlap_state(self):
         """schedule of the last decode call: -1 none yet, 0 one stream with five serial launches per layer (vh_tune("dec_overlap", 0),
-        tensor-parallel engine, or side streams that do not run concurrently), 1 overlapped on side streams, 3 overlapped on one stream
-        (any-order launches)."""
+        tensor-parallel engine, or side streams that do not run concurrently), 1 overlapped (attention / O projection on gated side streams)."""
         return int(self.lib.vh_mixtral_decode_overlap_state(self.h))
 
     def reset(self):
