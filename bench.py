@@ -327,6 +327,9 @@ def main():
                     help="debug (with --backend gloo --one-device): attempt the native RCCL init anyway — it must "
                          "fail (duplicate GPU) and every rank must agree on the torch fallback")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0 (invalid as a measurement)")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="live HIP-event sampling of the decode gate|up kernel: every n-th layer inside the timed steps (0 = off: "
+                         "the roofline object then has no live number)")
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="debug: run ONE rank's 1/N shard on one GPU with the collective skipped — per-rank compute "
                          "time of TP=N without communication (tokens are meaningless, result marked invalid)")
@@ -481,11 +484,12 @@ def main():
 
     # ---- decode: W warm-up steps, then exactly K timed steps ---------------------------------------------
     eng.decode(Wm)
-    eng.profile(stride=4, max_samples=K * 8 + 8)       # sample the gate|up GEMV of every 4th layer
+    eng.profile(stride=args.profile_stride, max_samples=K * 8 + 8)       # sample the gate|up GEMV of every 4th layer
     barrier()
     gpu_state.start("decode_phase")
     t1 = time.perf_counter()
     eng.decode(K)
+    t_host = time.perf_counter() - t1                  # the host's share: enqueueing K steps (the device runs behind it)
     barrier()
     dt = time.perf_counter() - t1
     gpu_state.stop()
@@ -580,7 +584,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "decode_tokens_per_s", "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world,
-            "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "steps": K, "warmup": Wm, "ms_per_step": round(ms_step, 4), "host_enqueue_ms_per_step": round(t_host * 1e3 / K, 4),
+            "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16 weights, f32 activations/accumulate",
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: 1 image (448x448, 1 tile -> 256 tokens)" if args.frames == 1 else

@@ -461,7 +461,6 @@ struct vh_mixtral {
     }
     // ---- overlapped decode schedule: attention on sA, O projection on sC, the rest on the caller's stream ----
     hipStream_t sA = nullptr, sC = nullptr;
-    std::vector<hipEvent_t> ev_o;                    // per layer: after the O projection (sC); only the profiled layers use it
     hipEvent_t ev_fork = nullptr, ev_joinA = nullptr, ev_joinC = nullptr;
     unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr;   // granule vectors (VhGranVec)
     unsigned long long* g_gate = nullptr;            // "this layer's fused-QKV kernel has started" (opens the side streams' gate kernels)
@@ -559,7 +558,6 @@ void vh_mixtral_destroy(vh_mixtral_t* m) {
     for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) hipEventDestroy(m->ev_r[i]); }
     if (m->cs) hipStreamDestroy(m->cs);
-    for (hipEvent_t e : m->ev_o) hipEventDestroy(e);
     for (hipEvent_t e : {m->ev_fork, m->ev_joinA, m->ev_joinC}) if (e) hipEventDestroy(e);
     if (m->sA) hipStreamDestroy(m->sA);
     if (m->sC) hipStreamDestroy(m->sC);
@@ -1072,9 +1070,6 @@ int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
     if (hipStreamCreateWithFlags(&sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sC, hipStreamNonBlocking) != hipSuccess)
         return 0;
     auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    ev_o.assign(c.n_layers, nullptr);
-    for (int l = 0; l < c.n_layers; ++l)
-        if (!mk(&ev_o[l])) return 0;
     if (!mk(&ev_fork) || !mk(&ev_joinA) || !mk(&ev_joinC)) return 0;
     // probe every PAIR of the three streams (HIP may multiplex streams onto fewer hardware queues: two streams of one queue run
     // in enqueue order, and a consumer enqueued first would wait for a producer queued behind it): two kernels, one per stream,
@@ -1138,22 +1133,28 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
         if (ov) {
             int* err = m->counters + 3;
             const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
-            // side streams first (host order is irrelevant to the device).  Attention's gate opens when QKV(l) STARTS (its K / V tiles
-            // are 5 MB: they load under the QKV stream); the O projection's gate opens when QKV block 0 has PUBLISHED (its 34 MB
-            // of weights would compete with the QKV stream; they load under the attention instead)
+            // Gates (one wave each; they only time the launches, the data dependencies are the granule tags):
+            //   attention   (sA): QKV(l) has STARTED — its K / V tiles are 5 MB, they load under the QKV stream;
+            //   O projection (sC): QKV's LAST block has published — its 34 MB of weights would slow the QKV stream (r05: 11.4 -> 15.6 us
+            //                      with the gate on the first block), they load under the attention instead;
+            //   gate|up   (main): the attention has published — its 384 PERSISTENT blocks split the expert rows statically, so they
+            //                      must be placed evenly: dispatched while attention blocks still hold 72 CUs and O blocks arrive, the
+            //                      late ones landed two and three to a CU and the kernel took 99 us for its 73 (r05 timeline).  Without
+            //                      this gate the schedule is 0.8 % faster WHEN gate|up wins the dispatch race against O (~1 us margin).
+            //                      A SAMPLED layer (live timing of gate|up alone) waits for the O projection's last block instead.
             VH_TRY(vhk_dec_gate(m->sA, m->g_gate, gq.tag, err), "dec gate");
             VH_TRY(vhk_dec_attn(m->sA, nullptr, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
                                 m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
                                 &gq, &ga), "dec attn");
-            VH_TRY(vhk_dec_gate(m->sC, vh_tuning()->dec_overlap == 2 ? m->g_gate : m->g_qkv, gq.tag, err), "dec gate");   // (2: experiment, both gates on QKV start)
+            VH_TRY(vhk_dec_gate(m->sC, m->g_qkv + (m->nqkv - 1), gq.tag, err), "dec gate");
             VH_TRY(vhk_dec_oproj(m->sC, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, &gd), "dec oproj");
             VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                                nullptr, nullptr, &gq, m->g_gate), "dec qkv");
             if (prof) {
-                // a sampled layer times gate|up ALONE: it starts behind the finished O projection instead of waiting inside the launch
-                hipEventRecord(m->ev_o[l], m->sC);
-                hipStreamWaitEvent(st, m->ev_o[l], 0);
+                VH_TRY(vhk_dec_gate(st, m->g_dattn + vhk_gran_pos_gemv(H - 1), gd.tag, err), "dec gate");
                 hipEventRecord(m->prof_ev[m->prof_used], st);
+            } else {
+                VH_TRY(vhk_dec_gate(st, m->g_attn, ga.tag, err), "dec gate");
             }
             VH_TRY(vhk_dec_gateup(st, m->xb, nullptr, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
                                   nullptr, &gd), "dec gateup");

@@ -105,7 +105,7 @@ __device__ __forceinline__ f32x4 xchg_ld4(const float* p) {
 // ---- granule vectors between concurrently resident kernels (VhGranVec, vh_kernels.h) -----------------------------------------
 // Every wait below is WAVE-collective (all 64 lanes run the same number of polls; exits are decided with __all) and bounded: a
 // producer that never publishes ends in the engine's error word (code 7), not in a hang.
-__device__ __forceinline__ size_t gran_pos_gemv(int n) { return (size_t)(((n >> 11) << 3) + (n & 7)) * 256 + ((n >> 3) & 255); }
+__device__ __forceinline__ size_t gran_pos_gemv(int n) { return vhk_gran_pos_gemv(n); }
 __device__ __forceinline__ void gran_put(const VhGranVec& gv, size_t pos, float v) {
     __hip_atomic_store(reinterpret_cast<xu64*>(gv.g) + pos, ((xu64)gv.tag << 32) | (xu64)__float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -154,7 +154,7 @@ __device__ __forceinline__ void gran_read_gemv(const VhGranVec& gv, int K, float
         for (;;) {
             if ((unsigned)(gran_ld(gv, sent) >> 32) == gv.tag) break;
             if (gran_spin_fail(spins, gv.err)) break;
-            __builtin_amdgcn_s_sleep(24);             // + the 8 of gran_spin_fail: ~1 us between looks
+            __builtin_amdgcn_s_sleep(8);              // + the 8 of gran_spin_fail: ~0.5 us between looks (<= 900 poller waves in all)
         }
     }
     __syncthreads();
@@ -1085,19 +1085,32 @@ static int dec_gateup_grid(int I) {
     // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
     // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
     const int n_iter = 2 * (I / 4);
-    const int grid = 3 * vh_num_cus() / 2;
+    const int cus = vh_num_cus();
+    // (r05) a tensor-parallel shard has few row groups (I = 1792 at TP = 8: 896): with 384 blocks they took 2 or 3 rounds of
+    // (HBM latency + 64 KB) each behind the router prologue — 16.4 us for 58.7 MB.  Up to 7 row groups per CU: equal shares of at
+    // most 3.5 resident blocks per CU (118 registers: 4 fit), i.e. one group per block at TP = 8, two at TP = 4.
+    if (n_iter <= 7 * cus) {
+        const int per = (2 * n_iter + 7 * cus - 1) / (7 * cus);          // ceil(n_iter / (3.5 cus))
+        return (n_iter + per - 1) / per;
+    }
+    const int grid = 3 * cus / 2;
     return grid > n_iter ? n_iter : grid;
 }
 // blocks of a consumer launch: the fused exchange's reducers are its first min(16, blocks) blocks
 int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
     (void)K;
-    if (which == 0) return (N + DEC_GEMV_R - 1) / DEC_GEMV_R;
+    if (which == 0) { const int r = (N + DEC_GEMV_R - 1) / DEC_GEMV_R < vh_num_cus() ? 2 : DEC_GEMV_R; return (N + r - 1) / r; }
     if (which == 1) return dec_gateup_grid(I);
     return N;   // LM head: the caller's grid
 }
 
+// (r05) rows per block for SMALL projections (a TP = 8 shard's fused QKV has 768 rows: 96 blocks of 8 rows leave 160 CUs idle)
+constexpr int DEC_GEMV_R_SMALL = 2;
+static bool dec_gemv_small(int N) { return (N + DEC_GEMV_R - 1) / DEC_GEMV_R < vh_num_cus(); }
+
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                 const uint16_t* W, int N, int K, float* out, const VhXchg* cx, const VhGranVec* gout, unsigned long long* gate) {
+    if (dec_gemv_small(N)) return launch_dec_gemv<DEC_GEMV_R_SMALL, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, gate);
     return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, gate);
 }
 

@@ -77,6 +77,7 @@ struct VhGranVec {
     int* err;                       // device error word (engine counters[3]): set when a bounded wait gives up
 };
 #define VH_GRAN_SPIN_LIMIT (1u << 21)      // polls of ~0.2-0.4 us: a producer that never publishes ends in the error word after ~0.5 s
+__host__ __device__ inline size_t vhk_gran_pos_gemv(int n) { return (size_t)(((n >> 11) << 3) + (n & 7)) * 256 + ((n >> 3) & 255); }   // layout 1: granule of element n
 __host__ __device__ inline size_t vh_gran_gemv_len(int K) { return (size_t)((K + 2047) / 2048) * 2048; }   // granules of a layout-1 vector
 
 struct vh_comm;
