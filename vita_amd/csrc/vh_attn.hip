@@ -537,9 +537,6 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 // 34 us at S = 552.)  The arithmetic per 32-key half tile (products, softmax, accumulation order) is the direct kernel's.
 // Measured (profiles/r04_attn_fa_v2.jsonl): S = 552 46.8 -> 34.3 us, S = 2344 468 -> 310 us.  A d = 64 instantiation for the ViT
 // (block = one head x 64 / 128 rows) was built and measured too: 50-63 vs 47 us on one image, a tie on eight — not kept.
-#ifndef FA_ABLATE
-#define FA_ABLATE 0      // development builds (profiles/ablate_fa.sh): 1 no global loads after the prologue, 2 no conversion / LDS writes after the prologue, 4 no softmax, 8 no PV products, 16 no QK products
-#endif
 template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_attn_fa(const VhAttnArgs p) {
@@ -656,7 +653,7 @@ void k_attn_fa(const VhAttnArgs p) {
         const unsigned char* Kh = buf; const unsigned char* Kl = buf + PL; const unsigned char* Vh = buf + 2 * PL; const unsigned char* Vl = buf + 3 * PL;
         const int kt0 = t * 64 + 32 * kg;
         unsigned char* nbuf = lds + ((t + 1) & 1) * 4 * PL;              // last read in tile t - 1: everyone is past it
-        const bool more = t + 1 < ntiles && !(FA_ABLATE & 2);
+        const bool more = t + 1 < ntiles;
         const int knext = min(t + 2, ntiles - 1) * 64;                  // (clamped: the last tile is simply re-read)
         if (kt0 < kloop) {                                            // (wave-uniform) this half tile has a visible key
             // ---- S = Q K^T for the two 16-key sub-tiles ------------------------------------------------------------------------
@@ -671,13 +668,9 @@ void k_attn_fa(const VhAttnArgs p) {
                     const int off = (gc >> 3) * 8192 + key * 128 + (((gc & 7) ^ ((key >> 1) & 7)) << 4);
                     const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
                     const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-#if defined(FA_ABLATE) && (FA_ABLATE & 16)
-                    a[0] += __builtin_bit_cast(f32x4, kh)[0] + __builtin_bit_cast(f32x4, kl)[1];
-#else
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[c], kh, a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[c], kl, a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[c], kh, a, 0, 0, 0);
-#endif
                 }
                 sacc[jt] = a;
             }
@@ -686,7 +679,7 @@ void k_attn_fa(const VhAttnArgs p) {
             // — half here, half behind the PV products — made hipcc wait vmcnt(0) here for the half reloaded a quarter tile earlier.)
             __builtin_amdgcn_sched_barrier(0);
             if (more) { store_part(0, nbuf); store_part(1, nbuf); }
-            if (!(FA_ABLATE & 1)) { load_part(0, knext); load_part(1, knext); }
+            load_part(0, knext); load_part(1, knext);
             __builtin_amdgcn_sched_barrier(0);
             // ---- online softmax in D layout (the direct kernel's) --------------------------------------------------------------
             const bool full_tile = kt0 + AT_KT <= (CAUSAL ? min(kend, q0 + p.q_off + 1) : kend);
@@ -700,11 +693,6 @@ void k_attn_fa(const VhAttnArgs p) {
                     s0v = (kt0 + lr < klim) ? s0v : -INFINITY;
                     s1v = (kt0 + 16 + lr < klim) ? s1v : -INFINITY;
                 }
-#if defined(FA_ABLATE) && (FA_ABLATE & 4)
-                alpha[r] = 1.f;
-                const float p0 = s0v, p1 = s1v;
-                l[r] += p0 + p1;
-#else
                 const float mx = grp16_max(fmaxf(s0v, s1v));
                 const float mn = fmaxf(m[r], mx);
                 const bool none = mn == -INFINITY;
@@ -713,7 +701,6 @@ void k_attn_fa(const VhAttnArgs p) {
                 const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1v - mn);
                 l[r] = l[r] * alpha[r] + grp16_sum(p0 + p1);
                 m[r] = mn;
-#endif
                 ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
                 ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
             }
@@ -733,20 +720,16 @@ void k_attn_fa(const VhAttnArgs p) {
                 const int off = row * 128 + (((4 * kg + lg) ^ ((row >> 1) & 7)) << 4);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Vh + off);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Vl + off);
-#if defined(FA_ABLATE) && (FA_ABLATE & 8)
-                o[tt][0] += __builtin_bit_cast(f32x4, bh)[0] + __builtin_bit_cast(f32x4, bl)[1] + __builtin_bit_cast(f32x4, ph)[0] + __builtin_bit_cast(f32x4, pl)[0];
-#else
                 o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, o[tt], 0, 0, 0);
                 o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bl, o[tt], 0, 0, 0);
                 o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, o[tt], 0, 0, 0);
-#endif
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             if (more) { store_part(0, nbuf); store_part(1, nbuf); }
-            if (!(FA_ABLATE & 1)) { load_part(0, knext); load_part(1, knext); }
+            load_part(0, knext); load_part(1, knext);
         }
         __syncthreads();
     }

@@ -1085,32 +1085,23 @@ static int dec_gateup_grid(int I) {
     // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
     // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
     const int n_iter = 2 * (I / 4);
+    // (r05: equal shares of up to 3.5 resident blocks per CU for the few row groups of a tensor-parallel shard — 896 blocks of one
+    // group at TP = 8 instead of 384 of two or three — together with 2-row blocks for the shard's 768-row fused QKV measured SLOWER:
+    // 1.405 against 1.332 ms per token of one rank's TP = 8 shard, profiles/r05_decode_schedule_ab.txt; not kept)
     const int cus = vh_num_cus();
-    // (r05) a tensor-parallel shard has few row groups (I = 1792 at TP = 8: 896): with 384 blocks they took 2 or 3 rounds of
-    // (HBM latency + 64 KB) each behind the router prologue — 16.4 us for 58.7 MB.  Up to 7 row groups per CU: equal shares of at
-    // most 3.5 resident blocks per CU (118 registers: 4 fit), i.e. one group per block at TP = 8, two at TP = 4.
-    if (n_iter <= 7 * cus) {
-        const int per = (2 * n_iter + 7 * cus - 1) / (7 * cus);          // ceil(n_iter / (3.5 cus))
-        return (n_iter + per - 1) / per;
-    }
     const int grid = 3 * cus / 2;
     return grid > n_iter ? n_iter : grid;
 }
 // blocks of a consumer launch: the fused exchange's reducers are its first min(16, blocks) blocks
 int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
     (void)K;
-    if (which == 0) { const int r = (N + DEC_GEMV_R - 1) / DEC_GEMV_R < vh_num_cus() ? 2 : DEC_GEMV_R; return (N + r - 1) / r; }
+    if (which == 0) return (N + DEC_GEMV_R - 1) / DEC_GEMV_R;
     if (which == 1) return dec_gateup_grid(I);
     return N;   // LM head: the caller's grid
 }
 
-// (r05) rows per block for SMALL projections (a TP = 8 shard's fused QKV has 768 rows: 96 blocks of 8 rows leave 160 CUs idle)
-constexpr int DEC_GEMV_R_SMALL = 2;
-static bool dec_gemv_small(int N) { return (N + DEC_GEMV_R - 1) / DEC_GEMV_R < vh_num_cus(); }
-
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                 const uint16_t* W, int N, int K, float* out, const VhXchg* cx, const VhGranVec* gout, unsigned long long* gate) {
-    if (dec_gemv_small(N)) return launch_dec_gemv<DEC_GEMV_R_SMALL, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, gate);
     return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, gate);
 }
 

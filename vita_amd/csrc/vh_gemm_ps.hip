@@ -129,7 +129,7 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
         const size_t kb = (size_t)(t.k0 + (hc >> 1)) * 128;
         const unsigned char* base = ((GLU && (i & 1)) ? w_up : w_gate) + kb;    // wave-uniform part: SGPR pair
         const uint32_t o = (hc & 1) ? offw1[i] : offw0[i];                      // per-lane part: one 32-bit VGPR
-        if (!(PS_ABLATE & 2)) glds16<NTW>(base, o, w_dst0 + slot * MG_SLOT + i * 2 * MG_SUB);
+        glds16<NTW>(base, o, w_dst0 + slot * MG_SLOT + i * 2 * MG_SUB);
     };
     // register-staged: this wave owns the 8-row half u = wid&1 of ALL 16 sub-tiles of the stages of its parity
     const int wu = wid & 1, wg = (wid >> 1) & 1;
@@ -142,21 +142,19 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
         int n = GLU ? t.n0 + (s16 >> 2) * 32 + (s16 & 1) * 16 + wr16 : t.n0 + s16 * 16 + wr16;
         if (n > p.N - 1) n = p.N - 1;             // clamped rows: products never stored
         const uint32_t o = (uint32_t)n * (uint32_t)(p.ldw * 2) + wcol;
-        if (PS_ABLATE & 2) return;
         if (NTW) dst = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + o));
         else dst = *reinterpret_cast<const u32x4*>(base + o);
     };
     unsigned char* const wr_dst0 = lds + W_BASE + wu * 1024 + lane * 16;
     auto w_store = [&](int kt, int s16, const u32x4& v) __attribute__((always_inline)) {
         // stage kt lives in slots (2 kt) % 4, +1: sub-tiles 0-7 / 8-15
-        if (!(PS_ABLATE & 2))
-            *reinterpret_cast<u32x4*>(wr_dst0 + (((2 * kt) & 3) + (s16 >> 3)) * MG_SLOT + (s16 & 7) * MG_SUB) = v;
+        *reinterpret_cast<u32x4*>(wr_dst0 + (((2 * kt) & 3) + (s16 >> 3)) * MG_SLOT + (s16 & 7) * MG_SUB) = v;
     };
     auto a_piece = [&](int kt, int i) __attribute__((always_inline)) {
         const int kc = kt < t.nk ? kt : t.nk - 1;
         const size_t kb = (size_t)(t.k0 + kc) * 128;
         const unsigned char* base = a_plane + kb;
-        if (!(PS_ABLATE & 1)) glds16<false>(base, offa[i], a_dst0 + (kt & 1) * A_BUF + i * MG_SUB);
+        glds16<false>(base, offa[i], a_dst0 + (kt & 1) * A_BUF + i * MG_SUB);
     };
 
     // ---- prologue --------------------------------------------------------------------------------------
@@ -220,12 +218,12 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
                 else if (MODE == 2) w_load(k + 2, q, wreg[q]);
             }
             bf16x8_t nh_ = ah, nl_ = al;
-            if (s + 1 < NSTEP && !(PS_ABLATE & 8)) {
+            if (s + 1 < NSTEP) {
                 const int ks1 = (s + 1) / (NSTEP / 2), rti1 = wm + 2 * ((s + 1) % (NSTEP / 2));
                 nh_ = *reinterpret_cast<const bf16x8_t*>(ab + rti1 * MG_SUB + (ks1 ? fo1 : fo0));
                 nl_ = *reinterpret_cast<const bf16x8_t*>(ab + (RTMAX + rti1) * MG_SUB + (ks1 ? fo1 : fo0));
             }
-            if (RTE > 0 && !(PS_ABLATE & 4) && !((PS_ABLATE & 16) && MODE != 0)) {   // 16: the weight waves skip their MFMAs
+            if (RTE > 0) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ks][c], ah, acc[i][c], 0, 0, 0);
 #pragma unroll
@@ -241,11 +239,9 @@ __device__ __forceinline__ void run_tile(const VhGemmPsArgs& p, const TileCtx& t
         }
         // pin that order: hipcc's scheduler otherwise sinks every fragment read to just before its MFMAs
         // (one register, lgkmcnt(0) in front of each group of four) and hoists all loads to the top
-        if ((PS_ABLATE & ~32) == 0) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);               // 8 weight + 2 activation fragment reads
-            StepOrder<0, NSTEP, NP, FRONT>::pin();
-            if (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);   // the LDS stores
-        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);               // 8 weight + 2 activation fragment reads
+        StepOrder<0, NSTEP, NP, FRONT>::pin();
+        if (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x200, 16, 0);   // the LDS stores
     };
 
     // the role branches are OUTSIDE the K loop (loops with matching barrier counts): with an if/else inside the

@@ -7,13 +7,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((address_space(3))) void* lds_void_t;
 typedef const __attribute__((address_space(1))) void* glb_void_t;
 
-// timing experiments only (results are wrong when non-zero): 1 = no activation pieces, 2 = no weight pieces,
-// 4 = no MFMAs, 8 = no fragment reads of the activations, 16 = no MFMAs in the weight-loading waves, 32 = no epilogue stores.  Built with -DPS_ABLATE=n by profiles/ablate_ps.sh.
-#ifndef PS_ABLATE
-#define PS_ABLATE 0
-#endif
+// (The compile-time ablation switches PS_ABLATE / FA_ABLATE of r02-r04 — one component compiled out per build, results in
+// profiles/EXPERIMENTS.md — were removed in r05; the scripts that built them are in profiles/scripts/ablate/ and need the r04 tree.)
 #ifndef PS_SCHED
-#define PS_SCHED 0                  // tile -> block schedule: 0 = contiguous run per XCD, 1 = cost-ordered grid stride (experiment)
+#define PS_SCHED 0                  // tile -> block schedule of the including kernel: 0 = contiguous run per XCD (k_gemm_ps), 1 = cost-ordered grid stride (k_gemm_sp sets it)
 #endif
 
 #define MG_SUB 2048                  // one 16-row x 128-byte (BK = 64) sub-tile
@@ -86,13 +83,6 @@ __device__ __forceinline__ void tile_epilogue(const VhGemmPsArgs& p, const TileC
     // launch, and it is where the slow boxes of the pool lose their time: QKV 133 us with the stores, 57 us without
     // (profiles/r03_proj_probe.txt; 70-80 us in all on a fast box).  So the tile goes through LDS (free after the K loop)
     // and leaves row by row: one wave instruction = 1 KB of ONE output row (fp32) / 256 B of two rows (bf16 planes).
-    if (PS_ABLATE & 32) {                            // timing experiment: no output at all
-#pragma unroll
-        for (int i = 0; i < RTW; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(acc[i][c]));
-        return;
-    }
     constexpr int NCOL = GLU ? 128 : 256;            // fp32 values per staged row
     constexpr int ROWB = NCOL * 4 + 16;              // + 16 B: consecutive rows start 4 banks apart
     constexpr int RC = GLU ? 192 : 96;               // rows per pass: 192 x 528 B = 99 KB / 96 x 1040 B = 97.5 KB

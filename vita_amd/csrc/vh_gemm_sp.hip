@@ -81,12 +81,12 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
             for (int s = 0; s < NSTEP; ++s) {
                 const int ks = s / (NSTEP / 2), i = s % (NSTEP / 2);
                 bf16x8_t nh_ = ah, nl_ = al;
-                if (s + 1 < NSTEP && !(PS_ABLATE & 8)) {
+                if (s + 1 < NSTEP) {
                     const int ks1 = (s + 1) / (NSTEP / 2), rti1 = wm + 2 * ((s + 1) % (NSTEP / 2));
                     nh_ = *reinterpret_cast<const bf16x8_t*>(ab + rti1 * MG_SUB + (ks1 ? fo1 : fo0));
                     nl_ = *reinterpret_cast<const bf16x8_t*>(ab + (RTMAX + rti1) * MG_SUB + (ks1 ? fo1 : fo0));
                 }
-                if (RTE > 0 && !(PS_ABLATE & 4)) {
+                if (RTE > 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ks][c], ah, acc[i][c], 0, 0, 0);
 #pragma unroll
@@ -98,10 +98,8 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
             }
             // pin the order: fragment reads one step ahead of the MFMAs that consume them (hipcc otherwise sinks every read
             // to just before its MFMAs and waits lgkmcnt(0) in front of each group of four)
-            if ((PS_ABLATE & ~32) == 0) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);               // 8 weight + 2 activation fragment reads
-                StepOrder<0, NSTEP, 0, 0>::pin();
-            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);               // 8 weight + 2 activation fragment reads
+            StepOrder<0, NSTEP, 0, 0>::pin();
         };
         auto loop = [&](auto rte_c) __attribute__((always_inline)) {
             for (int k = 0; k < t.nk; ++k) {
@@ -150,7 +148,6 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
                 int n = GLU ? t.n0 + (s16 >> 2) * 32 + (s16 & 1) * 16 + u * 8 + lr : t.n0 + s16 * 16 + u * 8 + lr;
                 if (n > p.N - 1) n = p.N - 1;                            // clamped rows: products never stored
                 const uint32_t o = (uint32_t)n * ldw2 + wcol[u];
-                if (PS_ABLATE & 2) continue;
                 if (NTW) wreg[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + o));
                 else wreg[q] = *reinterpret_cast<const u32x4*>(base + o);
             }
@@ -160,8 +157,7 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const int s16 = q >> 1, u = q & 1;
-                if (!(PS_ABLATE & 2))
-                    *reinterpret_cast<u32x4*>(wr_dst0 + (((2 * kt) & 3) + (s16 >> 3)) * MG_SLOT + (s16 & 7) * MG_SUB + u * 1024) = wreg[q];
+                *reinterpret_cast<u32x4*>(wr_dst0 + (((2 * kt) & 3) + (s16 >> 3)) * MG_SLOT + (s16 & 7) * MG_SUB + u * 1024) = wreg[q];
             }
         };
         // Stage 0 is staged by BOTH stagers (half each: it is needed at once); after that stager g owns the stages 1 + g, 3 + g, ...:
@@ -180,7 +176,6 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
                 int n = GLU ? t.n0 + (s16 >> 2) * 32 + (s16 & 1) * 16 + u * 8 + lr : t.n0 + s16 * 16 + u * 8 + lr;
                 if (n > p.N - 1) n = p.N - 1;
                 const uint32_t o = (uint32_t)n * ldw2 + wcol[u];
-                if (PS_ABLATE & 2) continue;
                 if (NTW) wreg[qq] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + o));
                 else wreg[qq] = *reinterpret_cast<const u32x4*>(base + o);
             }
@@ -188,7 +183,7 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
 #pragma unroll
             for (int qq = 0; qq < 16; ++qq) {
                 const int s16 = qq >> 1, u = qq & 1;                      // position inside slot g
-                if (!(PS_ABLATE & 2)) *reinterpret_cast<u32x4*>(wr_dst0 + g * MG_SLOT + s16 * MG_SUB + u * 1024) = wreg[qq];
+                *reinterpret_cast<u32x4*>(wr_dst0 + g * MG_SLOT + s16 * MG_SUB + u * 1024) = wreg[qq];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -241,7 +236,6 @@ __device__ __forceinline__ void run_tile_sp(const VhGemmPsArgs& p, const TileCtx
             unsigned char* dst = a_dst0 + (kt & 1) * A_BUF;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
-                if (PS_ABLATE & 1) continue;
                 glds16<false>(a_hi + kb, offa[i], dst + i * MG_SUB);
                 glds16<false>(a_lo + kb, offa[i], dst + (RTMAX + i) * MG_SUB);
             }
@@ -276,12 +270,8 @@ void k_gemm_sp(const VhGemmPsArgs p) {
     case RT:                                                                                               \
         if constexpr (RTMAX >= RT) run_tile_sp<GLU, RTMAX, (RT + 1) / 2, RT / 2, NTW>(p, t, lds, lane, wid); \
         break;
-#ifdef SP_ONLY_RT      // development builds: one row-tile count (resource usage of a single instantiation)
-            SP_CASE(SP_ONLY_RT)
-#else
             SP_CASE(1) SP_CASE(2) SP_CASE(3) SP_CASE(4) SP_CASE(5) SP_CASE(6)
             SP_CASE(7) SP_CASE(8) SP_CASE(9) SP_CASE(10) SP_CASE(11) SP_CASE(12)
-#endif
 #undef SP_CASE
             default: break;
         }
