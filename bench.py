@@ -119,7 +119,7 @@ class _BenchTokenizer:
         return [" ".join("</s>" if int(t) == 2 else f"w{int(t)}" for t in row) for row in ids.tolist()]
 
 
-TRAFFIC_FILES = ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+TRAFFIC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
 
 
 def traffic_source(kernel=None):
