@@ -137,7 +137,8 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
         lg = eng.logits_all[:10].cpu()
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
         assert eng.vocab_sharded and torch.equal(row0, lg[0]), "prefill() must return the full-vocabulary row under TP"
-        ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n), comm_status(eng), eng.decode_exchange)
+        ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n), comm_status(eng), eng.decode_exchange,
+                     eng.overlap_state())
         dist.barrier()
         eng.close()
     finally:
@@ -218,6 +219,12 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
         assert ret[0][5] == ret[1][5] and ret[0][5] in ("fused", "kernel"), (ret[0][5], ret[1][5])
     else:
         assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
+    # r05: with the one-kernel-per-exchange form the decode step runs the OVERLAPPED schedule under TP too (the attention exchange takes
+    # granules in and out on the O projection's side stream: vh_comm_allreduce_gran); the fused form keeps the serial schedule
+    if ret[0][5] == "kernel":
+        assert ret[0][6] == ret[1][6] == 1, f"overlapped decode schedule did not run under TP = 2: {ret[0][6]}, {ret[1][6]}"
+    else:
+        assert ret[0][6] == ret[1][6] == 0
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
     assert ret[0][1] == ret[1][1] == ref_ids

@@ -415,6 +415,7 @@ struct vh_mixtral {
         g_qkv = cv.take<unsigned long long>(nqkv);
         g_attn = cv.take<unsigned long long>(vh_gran_gemv_len(nq * hd));
         g_dattn = cv.take<unsigned long long>(vh_gran_gemv_len(H));
+        g_part = cv.take<unsigned long long>(vh_gran_gemv_len(H));
         g_gate = cv.take<unsigned long long>(2);
         probe = cv.take<int>(4);
         // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
@@ -462,7 +463,7 @@ struct vh_mixtral {
     // ---- overlapped decode schedule: attention on sA, O projection on sC, the rest on the caller's stream ----
     hipStream_t sA = nullptr, sC = nullptr;
     hipEvent_t ev_fork = nullptr, ev_joinA = nullptr, ev_joinC = nullptr;
-    unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr;   // granule vectors (VhGranVec)
+    unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr, *g_part = nullptr;   // granule vectors (VhGranVec)
     unsigned long long* g_gate = nullptr;            // "this layer's fused-QKV kernel has started" (opens the side streams' gate kernels)
     int* probe = nullptr;                            // 4 words of the stream-concurrency probe
     unsigned gran_epoch = 0;                         // last granule tag handed out (0 = never written)
@@ -1063,7 +1064,9 @@ static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, con
 // Deadlock freedom: a waiting kernel never holds what its producer needs — every producer is enqueued before its consumers and is
 // resident when they start (the gates open after QKV's blocks were dispatched); attention is <= nkv * splits blocks, the O
 // projection 2 and gate|up 1.5 blocks per CU of 120 / 128 registers against 512 per SIMD; every wait is bounded (error word,
-// counters[3]).  One rank only: under tensor parallelism the exchange kernels / VhXchg own these edges.
+// counters[3]).  Tensor parallel (IPC transport, one kernel per exchange): the attention exchange takes granules in and out and
+// rides the O projection's stream (vh_comm_allreduce_gran); the MoE exchange stays on the main stream between the down projection and
+// the next QKV.  The fused form (VhXchg), RCCL and the callback collective keep the serial schedule.
 int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
     if (streams_state >= 0) return streams_state;
     streams_state = 0;
@@ -1088,7 +1091,14 @@ int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
     return streams_state;
 }
 static bool overlap_wanted(const vh_mixtral* m) {
-    return vh_tuning()->dec_overlap != 0 && m->c.tp_world <= 1 && !vh_tuning()->force_allreduce && m->nq * m->hd <= 4096 && m->H <= 4096;
+    if (vh_tuning()->dec_overlap == 0 || vh_tuning()->force_allreduce || m->nq * m->hd > 4096 || m->H > 4096) return false;
+    if (m->c.tp_world <= 1) return true;
+    // tensor parallel: with the library's IPC transport in its one-kernel-per-exchange form the attention exchange takes granules in
+    // and out (vh_comm_allreduce_gran) and rides the O projection's side stream; every other collective keeps the serial schedule
+    // Ranks SHARING one device (tests) keep it only at world 2: the waiting gate|up blocks of eight ranks (8 x 384 x 4 waves) would not
+    // even fit the chip, and the O projection of a rank that lags would find no slot while the others spin on its partial.
+    return m->comm != nullptr && vh_tuning()->tp_fuse == 0 && (size_t)m->H <= vh_comm_capacity(m->comm) && m->H <= 32768 &&
+           (!vh_comm_ranks_share_device(m->comm) || m->c.tp_world <= 2);
 }
 // the side streams start behind everything already queued on st (prefill: KV cache, residual stream) ...
 static bool overlap_begin(vh_mixtral* m, hipStream_t st) {
@@ -1132,7 +1142,9 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
         const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
         if (ov) {
             int* err = m->counters + 3;
-            const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err};
+            const bool tp = m->c.tp_world > 1;
+            const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err},
+                            gp{m->g_part, m->next_tag(), err};     // gp: this rank's PARTIAL attention delta (tensor parallel only)
             // Gates (one wave each; they only time the launches, the data dependencies are the granule tags):
             //   attention   (sA): QKV(l) has STARTED — its K / V tiles are 5 MB, they load under the QKV stream;
             //   O projection (sC): QKV's LAST block has published — its 34 MB of weights would slow the QKV stream (r05: 11.4 -> 15.6 us
@@ -1147,7 +1159,11 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
                                 m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
                                 &gq, &ga), "dec attn");
             VH_TRY(vhk_dec_gate(m->sC, m->g_qkv + (m->nqkv - 1), gq.tag, err), "dec gate");
-            VH_TRY(vhk_dec_oproj(m->sC, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, &gd), "dec oproj");
+            VH_TRY(vhk_dec_oproj(m->sC, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, tp ? &gp : &gd), "dec oproj");
+            // tensor parallel: the all-reduce of the partial (RowParallel o_proj, vllm_file/mixtral.py:470-476) behind the O projection
+            // on its stream, granules in and out: it pushes an element to the peers as soon as the O projection has published it
+            if (tp && vh_comm_allreduce_gran(m->comm, &gp, &gd, H, m->sC) != VH_OK)
+                return fail(VH_E_COMM, "all-reduce failed: %s", vh_comm_last_error());
             VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                                nullptr, nullptr, &gq, m->g_gate), "dec qkv");
             if (prof) {
@@ -1160,6 +1176,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
                                   nullptr, &gd), "dec gateup");
             if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr), "dec down");
+            if (tp && m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");     // FusedMoE reduce_results (:405-414)
             continue;
         }
         VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,

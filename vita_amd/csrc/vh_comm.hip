@@ -100,6 +100,30 @@ __global__ __launch_bounds__(256) void k_ar_oneshot(float* __restrict__ buf, lon
     }
 }
 
+// The same exchange with its INPUT and OUTPUT as GEMV-layout granule vectors (VhGranVec, vh_kernels.h): the overlapped decode schedule
+// under tensor parallelism.  The O projection (side stream, possibly still running) publishes this rank's partial as tagged
+// granules; element i is pushed to the peers as soon as it has arrived, summed over the ranks in rank order, and handed to the
+// gate|up kernel (main stream, already resident) as a granule again — no kernel boundary on either side of the collective.
+__global__ __launch_bounds__(256) void k_ar_oneshot_gran(const VhGranVec gin, const VhGranVec gout, long count, Peers peers, uint64_t* local,
+                                                         size_t cap, int rank, int world, uint32_t tag, int* err) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const size_t pos = vhk_gran_pos_gemv((int)i);
+        float v = 0.f;
+        for (unsigned spins = 0;;) {                             // my partial element (agent scope: this device's O projection)
+            const u64 x = __hip_atomic_load(reinterpret_cast<const u64*>(gin.g) + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(x >> 32) == gin.tag) { v = __uint_as_float((uint32_t)x); break; }
+            if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (++spins > VH_COMM_SPIN_LIMIT) { __hip_atomic_store(err, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)rank * cap + i, tag, v);
+        float s = 0.f;
+        for (int r = 0; r < world; ++r) s += get(local + (size_t)r * cap + i, tag, err, 1);   // rank order: same sum everywhere
+        __hip_atomic_store(reinterpret_cast<u64*>(gout.g) + pos, ((u64)gout.tag << 32) | (u64)__float_as_uint(s), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- bulk path ---------------------------------------------------------------------------------------------------------
 // slice = elements owned by one rank (multiple of 4), cut into nchunk chunks of VH_COMM_CHUNK elements (the last one short).
 // The bulk area of a parity region starts BEHIND the one-shot slots (a payload word can never be read as a granule), and its
@@ -376,6 +400,33 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
 
 }  // extern "C"
 
+int vh_comm_ranks_share_device(const vh_comm* c) { return c && c->same_device ? 1 : 0; }
+
+// The one-shot all-reduce between two granule vectors (k_ar_oneshot_gran): same call counter, tag and parity discipline as
+// vh_comm_allreduce (the kinds interleave freely; every rank issues them in the same order).  Not part of the public C ABI.
+int vh_comm_allreduce_gran(vh_comm* c, const VhGranVec* gin, const VhGranVec* gout, long count, void* stream) {
+    if (!c || !gin || !gout || !gin->g || !gout->g || !c->connected) return cfail(VH_E_COMM, "vh_comm_allreduce_gran: not connected / null vector");
+    const size_t cap1 = c->cap < VH_COMM_ONESHOT_MAX ? c->cap : VH_COMM_ONESHOT_MAX;
+    if (count < 1 || (size_t)count > cap1) return cfail(VH_E_SHAPE, "vh_comm_allreduce_gran: message above the one-shot capacity");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    c->calls += 1;
+    uint32_t tag = (uint32_t)c->calls;
+    if (tag == 0) {
+        const int rc = comm_rewind(c, st);
+        if (rc != VH_OK) return rc;
+        c->calls += 1;
+        tag = (uint32_t)c->calls;
+    }
+    const size_t par = (size_t)(c->calls & 1);
+    Peers peers{};
+    for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r] + par * c->region;
+    hipLaunchKernelGGL(k_ar_oneshot_gran, dim3((int)((count + 255) / 256)), dim3(256), 0, st, *gin, *gout, count, peers,
+                       c->local + par * c->region, cap1, c->rank, c->world, tag, c->err);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cfail(VH_E_HIP, "vh_comm_allreduce_gran: launch", e);
+    return VH_OK;
+}
+
 // One all-reduce fused into the decode kernels: advances the call counter exactly as vh_comm_allreduce does (the two kinds
 // interleave freely) and describes the exchange for the producer and the consumer launch.  `which` picks the result vector
 // (0 attention sub-block, 1 MoE sub-block); `consumer_blocks` bounds the reducer count.  Not part of the public C ABI.
@@ -417,7 +468,7 @@ int vh_comm_status(vh_comm_t* c) {
     if (!c) return -1;
     int v = 0;
     if (hipMemcpy(&v, c->err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;   // 0 = no spin ever timed out; 1 = one-shot, 2 / 3 = bulk reduce / gather phase, 4 = barrier, 5 / 6 = fused exchange
+    return v;   // 0 = no spin ever timed out; 1 = one-shot, 2 / 3 = bulk reduce / gather phase, 4 = barrier, 5 / 6 = fused exchange, 7 = granule input
 }
 
 void vh_comm_destroy(vh_comm_t* c) {

@@ -82,6 +82,8 @@ __host__ __device__ inline size_t vh_gran_gemv_len(int K) { return (size_t)((K +
 
 struct vh_comm;
 int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, VhXchg* out, void* stream);   // vh_comm.hip
+int vh_comm_allreduce_gran(vh_comm* c, const VhGranVec* gin, const VhGranVec* gout, long count, void* stream);   // vh_comm.hip: one-shot all-reduce, granules in and out
+int vh_comm_ranks_share_device(const vh_comm* c);   // declared at creation (tests): every rank drives this device
 
 // ---- decode (vh_decode.hip) ---------------------------------------------------------
 // cx (nullable): the delta is the result of a fused exchange (then `delta` is ignored); px (nullable): push the outputs
