@@ -126,6 +126,9 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
         assert eng.c.n_q_heads == t.num_attention_heads // world and eng.c.n_kv_heads == t.num_key_value_heads // world
         assert eng.c.inter == t.intermediate_size // world
         _lib.tune("tp_overlap", overlap)
+        # r05: world 2 with the one-kernel-per-exchange form also runs the OVERLAPPED decode schedule (on request under TP): the attention
+        # exchange then takes granules in and out on the O projection's side stream (vh_comm_allreduce_gran)
+        _lib.tune("dec_overlap", 1 if (world == 2 and fuse == 0) else -1)
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective=collective)
         rng = np.random.default_rng(5)
         ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
@@ -219,9 +222,9 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
         assert ret[0][5] == ret[1][5] and ret[0][5] in ("fused", "kernel"), (ret[0][5], ret[1][5])
     else:
         assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
-    # r05: with the one-kernel-per-exchange form the decode step runs the OVERLAPPED schedule under TP too (the attention exchange takes
-    # granules in and out on the O projection's side stream: vh_comm_allreduce_gran); the fused form keeps the serial schedule
-    if ret[0][5] == "kernel":
+    # r05: (overlap, fuse) = (1, 0) and (0, 0) also ask for the OVERLAPPED decode schedule under TP (the attention exchange takes granules
+    # in and out on the O projection's side stream: vh_comm_allreduce_gran); every other case keeps the serial schedule
+    if fuse == 0:
         assert ret[0][6] == ret[1][6] == 1, f"overlapped decode schedule did not run under TP = 2: {ret[0][6]}, {ret[1][6]}"
     else:
         assert ret[0][6] == ret[1][6] == 0

@@ -140,7 +140,7 @@ def test_overlapped_decode_schedule_equals_one_stream(full, dev):
             torch.cuda.synchronize()
             runs.append((eng.generated(), eng.logits_all[:25].clone(), eng.overlap_state()))
     finally:
-        _lib.tune("dec_overlap", 1)
+        _lib.tune("dec_overlap", -1)
     assert [r[2] for r in runs] == [1, 0, 1, 1], f"schedules that ran: {[r[2] for r in runs]} (1 missing: the side streams are not concurrent on this box?)"
     assert len(runs[0][0]) == 25
     for toks, lg, _ in runs[1:]:

@@ -250,7 +250,7 @@ def test_removed_knobs_are_rejected():
     assert len(KNOBS) <= 16
     for key in KNOBS:
         _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4, "attn_fa": 1,
-                        "dec_overlap": 1}.get(key, 0))    # (every key back at its default)
+                        "dec_overlap": -1}.get(key, 0))    # (every key back at its default)
 
 
 # r04's 15 keys + r05's dec_overlap (the overlapped decode schedule; 0 = the one-stream schedule every earlier round ran)

@@ -84,7 +84,7 @@ def test_decode_schedules_vs_oracle(dev, overlap):
     try:
         _run(dev, cfg, S=130, n_new=12, seed=4, chunked=True)
     finally:
-        _lib.tune("dec_overlap", 1)
+        _lib.tune("dec_overlap", -1)
 
 
 def test_group4_experts8(dev):

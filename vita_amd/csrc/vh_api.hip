@@ -1091,8 +1091,18 @@ int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
     return streams_state;
 }
 static bool overlap_wanted(const vh_mixtral* m) {
-    if (vh_tuning()->dec_overlap == 0 || vh_tuning()->force_allreduce || m->nq * m->hd > 4096 || m->H > 4096) return false;
+    const int want = vh_tuning()->dec_overlap;       // -1 auto, 0 never, 1 wherever the schedule is available
+    if (want == 0 || vh_tuning()->force_allreduce || m->nq * m->hd > 4096 || m->H > 4096) return false;
+    // auto: a single-rank engine whose expert slices have <= 7168 columns, where it measured a gain (one rank's shard of a TP = 2 / 4 / 8
+    // layer, collective skipped: 2.6 / 4.7 / 6.9 % faster, profiles/r05_emulated_tp*.json — the five launch ramps are most of such a layer).
+    // One rank's layer of the released model (I = 14336: 789 MB, 144 us) is a tie (211.5 against 211.4 tok/s,
+    // profiles/r05_bench_driver_line*.json): its two expert kernels already run at the copy ceiling, and the serial schedule keeps the
+    // dominant kernel's time free of in-kernel waits
+    if (want < 0 && (m->c.tp_world > 1 || m->I > 7168)) return false;
     if (m->c.tp_world <= 1) return true;
+    // (tensor parallel: only on request.  The path is tested at world 2 on one device with small kernels; two full-size ranks SHARING a
+    // device starve each other — waiting gate|up blocks of both ranks fill the registers the other rank's O projection needs, r05 call 10
+    // — and a node where each rank owns its device was never available to try it)
     // tensor parallel: with the library's IPC transport in its one-kernel-per-exchange form the attention exchange takes granules in
     // and out (vh_comm_allreduce_gran) and rides the O projection's side stream; every other collective keeps the serial schedule
     // Ranks SHARING one device (tests) keep it only at world 2: the waiting gate|up blocks of eight ranks (8 x 384 x 4 waves) would not
@@ -1167,7 +1177,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
             VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
                                nullptr, nullptr, &gq, m->g_gate), "dec qkv");
             if (prof) {
-                VH_TRY(vhk_dec_gate(st, m->g_dattn + vhk_gran_pos_gemv(H - 1), gd.tag, err), "dec gate");
+                VH_TRY(vhk_dec_gate(st, m->g_dattn, gd.tag, err, H >= 64 ? H / 64 : 1, H), "dec gate");
                 hipEventRecord(m->prof_ev[m->prof_used], st);
             } else {
                 VH_TRY(vhk_dec_gate(st, m->g_attn, ga.tag, err), "dec gate");

@@ -836,11 +836,14 @@ __global__ void k_dec_probe(int* mine, int* theirs, int* ok) {
 // later (~2 us) — a cross-stream event takes 7-12 us to release its waiter on this platform (profiles/r05 timelines), and any
 // marker or completion event on the main stream costs 4-5 us of its critical path.  A gate only times the launch; the data
 // dependencies are the granule tags.  Bounded like every wait.
-__global__ void k_dec_gate(const unsigned long long* gate, unsigned tag, int* err) {
+// stride > 0: lane l looks at GEMV-layout element (l + 1) * stride - 1 instead (64 elements spread over the producer's blocks: "the
+// whole vector has been published", used in front of a gate|up launch whose time is sampled).
+__global__ void k_dec_gate(const unsigned long long* gate, unsigned tag, int* err, int stride, int n) {
+    const size_t pos = stride > 0 ? gran_pos_gemv(min(((int)threadIdx.x + 1) * stride, n) - 1) : 0;
     unsigned spins = 0;
     for (;;) {
-        const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(x >> 32) == tag) return;
+        const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(gate) + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(x >> 32) == tag)) return;
         if (gran_spin_fail(spins, err)) return;
     }
 }
@@ -1191,8 +1194,8 @@ int vhk_dec_probe(hipStream_t st, int* mine, int* theirs, int* ok) {
     hipLaunchKernelGGL(k_dec_probe, dim3(1), dim3(64), 0, st, mine, theirs, ok);
     return 0;
 }
-int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err) {
-    hipLaunchKernelGGL(k_dec_gate, dim3(1), dim3(64), 0, st, gate, tag, err);
+int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err, int stride, int n) {
+    hipLaunchKernelGGL(k_dec_gate, dim3(1), dim3(64), 0, st, gate, tag, err, stride, n);
     return 0;
 }
 

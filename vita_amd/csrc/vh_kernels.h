@@ -28,9 +28,10 @@ struct VhTuning {
     int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange,
                                // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Chosen at bring-up by
                                // vita_amd.parallel (timed on the ranks' own devices; "kernel" whenever ranks share a device)
-    int dec_overlap = 1;       // batch-1 decode on one rank: 1 = overlapped schedule (attention and O projection on side streams behind gate
-                               // kernels, their inputs and outputs as tagged granules; needs streams that really run concurrently —
-                               // probed once per engine), 0 = one stream, five serial launches per layer (attention and O projection on side streams, their inputs
+    int dec_overlap = -1;      // batch-1 decode: 1 = overlapped schedule (attention and O projection on side streams behind gate kernels, their
+                               // inputs and outputs as tagged granules; needs streams that really run concurrently — probed once per
+                               // engine), 0 = one stream, five serial launches per layer, -1 = auto (overlapped where it measured a
+                               // gain: single-rank engines with expert slices of <= 7168 columns; serial for the full-size layer and under TP) (attention and O projection on side streams, their inputs
                                // and outputs as tagged granules: a kernel's launch, weight / K-V loads and prologue run under its
                                // predecessor; needs streams that really run concurrently — probed once per engine), 0 = one stream
     int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
@@ -98,7 +99,8 @@ int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache,
                  const VhGranVec* gq = nullptr, const VhGranVec* gout = nullptr);   // gq: qkv as linear granules; gout: attn_out as GEMV-layout granules
 int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr,
                   const VhGranVec* gin = nullptr, const VhGranVec* gout = nullptr);   // both in the GEMV layout (of K resp. of the consumer's K = N)
-int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err);   // one wave that ends when *gate carries tag
+int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err, int stride = 0, int n = 0);   // one wave that ends when *gate
+                                                              // carries tag (stride > 0: when 64 spread elements of an n-element GEMV-layout vector do)
 // ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
 #define VH_BMAX 4
 struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
