@@ -5,7 +5,10 @@ duplex demo feeds the same shape, web_demo/web_interactive_demo.py:284-366) at t
   8 frames of 448 x 448 -> ONE batch of n = 8 tiles through the 24-layer InternViT + projector: 8 x 256 image tokens
   10 s of audio (998 fbank frames) -> 24-layer Whale + adapter: 124 audio tokens
   S = 1 + 139 + 2048 + 32 + 124 = 2344 prompt rows (experts see ~586 rows each: four m-tiles per expert in the streaming GEMM,
-  the longest prefill any test runs) through VITA_VIDEO_LAYERS backbone layers (default 8), 6 greedy steps
+  the longest prefill any test runs) through VITA_VIDEO_LAYERS backbone layers (default 8), 6 greedy steps.
+  (r05 tried 16 layers by default: ONE of the 37 504 router decisions — row 2272 at layer 10 — sits on a tie of the oracle's own 2nd / 3rd expert
+  logits; the device takes the other expert, and the 71 rows behind it that attend to it move by up to 1.7e-2 at layer 15, above the hidden-state
+  bar.  The full-depth corners of the suite are the S = 552 request (32 layers, also under TP = 8) and the reference's assets (S = 1496, 32 layers).)
 
 against the fp64 encoder restatements and the layer-streamed fp32 oracle: encoder outputs, spliced embeddings, every router
 decision, hidden states, logits < 1e-3, ids ==.  (n = 5 tiles: tests/test_assets_gpu.py; n = 1: tests/test_realgeom_gpu.py.)"""
@@ -76,14 +79,27 @@ def test_eight_frame_video_prompt_matches_oracle(dev):
 
     full = np.concatenate([o_emb, stream.embed_rows(t, toks[:-1], SEED)], 0)
     t0 = time.time()
-    ref = stream.forward(t, SEED, full, n_layers=L, capture=sorted(d_hid), logits_from=S - 1)
+    ref = stream.forward(t, SEED, full, n_layers=L, capture=sorted(d_hid), logits_from=S - 1, margins=True)
     print(f"[video] oracle backbone ({L} layers, {full.shape[0]} rows) in {time.time() - t0:.1f}s")
-    mism = np.argwhere((np.sort(route, -1) != np.sort(ref["route"][:, :S], -1)).any(-1))
-    print(f"router top-2 sets: {route.shape[0] * S} decisions, {len(mism)} differ", mism[:5].tolist())
-    assert len(mism) == 0
+    # Router decisions: 2344 rows x L layers of a DISCONTINUOUS choice.  A row is excused from the layer on where the ORACLE's own
+    # margin between its 2nd and 3rd expert is a tie at fp32 re-association noise (< TIE): the device then legitimately follows the
+    # other expert and that row's hidden state goes its own way (r05: at 16 layers one row of 37 504 decisions, row 2272 at layer 10).
+    # Every other decision must be the oracle's, and the last-row logits / greedy ids keep the north-star bar.
+    TIE, MAX_TIED_ROWS = 3e-4, 4
+    diff = (np.sort(route, -1) != np.sort(ref["route"][:, :S], -1)).any(-1)             # [L, S]
+    tied_rows = np.flatnonzero(diff.any(0))
+    print(f"router top-2 sets: {route.shape[0] * S} decisions, {int(diff.sum())} differ in {len(tied_rows)} row(s)")
+    for r in tied_rows:
+        l0 = int(np.argmax(diff[:, r]))
+        mg = float(ref["margin"][l0, r])
+        print(f"  row {int(r)}: first differs at layer {l0}, oracle margin (2nd - 3rd expert logit) {mg:.2e}")
+        assert mg < TIE, f"row {int(r)} layer {l0}: the device took another expert where the oracle's margin is {mg:.2e} (not a tie)"
+    assert len(tied_rows) <= MAX_TIED_ROWS and S - 1 not in tied_rows
+    keep = np.ones(S, bool)
+    keep[tied_rows] = False
     for l in sorted(d_hid):
         h_ref = ref["hidden"][l][:S]
-        assert_close(f"hidden after layer {l}", d_hid[l], h_ref, atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
+        assert_close(f"hidden after layer {l} ({int(keep.sum())} rows)", d_hid[l][keep], h_ref[keep], atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
     ref_ids = ref["logits"].argmax(-1).tolist()
     print("device ids", toks, "oracle ids", ref_ids)
     print(report(f"logits of the {T_NEW} steps", logits, ref["logits"]))
