@@ -25,6 +25,12 @@
 // prologue ("delta" buffers) so that under tensor parallelism the same kernels run
 // unchanged with an all-reduce on the delta buffer between them.
 //
+// r05: every kernel of the attention block also exists as a GR ("granule") instantiation for the OVERLAPPED schedule
+// (vh_api.hip: decode_one_step): its inputs / outputs are tagged 8-byte {tag, fp32} granules polled with agent-scope
+// atomics (VhGranVec), so that attention and the O projection can be resident on side streams — K / V tiles and weights in
+// flight — while the kernel that feeds them still runs; k_dec_gate is the one-wave kernel that times their launch.  Same
+// per-thread arithmetic and reduction order as the serial instantiations: the two schedules are bit-identical.
+//
 // Reference semantics restated: transformers/models/mixtral/modeling_mixtral.py
 // (MixtralRMSNorm, MixtralAttention + apply_rotary_pos_emb, MixtralTopKRouter,
 // MixtralExperts) as called from vita/model/language_model/vita_mixtral.py:158-173.
