@@ -237,6 +237,36 @@ def test_gemm_ps_ksplit_slabs(dev, ps_cfg):
         assert_close(f"ksplit {ks}", to_np(y.sum(0)), ref, atol=2e-4)
 
 
+@pytest.mark.parametrize("cnt", [[2, 0, 1, 0, 0, 2, 0, 1], [1, 1, 1, 0, 1, 1, 0, 1], [3, 2, 4, 1, 2, 1, 2, 1], [6, 0, 0, 0, 0, 0, 0, 0]])
+def test_gemm_ps_device_chosen_ksplit_few_rows(dev, cnt):
+    """the down projection of an iteration of a few concurrent sequences (vh_api.hip: decode_iteration): every expert holds a handful of rows,
+    the kernel picks the K split itself (ksplit = -4) and reports it; the slabs it wrote add up to the unsplit product.  With one row tile per
+    expert a partial round cannot be M-split, so 4 touched experts x 16 n-tiles take 4 slabs (256 tiles: the whole chip), not 2."""
+    from vita_amd import ops
+    rng = np.random.default_rng(sum(cnt) * 31 + cnt[0])
+    E, H, I = 8, 4096, 1024
+    M = int(sum(cnt))
+    h = rng.standard_normal((M, I), dtype=np.float32)
+    w2 = _w(rng, E, H, I)
+    goff = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    perm = rng.permutation(M).astype(np.int32)
+    hh, hl = ops.split_planes(_dev(h, dev))
+    y = torch.full((4, M, H), 7.0, dtype=torch.float32, device=dev)
+    nslab = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.gemm_ps(hh, hl, _dev(w2, dev, torch.bfloat16), group_off=_dev(goff, dev, torch.int32), ngroups=E, w_group_stride=H * I,
+                c_rowidx=_dev(perm, dev, torch.int32), out=y, ksplit=-4, nslab_out=nslab)
+    ks = int(nslab.item())
+    assert 1 <= ks <= 4
+    ref = np.zeros((M, H))
+    for e in range(E):
+        for p in range(goff[e], goff[e + 1]):
+            ref[perm[p]] = h[p].astype(np.float64) @ w2[e].T
+    assert_close(f"device-chosen ksplit {ks}", to_np(y[:ks].sum(0)), ref, atol=3e-4)
+    assert torch.all(y[ks:] == 7.0)                                    # slabs above the reported count are not touched
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256 and sum(c > 0 for c in cnt) == 4:
+        assert ks == 4
+
+
 def _planes_to_f32(hi, lo):
     return hi.float() + lo.float()
 

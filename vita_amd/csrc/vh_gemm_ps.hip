@@ -391,7 +391,11 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
     // round is M-split relies on L2 for the second reader of each weight tile (gate|up: +5 % with nt)
     bool nt = vh_tuning()->ps_nt > 0;
-    if (vh_tuning()->ps_nt < 0) {
+    if (vh_tuning()->ps_nt < 0 && a.group_off && avg <= 8) {
+        // iterations of a few concurrent sequences: one row tile per expert, so no last-round tile is M-split and no weight tile has a second
+        // reader (r05: 12.27 / 13.50 / 17.58 ms per iteration of 3 / 4 / 8 sequences with the hint against 12.61 / 13.90 / 18.19 without)
+        nt = true;
+    } else if (vh_tuning()->ps_nt < 0) {
         const int NOUT = a.W_up ? 128 : 256;
         const long T = (long)groups * ((avg + (cfg == 0 ? 63 : 191)) / (cfg == 0 ? 64 : 192)) * ((a.N + NOUT - 1) / NOUT) * (a.ksplit > 0 ? a.ksplit : 2);
         const long nb = grid / 8, Tx = (T + 7) / 8, r = Tx % nb;

@@ -213,14 +213,26 @@ __device__ __forceinline__ void for_each_tile(const VhGemmPsArgs& p, F&& f) {
     // rounds(ks) / ks + a per-tile overhead and takes the minimum; the count goes to *nslab_out for the reducer.
     int KS = p.ksplit > 1 ? p.ksplit : 1;
     if (p.ksplit < 0) {
+        // Iterations of a few concurrent sequences (every expert <= 16 rows: ONE row tile per m-tile): a last-round tile cannot be cut along M
+        // (its second half would be empty), so a partial round costs a whole one; and a slab is a few rows, not a prefill's hundreds — its price
+        // scales with the rows.  (r05, profiles/r05_kernel_stats_concurrent_b3.txt: with the M-split credit and the prefill's slab price, 4
+        // touched experts took ks = 2 — 128 tiles on half the CUs — where ks = 4 fills the chip: B = 3 at 12.6 ms per iteration against r02's 11.9.)
+        // (8-wave kernels only: the specialised kernel takes tall tiles, and its code stays what the r05 prefill numbers were measured on)
+#if PS_SCHED == 0
+        const bool one_rt = n_exp > 0 && rows_of(ord[0]) <= 16;
+        const int slab_rows = p.M < 512 ? p.M : 512;
+#else
+        constexpr bool one_rt = false;
+        constexpr int slab_rows = 512;
+#endif
         int best = 1 << 30;
         for (int ks = 1; ks <= -p.ksplit && ks <= nk_total; ++ks) {
             const int Tx = (MT * NT * ks + 7) >> 3;                   // tiles of the fullest XCD
             const int Rr = Tx / nb, rr = Tx - Rr * nb;
-            const int rounds16 = 16 * Rr + (rr == 0 ? 0 : (2 * rr <= nb ? 9 : 16));   // M-split last round ~ 0.55
+            const int rounds16 = 16 * Rr + (rr == 0 ? 0 : ((2 * rr <= nb && !one_rt) ? 9 : 16));   // M-split last round ~ 0.55
             // + ~6 % of a full tile per round (prologue, epilogue) + what a slab costs to store and to sum again, in the
-            // same units (a K = 4096 slab ~ 48; r03, profiles/r03_proj_variants.txt: O projection 5 slabs 57.5 us, 2 slabs 52.8)
-            const int est = (rounds16 * 64) / ks + 4 * rounds16 + ks * ((48 * 64) / nk_total);
+            // same units (a K = 4096 slab of >= 512 rows ~ 48; r03, profiles/r03_proj_variants.txt: O projection 5 slabs 57.5 us, 2 slabs 52.8)
+            const int est = (rounds16 * 64) / ks + 4 * rounds16 + ks * (((48 * 64) / nk_total) * slab_rows >> 9);
             if (est < best) { best = est; KS = ks; }
         }
         if (p.nslab_out && blockIdx.x == 0 && threadIdx.x == 0) *p.nslab_out = KS;
