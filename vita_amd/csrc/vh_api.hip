@@ -1305,8 +1305,9 @@ int vh_mixtral_seq_prefill(vh_mixtral_t* m, int s, const float* embeds, int Sn, 
 // the shared weights per group).  The MoE of a layer runs
 //   n >= batch_moe_min (default 3): ONCE for the whole iteration on the prefill's weight-streaming GEMM with S = n — rows
 //       sorted by expert, every TOUCHED expert streamed exactly once at ~5 TB/s however many sequences picked it
-//       (k_gemm_ps cfg 0, <= 64 rows per tile, SURVEY 8(f)#1: "continuous batching");
-//   otherwise per sequence with the batch-1 GEMV kernels (de-duplicating GEMV variant behind batch_moe).
+//       (k_gemm_ps cfg 0, <= 64 rows per tile — with its few-row rules: vh_gemm_ps_inl.h K-split estimator, vh_gemm_ps.hip cache hint;
+//       "continuous batching");
+//   otherwise per sequence with the batch-1 GEMV kernels.
 // Sequence state is addressed in place (slots); the MoE delta of a sequence is a row of the shared `ptmp` buffer.
 static int decode_iteration(vh_mixtral* m, hipStream_t st, const int* ids, int n) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
