@@ -556,12 +556,12 @@ vh_mixtral_t* vh_mixtral_create(const vh_mixtral_cfg* cfg, const vh_mixtral_laye
 
 void vh_mixtral_destroy(vh_mixtral_t* m) {
     if (!m) return;
-    for (hipEvent_t e : m->prof_ev) hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) hipEventDestroy(m->ev_r[i]); }
-    if (m->cs) hipStreamDestroy(m->cs);
-    for (hipEvent_t e : {m->ev_fork, m->ev_joinA, m->ev_joinC}) if (e) hipEventDestroy(e);
-    if (m->sA) hipStreamDestroy(m->sA);
-    if (m->sC) hipStreamDestroy(m->sC);
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) (void)hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) (void)hipEventDestroy(m->ev_r[i]); }
+    if (m->cs) (void)hipStreamDestroy(m->cs);
+    for (hipEvent_t e : {m->ev_fork, m->ev_joinA, m->ev_joinC}) if (e) (void)hipEventDestroy(e);
+    if (m->sA) (void)hipStreamDestroy(m->sA);
+    if (m->sC) (void)hipStreamDestroy(m->sC);
     if (m->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->rccl_comm);
     delete m;
 }
@@ -692,8 +692,8 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     if (overlap) {
         if (m->ensure_comm_stream() != 0) return fail(VH_E_HIP, "prefill: comm stream creation failed");
         // the comm stream starts behind everything already queued on the compute stream
-        hipEventRecord(m->ev_c[0], st);
-        hipStreamWaitEvent(m->cs, m->ev_c[0], 0);
+        (void)hipEventRecord(m->ev_c[0], st);
+        (void)hipStreamWaitEvent(m->cs, m->ev_c[0], 0);
     }
 
     // py holds 8 * max_prefill * H floats: K-split slabs of the projections (and of the MoE down projection later)
@@ -725,7 +725,7 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             VH_TRY(vhk_rmsnorm_route(st, m->px, nullptr, m->pxn_hi, m->pxn_lo, w.attn_norm, Sn, H, m->c.rms_eps, nullptr, 0,
                                      nullptr, nullptr, combine_pending ? &cu : nullptr), "rmsnorm");
             if (combine_pending && hidden_dbg)
-                hipMemcpyAsync(hidden_dbg + (size_t)(l - 1) * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
+                (void)hipMemcpyAsync(hidden_dbg + (size_t)(l - 1) * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
                                hipMemcpyDeviceToDevice, st);
             combine_pending = false;
             VhGemmPsArgs g{};
@@ -775,13 +775,13 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                     g.c_split_stride = Sm * H2; g.nslab_out = m->pnslab + 2 + h;
                     VH_TRY(vhk_gemm_ps(st, g), "o gemm");
                     VH_TRY(vhk_sum_slabs(st, part, H2, yh, H2, Sn, H2, m->pnslab + 2 + h, 1, g.c_split_stride, 0), "slab sum");
-                    hipEventRecord(m->ev_c[h], st);
-                    hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
+                    (void)hipEventRecord(m->ev_c[h], st);
+                    (void)hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
                     if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
-                    hipEventRecord(m->ev_r[h], m->cs);
+                    (void)hipEventRecord(m->ev_r[h], m->cs);
                 }
-                hipStreamWaitEvent(st, m->ev_r[0], 0);
-                hipStreamWaitEvent(st, m->ev_r[1], 0);
+                (void)hipStreamWaitEvent(st, m->ev_r[0], 0);
+                (void)hipStreamWaitEvent(st, m->ev_r[1], 0);
                 VH_TRY(vhk_add_halves(st, m->px, m->ptmp, m->ptmp + (size_t)Sn * H2, Sn, H), "add");
             } else {
                 g.N = H; g.C = m->py; g.ldc = H; g.c_split_stride = Sm * H; g.nslab_out = m->pnslab + 2;
@@ -808,13 +808,13 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                     float* part = m->ptmp + (size_t)h * Sn * H2;
                     g.W = w.wo + (size_t)h * H2 * g.ldw; g.N = H2; g.C = part; g.ldc = H2;
                     VH_TRY(vhk_gemm(st, g), "o gemm");
-                    hipEventRecord(m->ev_c[h], st);
-                    hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
+                    (void)hipEventRecord(m->ev_c[h], st);
+                    (void)hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
                     if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
-                    hipEventRecord(m->ev_r[h], m->cs);
+                    (void)hipEventRecord(m->ev_r[h], m->cs);
                 }
-                hipStreamWaitEvent(st, m->ev_r[0], 0);
-                hipStreamWaitEvent(st, m->ev_r[1], 0);
+                (void)hipStreamWaitEvent(st, m->ev_r[0], 0);
+                (void)hipStreamWaitEvent(st, m->ev_r[1], 0);
                 VH_TRY(vhk_add_halves(st, m->px, m->ptmp, m->ptmp + (size_t)Sn * H2, Sn, H), "add");
             } else {
                 if (tp) { g.C = m->ptmp; g.ldc = H; }
@@ -844,9 +844,9 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             g.group_off = m->pgoff; g.ngroups = E;
             g.C_hi = m->ph_hi; g.C_lo = m->ph_lo; g.ldc_split = I; g.M = 2 * Sn; g.N = I; g.K = H; g.ksplit = 1;
             const bool prof = m->prof_stride < 0 && (l % -m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
-            if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
+            if (prof) (void)hipEventRecord(m->prof_ev[m->prof_used], st);
             VH_TRY(vhk_gemm_ps(st, g), "gate/up gemm");
-            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+            if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             nslab = vh_tuning()->moe_ksplit;           // < 0: chosen by the kernel from the expert sizes (up to -n)
             if (nslab == 0) nslab = 1;
             if (nslab > 4) nslab = 4;
@@ -873,13 +873,13 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
                     if (hipMemsetAsync(part, 0, (size_t)Sn * H2 * sizeof(float), st) != hipSuccess)
                         return fail(VH_E_HIP, "memset failed");
                     VH_TRY(vhk_moe_combine(st, part, yh, m->pwts, Sn, H2, nslab, hslab, nslab_dev), "combine");
-                    hipEventRecord(m->ev_c[h], st);
-                    hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
+                    (void)hipEventRecord(m->ev_c[h], st);
+                    (void)hipStreamWaitEvent(m->cs, m->ev_c[h], 0);
                     if (m->allreduce(part, (long)Sn * H2, m->cs) != 0) return fail(VH_E_COMM, "all-reduce failed");
-                    hipEventRecord(m->ev_r[h], m->cs);
+                    (void)hipEventRecord(m->ev_r[h], m->cs);
                 }
-                hipStreamWaitEvent(st, m->ev_r[0], 0);
-                hipStreamWaitEvent(st, m->ev_r[1], 0);
+                (void)hipStreamWaitEvent(st, m->ev_r[0], 0);
+                (void)hipStreamWaitEvent(st, m->ev_r[1], 0);
                 VH_TRY(vhk_add_halves(st, m->px, m->ptmp, m->ptmp + (size_t)Sn * H2, Sn, H), "add");
                 moe_done = true;
             } else {
@@ -900,10 +900,10 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             VH_TRY(vhk_moe_combine(st, m->px, m->py, m->pwts, Sn, H, nslab, slab, nslab_dev), "combine");
         }
         if (m->route_dbg)
-            hipMemcpyAsync(m->route_dbg + (size_t)l * 2 * Sn, m->pids, (size_t)2 * Sn * sizeof(int),
+            (void)hipMemcpyAsync(m->route_dbg + (size_t)l * 2 * Sn, m->pids, (size_t)2 * Sn * sizeof(int),
                            hipMemcpyDeviceToDevice, st);
         if (hidden_dbg && !combine_pending)
-            hipMemcpyAsync(hidden_dbg + (size_t)l * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
+            (void)hipMemcpyAsync(hidden_dbg + (size_t)l * Sn * H, m->px, (size_t)Sn * H * sizeof(float),
                            hipMemcpyDeviceToDevice, st);
     }
     // logits of the last position only (the reference computes all S rows and uses the last:
@@ -914,8 +914,8 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     }
     m->host_pos = pos0 + Sn;
     if (logits_out)
-        hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * sizeof(float), hipMemcpyDeviceToDevice, st);
-    hipError_t e = hipGetLastError();
+        (void)hipMemcpyAsync(logits_out, m->logits, (size_t)m->V * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipError_t e = hipGetLastError();          // also what an event / copy enqueue above ((void) calls) left behind
     if (e != hipSuccess) return fail(VH_E_HIP, "prefill: %s", hipGetErrorString(e));
     return VH_OK;
 }
@@ -1114,18 +1114,25 @@ static bool overlap_wanted(const vh_mixtral* m) {
 static bool overlap_begin(vh_mixtral* m, hipStream_t st) {
     m->overlap_state = 0;
     if (!overlap_wanted(m) || m->ensure_overlap_streams(st) != 1) return false;
-    hipEventRecord(m->ev_fork, st);
-    hipStreamWaitEvent(m->sA, m->ev_fork, 0);
-    hipStreamWaitEvent(m->sC, m->ev_fork, 0);
+    if (hipEventRecord(m->ev_fork, st) != hipSuccess || hipStreamWaitEvent(m->sA, m->ev_fork, 0) != hipSuccess ||
+        hipStreamWaitEvent(m->sC, m->ev_fork, 0) != hipSuccess) {
+        (void)hipGetLastError();                     // nothing of the step is on a side stream yet: the serial schedule runs
+        return false;
+    }
     m->overlap_state = 1;
     return true;
 }
-// ... and st ends behind them: a caller that synchronises st has the whole step
-static void overlap_end(vh_mixtral* m, hipStream_t st) {
-    hipEventRecord(m->ev_joinA, m->sA);
-    hipEventRecord(m->ev_joinC, m->sC);
-    hipStreamWaitEvent(st, m->ev_joinA, 0);
-    hipStreamWaitEvent(st, m->ev_joinC, 0);
+// ... and st ends behind them: a caller that synchronises st has the whole step.  If the join cannot be enqueued the side streams are
+// drained here (the caller's stream would otherwise run ahead of them) and the engine refuses further steps.
+static int overlap_end(vh_mixtral* m, hipStream_t st) {
+    if (hipEventRecord(m->ev_joinA, m->sA) == hipSuccess && hipEventRecord(m->ev_joinC, m->sC) == hipSuccess &&
+        hipStreamWaitEvent(st, m->ev_joinA, 0) == hipSuccess && hipStreamWaitEvent(st, m->ev_joinC, 0) == hipSuccess)
+        return VH_OK;
+    const hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(m->sA);
+    (void)hipStreamSynchronize(m->sC);
+    m->poisoned = 1;
+    return fail(VH_E_HIP, "decode: joining the side streams failed: %s", hipGetErrorString(e));
 }
 int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m) { return m ? m->overlap_state : -1; }
 
@@ -1178,13 +1185,13 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
                                nullptr, nullptr, &gq, m->g_gate), "dec qkv");
             if (prof) {
                 VH_TRY(vhk_dec_gate(st, m->g_dattn, gd.tag, err, H >= 64 ? H / 64 : 1, H), "dec gate");
-                hipEventRecord(m->prof_ev[m->prof_used], st);
+                (void)hipEventRecord(m->prof_ev[m->prof_used], st);
             } else {
                 VH_TRY(vhk_dec_gate(st, m->g_attn, ga.tag, err), "dec gate");
             }
             VH_TRY(vhk_dec_gateup(st, m->xb, nullptr, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
                                   nullptr, &gd), "dec gateup");
-            if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+            if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr), "dec down");
             if (tp && m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");     // FusedMoE reduce_results (:405-414)
             continue;
@@ -1198,10 +1205,10 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
             return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
         VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
         if (!fuse && m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
-        if (prof) hipEventRecord(m->prof_ev[m->prof_used], st);
+        if (prof) (void)hipEventRecord(m->prof_ev[m->prof_used], st);
         VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
                               m->route, m->hbuf, 0, fuse ? &xa : nullptr), "dec gateup");
-        if (prof) { hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+        if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
         if (fuse) {
             // the consumer of this exchange is the next layer's QKV GEMV, or the LM head after the last layer
             const int blocks = l + 1 < m->c.n_layers ? vhk_dec_consumer_blocks(0, m->nqkv, H, I) : m->lm_grid;
@@ -1240,7 +1247,10 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
         }
         m->host_pos += 1;
     }
-    if (ov) overlap_end(m, st);
+    if (ov) {
+        const int rj = overlap_end(m, st);
+        if (rc == VH_OK) rc = rj;
+    }
     return rc;
 }
 
@@ -1481,7 +1491,10 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         m->unbind();
         if (rc != VH_OK) break;
     }
-    if (ov) overlap_end(m, st);
+    if (ov) {
+        const int rj = overlap_end(m, st);
+        if (rc == VH_OK) rc = rj;
+    }
     return rc;
 }
 
