@@ -304,12 +304,12 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
         (e = hipMalloc(reinterpret_cast<void**>(&c->reduced[0]), 2 * ((red_elems + 63) & ~size_t(63)) * sizeof(float))) != hipSuccess ||
         (e = hipDeviceSynchronize()) != hipSuccess) {
         cfail(VH_E_HIP, "vh_comm_create: initialisation", e);
-        hipFree(c->local); delete c; return nullptr;
+        (void)hipFree(c->local); (void)hipFree(c->err); (void)hipFree(c->reduced[0]); delete c; return nullptr;   // (null pointers are no-ops)
     }
     hipIpcMemHandle_t h;
     if ((e = hipIpcGetMemHandle(&h, c->local)) != hipSuccess) {
         cfail(VH_E_HIP, "vh_comm_create: hipIpcGetMemHandle", e);
-        hipFree(c->local); hipFree(c->err); delete c; return nullptr;
+        (void)hipFree(c->local); (void)hipFree(c->err); (void)hipFree(c->reduced[0]); delete c; return nullptr;
     }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     memcpy(handle_out, &h, sizeof(h));
@@ -474,10 +474,10 @@ int vh_comm_status(vh_comm_t* c) {
 void vh_comm_destroy(vh_comm_t* c) {
     if (!c) return;
     for (int r = 0; r < c->world; ++r)
-        if (c->opened[r]) hipIpcCloseMemHandle(c->peer[r]);
-    hipFree(c->local);
-    hipFree(c->err);
-    hipFree(c->reduced[0]);
+        if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    (void)hipFree(c->local);
+    (void)hipFree(c->err);
+    (void)hipFree(c->reduced[0]);
     delete c;
 }
 
