@@ -119,7 +119,7 @@ class _BenchTokenizer:
         return [" ".join("</s>" if int(t) == 2 else f"w{int(t)}" for t in row) for row in ids.tolist()]
 
 
-TRAFFIC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+TRAFFIC_FILES = ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
 
 
 def traffic_source(kernel=None):
@@ -151,6 +151,19 @@ def pmc_traffic(kernel):
     return None
 
 
+def kernel_trace_us(kernel):
+    """average duration (us) of `kernel` in the committed `rocprofv3 --kernel-trace --stats` run of this same command (TP=1; written by
+    profiles/r06_measure.sh -> profiles/r06_kernel_times.json), or None.  Kernel time proper: the live HIP events of this process also
+    contain the launch gap in front of the kernel (~2-4 % longer)."""
+    for name in ("r06_kernel_times.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)[kernel]["avg_us"]), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
 PREFILL_KERNEL_KEY = "k_gemm_ps_moe_gateup (prefill S=552)"     # key of the PMC traffic files (profiles/make_traffic_json.py)
 
 
@@ -166,6 +179,9 @@ def prefill_kernel_roofline(S, E, I_r, H, layers, total_ms, samples, world=1):
     return {"bound": "hbm", "kernel": "k_gemm_sp<GLU> (vh_gemm_sp.hip: MoE gate|up grouped GEMM + SiLU*up, all experts; specialised form of k_gemm_ps)",
             "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "frac_live_events": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "frac_kernel_trace": (round(nbytes / (kernel_trace_us("k_gemm_sp_glu")[0] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+                                  if one_gpu and kernel_trace_us("k_gemm_sp_glu")[0] else None),
             "bytes_per_launch": nbytes, "avg_launch_us": round(us, 2) if us else None, "samples": int(samples),
             "launches_per_prefill": int(layers),
             # exact mode: 2 bf16 MFMAs per weight fragment (hi + lo planes) -> 2 x (2 S rows x 2 I x H MACs) x 2 FLOP at 2.5 PF dense
@@ -275,7 +291,10 @@ def cpu_baseline(cfg, n_layers=2, ctx=None, n_tok=6, encoders=True, request=None
            "ms_per_layer_token": round(per_layer * 1e3, 3), "ms_lm_head": round(head * 1e3, 3),
            "tokens_per_s_by_threads": {str(k): round(v[0], 4) for k, v in sweep.items()},
            "prefill_ms": round(prefill_ms, 1), "prefill_cores": int(pre_thr),
-           "prefill_sample": f"the same {n_layers} layers over the S={S} prompt rows, x{L_full}/{n_layers} + LM head (extrapolated)"}
+           "prefill_sample": f"the same {n_layers} layers over the S={S} prompt rows, x{L_full}/{n_layers} + LM head (extrapolated)",
+           # every leg with ITS thread count (each is the best of the counts tried; the top-level "cores" is the decode leg's)
+           "legs": {"decode": {"value": round(tok_s, 4), "unit": "tokens/s", "cores": int(threads)},
+                    "prefill": {"value": round(prefill_ms, 1), "unit": "ms", "cores": int(pre_thr)}}}
     if encoders and request is not None:
         import torch as _torch
         from oracle import encoders_torch as ot
@@ -297,6 +316,8 @@ def cpu_baseline(cfg, n_layers=2, ctx=None, n_tok=6, encoders=True, request=None
                 t_a[thr] = time.perf_counter() - t0
             _torch.set_num_threads(all_t)
         bv, ba = min(t_v, key=t_v.get), min(t_a, key=t_a.get)
+        out["legs"]["vit_projector"] = {"value": round(t_v[bv] * 1e3, 1), "unit": "ms", "cores": int(bv)}
+        out["legs"]["audio_encoder"] = {"value": round(t_a[ba] * 1e3, 1), "unit": "ms", "cores": int(ba)}
         out.update({"vit_projector_ms": round(t_v[bv] * 1e3, 1), "audio_encoder_ms": round(t_a[ba] * 1e3, 1),
                     "encoder_cores": int(bv), "audio_encoder_cores": int(ba),
                     "encoder_ms_by_threads": {str(k): [round(t_v[k] * 1e3, 1), round(t_a[k] * 1e3, 1)] for k in t_v},
@@ -331,8 +352,14 @@ def main():
                     help="live HIP-event sampling of the decode gate|up kernel: every n-th layer inside the timed steps (0 = off: "
                          "the roofline object then has no live number)")
     ap.add_argument("--emulate-tp", type=int, default=0,
-                    help="debug: run ONE rank's 1/N shard on one GPU with the collective skipped — per-rank compute "
-                         "time of TP=N without communication (tokens are meaningless, result marked invalid)")
+                    help="debug: run ONE rank's 1/N shard on one GPU — per-rank time of TP=N without a second device (tokens are "
+                         "those of the shard alone, result marked invalid).  With --loopback the 65 exchanges of a decode step run too")
+    ap.add_argument("--loopback", action="store_true",
+                    help="with --emulate-tp N: attach a loop-back communicator (vh_comm_create_loopback: the rank pushes into its own N "
+                         "receive slots and reduces them — the stores, polls, tags and launches of the real exchange, no link)")
+    ap.add_argument("--exchange", default="fused", choices=["fused", "kernel"],
+                    help="with --loopback: form of the decode exchange — fused into the producer / consumer kernels (what ranks that own "
+                         "their device vote for) or one all-reduce kernel per exchange")
     ap.add_argument("--frames", type=int, default=1,
                     help="debug: number of 448x448 tiles / video frames in the prompt (default 1 = configs[2]; 4-16 is the "
                          "video shape of configs[4])")
@@ -410,6 +437,17 @@ def main():
     model.get_vision_tower().load_model()
     eng = model.engine
     collective = "none"
+    loop_comm = None
+    if args.loopback:
+        if not args.emulate_tp or world > 1:
+            raise SystemExit("--loopback needs --emulate-tp N on one process")
+        from vita_amd import _lib as _l
+        from vita_amd.parallel import IpcComm
+        loop_comm = IpcComm(0, args.emulate_tp, t.hidden_size, loopback=True)
+        eng.attach_comm(loop_comm)
+        _l.tune("tp_fuse", 1 if args.exchange == "fused" else 0)
+        eng.decode_exchange = args.exchange
+        collective = f"loopback+{args.exchange}"
     if world > 1:
         from vita_amd.parallel import collective_label, setup_tensor_parallel
         collective = collective_label(eng, setup_tensor_parallel(eng, rank, world, dev, backend=args.backend, collective=args.collective))
@@ -595,9 +633,10 @@ def main():
                                    "greedy decode, batch 1; VITA-Mixtral-8x7B geometry (32 layers, 8 experts top-2)",
                        "parallelism": f"tp{world}", "collective": collective, "prompt_tokens": int(S),
                        "layers": t.num_hidden_layers,
-                       # which decode schedule the timed steps ran: "overlapped" = attention / O projection on gated side streams with
-                       # tagged-granule hand-offs, "one-stream" = five serial launches per layer
-                       "decode_schedule": {1: "overlapped", 0: "one-stream"}.get(eng.overlap_state(), "unknown")},
+                       # how the timed steps ran a layer's attention block: "fused-attention-block" = ONE launch (QKV rows, attention tiles
+                       # and O rows as work items with granule hand-offs), "three-launches" = QKV, attention, O projection
+                       "decode_schedule": eng.decode_schedule(),
+                       "launches_per_layer": 3 if eng.decode_schedule() == "fused-attention-block" else 5},
             "prefill_ms": round(phase["prefill_ms"], 3), "vit_projector_ms": round(phase["vit_proj_ms"], 3),
             "audio_encoder_ms": round(phase["audio_ms"], 3),
             "ttft_ms": round(phase["prefill_ms"] + phase["vit_proj_ms"] + phase["audio_ms"], 3),
@@ -612,6 +651,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_dec_gateup (router + gate|up GEMV of the 2 routed experts)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+                         # the same fraction under its two clocks: live HIP events around the launch inside THIS run's timed steps (they
+                         # include the launch gap) and the kernel's own duration in the committed rocprofv3 --kernel-trace run of this command
+                         "frac_live_events": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+                         "frac_kernel_trace": (round(gateup_bytes / (kernel_trace_us("k_dec_gateup")[0] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+                                               if world == 1 and not args.emulate_tp and kernel_trace_us("k_dec_gateup")[0] else None),
+                         "kernel_trace_source": kernel_trace_us("k_dec_gateup")[1] if world == 1 and not args.emulate_tp else None,
                          "bytes_per_launch": gateup_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "samples": n_samp,
                          "traffic": pmc_traffic("k_dec_gateup") if world == 1 else None,
                          "traffic_source": (f"{traffic_source()} (static: rocprofv3 --pmc FETCH_SIZE pass of this kernel, "
@@ -631,6 +676,9 @@ def main():
             out["tune"] = args.tune
         if args.emulate_tp:
             out["INVALID_emulated_tp_rank_compute_only"] = args.emulate_tp
+            out["emulated_tp"] = {"world": args.emulate_tp, "exchanges": ("looped back into this rank's own receive slots: 2 per layer + the head's "
+                                                                           "candidate exchange, " + args.exchange + " form") if args.loopback else "skipped",
+                                  "decode_schedule": eng.decode_schedule(), "comm_status": loop_comm.status() if loop_comm else None}
         if args.text_tokens != 32:
             out["INVALID_debug_text_tokens"] = args.text_tokens
         if args.frames != 1:

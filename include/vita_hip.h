@@ -37,9 +37,9 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
-/* Kernel-variant knobs (16 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
+/* Kernel-variant knobs (17 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
  * "prefill_attn_gemm", "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse",
- * "comm_allow_coarse", "dec_overlap"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
+ * "comm_allow_coarse", "comm_ranks_per_device", "dec_fused"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
  * measured-best variants, ids are identical across variants.  Unknown keys (e.g. of variants removed in r04) return VH_E_ARG. */
 int vh_tune(const char* key, int value);
 
@@ -248,10 +248,16 @@ int vh_mixtral_init_rccl(vh_mixtral_t* m, const void* unique_id_128_bytes /* hos
  * values in place across the ranks (every rank must call it, in the same order, with the same count); results are
  * bit-identical on all ranks.  vh_comm_status: 0, or the phase whose bounded spin timed out (sticky: once set, every
  * later poll gives up at once).  vh_comm_create FAILS when fine-grained memory cannot be allocated, unless the caller
- * declared that all ranks share one device (vh_tune("comm_allow_coarse", 1): same-device tests).  The 32-bit granule tag
- * wraps every 2^32 calls; the library then re-zeroes its regions between two barriers (collective, same call on all ranks). */
+ * declared that all ranks share one device (vh_tune("comm_allow_coarse", 1): same-device tests); it reads
+ * vh_tune("comm_ranks_per_device", n) — how many ranks drive this rank's device (1 on a node with a GPU per rank).  The 32-bit
+ * granule tag wraps every 2^32 calls; the library then re-zeroes its regions between two barriers (collective, same call on all ranks).
+ * vh_comm_create_loopback: a connected single-process communicator in which `rank` plays all `world` ranks into its own receive slots
+ * (the stores, polls, tags and rank-ordered sums of a real exchange without a link; sums equal the inputs) — what
+ * `bench.py --emulate-tp N --loopback` attaches to put the 65 exchanges of a decode step into one rank's measured time.
+ * cap_elems <= 32768 (decode-sized messages only). */
 typedef struct vh_comm vh_comm_t;
 vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_out);
+vh_comm_t* vh_comm_create_loopback(int rank, int world, size_t cap_elems);
 int vh_comm_connect(vh_comm_t* c, const void* handles);
 size_t vh_comm_capacity(const vh_comm_t* c);
 int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream);
@@ -272,20 +278,17 @@ int vh_mixtral_cancel_rccl(vh_mixtral_t* m);
 int vh_mixtral_route_debug(vh_mixtral_t* m, int* ids_out);
 int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int S, int pos0, float* logits_out, float* hidden_dbg,
                        void* stream);
-/* Run n_steps greedy decode steps back to back with no host interaction.  The OVERLAPPED schedule (vh_tune("dec_overlap", 1); the
- * default -1 = auto takes it for single-rank engines with expert slices of <= 7168 columns, where it measured 3-7 %, and the
- * serial schedule for one rank's full-size layer, where it is a tie, and under tensor parallelism, where it runs on request only): the attention and O-projection
- * kernels of a layer are enqueued on two side streams
- * of the engine, each behind a one-wave gate kernel that ends when the layer's fused-QKV kernel has started, so that their
- * launch, K / V-tile and weight loads and prologue run under the QKV kernel; their inputs and outputs travel as tagged granules.
- * `stream` still brackets the call: the side streams start behind everything queued on it and it ends behind them.  The first
- * call probes once whether streams of this process really run concurrently; if not, the one-stream schedule is used (same
- * arithmetic, same results bit for bit).
+/* Run n_steps greedy decode steps back to back with no host interaction.  Three launches per layer: the ATTENTION BLOCK as one
+ * launch (k_dec_ablk: the fused-QKV rows, the split-KV attention tiles and the O-projection rows are work items of 2 persistent
+ * blocks per CU; q|k|v and the attention output travel between items as tagged 8-byte granules, an item's weights / K-V tile are
+ * in flight while it waits for its input; vh_tune("dec_fused", 0) runs it as three launches with the same arithmetic, bit for
+ * bit), the router + gate|up GEMV of the two chosen experts, and the down projection.  Under tensor parallelism the two
+ * all-reduces of a layer are fused into these launches (producer rows push to the peers, the first blocks of the consumer sum in
+ * rank order: vh_tune("tp_fuse", 1), what ranks that own their device vote for) or run as one small kernel each.
  * Replaces the per-token forward of HF MixtralDecoderLayer x L as reached from vita/model/language_model/vita_mixtral.py:158-173. */
 int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream);
-/* schedule of the last decode call: -1 none yet, 0 one stream, five serial launches per layer (switched off, tensor-parallel engine,
- * or the side streams do not run concurrently here), 1 overlapped. */
-int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m);
+/* attention block of the last decode call: -1 none yet, 0 three launches (QKV, attention, O projection), 1 one fused launch. */
+int vh_mixtral_decode_schedule(const vh_mixtral_t* m);
 /* Device pointers into the engine state (for the host loop and the tests). */
 const int* vh_mixtral_tokens(const vh_mixtral_t* m);     /* int[max_new]: generated ids   */
 const int* vh_mixtral_counters(const vh_mixtral_t* m);   /* int[4]: {pos, n_generated, attn hand-off counter, device error flag (0 = ok)} */

@@ -105,3 +105,34 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
     if margins:
         out["margin"] = margin
     return out
+
+
+def forward_many(t, seed, embeds_list, n_layers=None, logits_from=None):
+    """forward() for SEVERAL independent sequences with every layer's weights generated once (a layer is 5.7 GB of fp32: the
+    generator, not the arithmetic, is what a short sequence pays for).  embeds_list: [S_i, H] arrays; logits_from: per-sequence
+    first row whose logits are wanted (default 0).  Returns a list of dict(logits [S_i - from_i, V], route [n_layers, S_i, 2])."""
+    n_layers = t.num_hidden_layers if n_layers is None else n_layers
+    n = len(embeds_list)
+    logits_from = [0] * n if logits_from is None else list(logits_from)
+    d, nq, nkv = t.head_dim, t.num_attention_heads, t.num_key_value_heads
+    bufs = LayerBuffers(t)
+    xs = [e.astype(F32) for e in embeds_list]
+    routes = [np.empty((n_layers, x.shape[0], 2), np.int32) for x in xs]
+    rope = [om.rope_cos_sin(np.arange(x.shape[0]), d, t.rope_theta) for x in xs]
+    for l in range(n_layers):
+        L = bufs.load(t, l, seed)
+        for i, x in enumerate(xs):
+            S = x.shape[0]
+            cos, sin = rope[i]
+            xn = om.rmsnorm(x, L["ln1"], t.rms_norm_eps)
+            q = (xn @ L["q"].T).astype(F32).reshape(S, nq, d).transpose(1, 0, 2)
+            k = (xn @ L["k"].T).astype(F32).reshape(S, nkv, d).transpose(1, 0, 2)
+            v = (xn @ L["v"].T).astype(F32).reshape(S, nkv, d).transpose(1, 0, 2)
+            q, k = om.apply_rope(q, cos, sin), om.apply_rope(k, cos, sin)
+            x = (x + om.attention(q, k, v, 0) @ L["o"].T).astype(F32)
+            y, idx, _ = om.moe(om.rmsnorm(x, L["ln2"], t.rms_norm_eps), L, t.num_experts_per_tok)
+            routes[i][l] = idx
+            xs[i] = (x + y).astype(F32)
+    norm = np.ones(t.hidden_size, F32)
+    lm = hashw.fill((t.vocab_size, t.hidden_size), hashw.tensor_seed("lm_head.weight", seed))
+    return [dict(logits=(om.rmsnorm(x[f:], norm, t.rms_norm_eps) @ lm.T).astype(F32), route=r) for x, f, r in zip(xs, logits_from, routes)]

@@ -126,9 +126,6 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
         assert eng.c.n_q_heads == t.num_attention_heads // world and eng.c.n_kv_heads == t.num_key_value_heads // world
         assert eng.c.inter == t.intermediate_size // world
         _lib.tune("tp_overlap", overlap)
-        # r05: world 2 with the one-kernel-per-exchange form also runs the OVERLAPPED decode schedule (on request under TP): the attention
-        # exchange then takes granules in and out on the O projection's side stream (vh_comm_allreduce_gran)
-        _lib.tune("dec_overlap", 1 if (world == 2 and fuse == 0) else -1)
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective=collective)
         rng = np.random.default_rng(5)
         ids = rng.integers(3, cfg.text.vocab_size, size=37).tolist()
@@ -141,7 +138,7 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
         assert eng.vocab_sharded and torch.equal(row0, lg[0]), "prefill() must return the full-vocabulary row under TP"
         ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n), comm_status(eng), eng.decode_exchange,
-                     eng.overlap_state())
+                     eng.decode_schedule())
         dist.barrier()
         eng.close()
     finally:
@@ -194,6 +191,7 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     for r in range(world):
         assert ret[r][1] == ref_ids, f"rank {r} tokens differ from the unsharded oracle: {ret[r][1]} vs {ref_ids}"
         assert np.array_equal(ret[r][2], ret[0][2]), f"rank {r} logits differ from rank 0's"
+        assert ret[r][6] == "fused-attention-block", ret[r][6]      # the schedule a tensor-parallel rank runs by default
     assert float(np.abs(ret[0][2] - ref_lg).max()) < 1e-3
 
 
@@ -222,12 +220,9 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
         assert ret[0][5] == ret[1][5] and ret[0][5] in ("fused", "kernel"), (ret[0][5], ret[1][5])
     else:
         assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
-    # r05: (overlap, fuse) = (1, 0) and (0, 0) also ask for the OVERLAPPED decode schedule under TP (the attention exchange takes granules
-    # in and out on the O projection's side stream: vh_comm_allreduce_gran); every other case keeps the serial schedule
-    if fuse == 0:
-        assert ret[0][6] == ret[1][6] == 1, f"overlapped decode schedule did not run under TP = 2: {ret[0][6]}, {ret[1][6]}"
-    else:
-        assert ret[0][6] == ret[1][6] == 0
+    # every case runs the default decode schedule of a tensor-parallel rank: the attention block as ONE launch (k_dec_ablk), with the
+    # exchange fused into it (consumer of the MoE exchange at its head, producer of the attention exchange in its O items) or as kernels
+    assert ret[0][6] == ret[1][6] == "fused-attention-block", (ret[0][6], ret[1][6])
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
     assert ret[0][1] == ret[1][1] == ref_ids
@@ -257,11 +252,11 @@ def test_tp2_engine_over_torch_allreduce_fallback(dev):
     assert np.abs(ret[0][2] - ref_lg).max() < 1e-3
 
 
-# ---- TP = 8 at the RELEASED shard shapes (VERDICT r03 missing #2) -------------------------------------------------------------
-REAL_TP_LAYERS, REAL_TP_S, REAL_TP_NEW = 2, 45, 6
+# ---- the RELEASED shard shapes at TP = 8 / 4 / 2 (VERDICT r03 missing #2, r05 missing #3) ------------------------------------------
+REAL_TP_S, REAL_TP_NEW = 45, 6
 
 
-def _tp_real_worker(rank, world, port, ret):
+def _tp_real_worker(rank, world, port, ret, layers=2):
     """one rank of the released geometry (H 4096, 32 / 8 heads at d = 128 -> 4 q heads + 1 KV head per rank, I 14336 -> 1792
     columns of every expert per rank, V 51760 -> 6470 vocabulary rows per rank), weights from the counter-based generator
     (this rank's slices only: vita_amd.checkpoint.synth_mixtral_device)."""
@@ -277,11 +272,12 @@ def _tp_real_worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cfg = VitaConfig()
-        cfg.text.num_hidden_layers = REAL_TP_LAYERS
+        cfg.text.num_hidden_layers = layers
         packed = synth_mixtral_device(cfg, dev, seed=0, rank=rank, world=world)
         eng = MixtralEngine(cfg, packed, dev, max_ctx=128, max_prefill=64, max_new=16, rank=rank, world=world, logit_rows=16)
         t = cfg.text
-        assert (eng.c.n_q_heads, eng.c.n_kv_heads, eng.c.inter, eng.c.vocab_n) == (4, 1, 1792, 6470)   # the released TP = 8 shard
+        # the released shard: TP = 8 -> (4, 1, 1792, 6470); TP = 4 -> (8, 2, 3584, 12940); TP = 2 -> (16, 4, 7168, 25880)
+        assert (eng.c.n_q_heads, eng.c.n_kv_heads, eng.c.inter, eng.c.vocab_n) == (32 // world, 8 // world, 14336 // world, 51760 // world)
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
         ids = np.random.default_rng(11).integers(3, t.vocab_size, size=REAL_TP_S).tolist()
         emb = packed["embed"][torch.as_tensor(ids, device=dev)].float()
@@ -290,7 +286,7 @@ def _tp_real_worker(rank, world, port, ret):
         torch.cuda.synchronize()
         lg = eng.logits_all[:REAL_TP_NEW].cpu()
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
-        ret[rank] = (name, eng.generated(), lg.numpy(), comm_status(eng), eng.decode_exchange)
+        ret[rank] = (name, eng.generated(), lg.numpy(), comm_status(eng), eng.decode_exchange, eng.decode_schedule())
         dist.barrier()
         eng.close()
     finally:
@@ -298,32 +294,37 @@ def _tp_real_worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(1500)
-def test_tp8_released_shard_shapes_match_oracle(dev):
-    """world 8 (processes on ONE GPU) at the released per-rank shapes, 2 layers, over the library's IPC all-reduce: greedy ids ==
-    the layer-streamed fp32 oracle's (oracle/stream.py, the unsharded arithmetic on the same generator's weights), logits within
-    1e-3, every rank bit-identical.  Reference partition: web_demo/vllm_tools/vllm_file/mixtral.py:441-470 (QKVParallelLinear /
-    RowParallelLinear head split), :375-414 (FusedMoE intermediate split), :939-951 (ParallelLMHead)."""
+@pytest.mark.parametrize("world,layers", [(8, 2), (4, 8), (2, 2)])
+def test_tp_released_shard_shapes_match_oracle(dev, world, layers):
+    """world 8 / 4 / 2 (processes on ONE GPU) at the released per-rank shapes (1792 / 3584 / 7168 expert columns, 4 + 1 / 8 + 2 /
+    16 + 4 heads: each width picks its own instantiations of the decode kernels — k_dec_ablk<2, NJO, RQ>, k_dec_down<NJ, 2> — and
+    its own tilings of the prefill GEMMs), 2 or 8 layers, over the library's IPC all-reduce, the decode steps on the default
+    schedule of a tensor-parallel rank (fused attention-block launch): greedy ids == the layer-streamed fp32 oracle's
+    (oracle/stream.py, the unsharded arithmetic on the same generator's weights), logits within 1e-3, every rank bit-identical.
+    TP = 2 is the degree both web demos deploy (web_demo/web_ability_demo.py:340-348), 2 x TP = 4 is BASELINE configs[4].
+    Reference partition: web_demo/vllm_tools/vllm_file/mixtral.py:441-470 (QKVParallelLinear / RowParallelLinear head split),
+    :375-414 (FusedMoE intermediate split), :939-951 (ParallelLMHead)."""
     import torch.multiprocessing as mp
     from oracle import stream
     from vita_amd.config import VitaConfig
-    world = 8
     ret = mp.Manager().dict()
-    mp.spawn(_tp_real_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_tp_real_worker, args=(world, _free_port(), ret, layers), nprocs=world, join=True)
     names = {ret[r][0] for r in range(world)}
     assert len(names) == 1, dict((r, ret[r][0]) for r in range(world))
-    _require_ipc(names, "released-shape TP = 8")
+    _require_ipc(names, f"released-shape TP = {world}")
     assert all(ret[r][3] == 0 for r in range(world)) and all(ret[r][4] == "kernel" for r in range(world))
+    assert all(ret[r][5] == "fused-attention-block" for r in range(world)), {r: ret[r][5] for r in range(world)}
     cfg = VitaConfig()
     t = cfg.text
     ids = np.random.default_rng(11).integers(3, t.vocab_size, size=REAL_TP_S).tolist()
     toks = ret[0][1]
     assert len(toks) == REAL_TP_NEW
     full = stream.embed_rows(t, ids + toks[:-1], 0)
-    ref = stream.forward(t, 0, full, n_layers=REAL_TP_LAYERS, logits_from=REAL_TP_S - 1)
+    ref = stream.forward(t, 0, full, n_layers=layers, logits_from=REAL_TP_S - 1)
     ref_ids = ref["logits"].argmax(-1).tolist()
     for r in range(world):
         assert ret[r][1] == ref_ids, f"rank {r}: {ret[r][1]} vs oracle {ref_ids}"
         assert np.array_equal(ret[r][2], ret[0][2]), f"rank {r} logits differ from rank 0's"
     err = float(np.abs(ret[0][2] - ref["logits"]).max())
-    print(f"TP = 8 released shard shapes: ids {toks} == oracle, max |logit diff| {err:.2e}")
+    print(f"TP = {world} released shard shapes, {layers} layers: ids {toks} == oracle, max |logit diff| {err:.2e}")
     assert err < 1e-3

@@ -120,28 +120,29 @@ def test_deterministic_and_batched_steps(full, dev):
     assert int(eng.counters[0].item()) == 70 + 15
 
 
-def test_overlapped_decode_schedule_equals_one_stream(full, dev):
-    """r05: the overlapped decode schedule (attention and O projection on side streams, qkv / attn_out / delta_attn as tagged
-    granules between kernels that are resident together) runs the SAME kernels on the same numbers as the one-stream schedule:
-    ids and every logit bit-identical, at a context that crosses several 64-key tiles, repeatedly (tags advance, buffers are
-    reused), and the probe must have found concurrent streams on this box — otherwise nothing was tested."""
+def test_fused_attention_block_equals_three_launches(full, dev):
+    """r06: the attention block of a decode layer as ONE launch (k_dec_ablk: fused-QKV rows, attention tiles and O-projection rows as
+    work items with granule hand-offs — the default) runs the SAME arithmetic as its three separate kernels
+    (vh_tune("dec_fused", 0)): ids and every logit bit-identical, at a context that crosses several 64-key tiles, repeatedly
+    (tags advance, granule buffers are reused), no device-side time-out.  (Device against itself: the three-launch form is what
+    tests/test_realgeom_gpu.py and tests/test_ops_gpu.py anchor to the fp32 oracle.)"""
     from vita_amd import _lib
     cfg, packed, eng = full
     rng = np.random.default_rng(4)
     emb = _emb(packed, rng.integers(3, cfg.text.vocab_size, size=150).tolist(), dev)
     runs = []
     try:
-        for ov in (1, 0, 1, 1):
-            _lib.tune("dec_overlap", ov)
+        for fused in (1, 0, -1, 1):
+            _lib.tune("dec_fused", fused)
             eng.prefill(emb)
             eng.decode(3)
             eng.decode(1)
             eng.decode(20)
             torch.cuda.synchronize()
-            runs.append((eng.generated(), eng.logits_all[:25].clone(), eng.overlap_state()))
+            runs.append((eng.generated(), eng.logits_all[:25].clone(), eng.decode_schedule()))
     finally:
-        _lib.tune("dec_overlap", -1)
-    assert [r[2] for r in runs] == [1, 0, 1, 1], f"schedules that ran: {[r[2] for r in runs]} (1 missing: the side streams are not concurrent on this box?)"
+        _lib.tune("dec_fused", -1)
+    assert [r[2] for r in runs] == ["fused-attention-block", "three-launches", "fused-attention-block", "fused-attention-block"], [r[2] for r in runs]
     assert len(runs[0][0]) == 25
     for toks, lg, _ in runs[1:]:
         assert toks == runs[0][0]

@@ -72,19 +72,20 @@ def test_tiny_decode_batch_call(dev):
     _run(dev, VitaConfig.tiny(), S=17, n_new=24, chunked=True)
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
-def test_decode_schedules_vs_oracle(dev, overlap):
-    """both decode schedules against the oracle on the GQA 4 : 1 / 8-expert geometry: 1 = the overlapped schedule (attention and O
-    projection on side streams, tagged granules between them — the default), 0 = one stream (the schedule of r01-r04)."""
+@pytest.mark.parametrize("fused", [0, 1])
+def test_decode_schedules_vs_oracle(dev, fused):
+    """both forms of a decode layer's attention block against the oracle on the GQA 4 : 1 / 8-expert geometry: 1 = ONE launch
+    (k_dec_ablk: fused-QKV rows, attention tiles and O rows as work items, tagged granules between them — the default), 0 = three
+    launches (the kernels of r01-r05)."""
     from vita_amd import _lib
     cfg = VitaConfig.tiny()
     cfg.text = TextConfig(hidden_size=512, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
                           intermediate_size=1024, num_local_experts=8, vocab_size=2000)
-    _lib.tune("dec_overlap", overlap)
+    _lib.tune("dec_fused", fused)
     try:
         _run(dev, cfg, S=130, n_new=12, seed=4, chunked=True)
     finally:
-        _lib.tune("dec_overlap", -1)
+        _lib.tune("dec_fused", -1)
 
 
 def test_group4_experts8(dev):

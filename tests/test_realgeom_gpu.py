@@ -146,10 +146,11 @@ def _free_port():
 
 
 def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
-    """one rank of the released TP = 8 partition (4 q heads + 1 KV head, 1792 columns of every expert, 6470 vocabulary rows;
-    web_demo/vllm_tools/vllm_file/mixtral.py:375-414,441-476,939-951) running the WHOLE omni request: replicated encoders +
-    projector, splice, sharded prefill (64 bulk all-reduces of 9 MB) and greedy decode (65 exchanges per token) over the
-    library's IPC all-reduce, eight processes on one GPU."""
+    """one rank of the released partition at `world` ranks (TP = 8: 4 q heads + 1 KV head, 1792 columns of every expert, 6470
+    vocabulary rows; TP = 2, the degree both web demos run — web_demo/web_ability_demo.py:340-348 —: 16 q + 4 KV heads, 7168
+    columns, 25880 rows; web_demo/vllm_tools/vllm_file/mixtral.py:375-414,441-476,939-951) running the WHOLE omni request:
+    replicated encoders + projector, splice, sharded prefill (64 bulk all-reduces of 9 MB) and greedy decode (65 exchanges per
+    token) over the library's IPC all-reduce, `world` processes on one GPU."""
     import torch.distributed as dist
     from vita_amd.model.vita_mixtral import VITAMixtralForCausalLM
     from vita_amd.parallel import setup_tensor_parallel
@@ -171,7 +172,8 @@ def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
         model = VITAMixtralForCausalLM(cfg, sd_enc, device=dev, packed_llm=packed, max_new_tokens=TP8_NEW + 8, max_prefill=640,
                                        rank=rank, world=world, keep_scores=True)
         eng = model.engine
-        assert (eng.c.n_q_heads, eng.c.n_kv_heads, eng.c.inter, eng.c.vocab_n) == (4, 1, 1792, 6470)
+        assert (eng.c.n_q_heads, eng.c.n_kv_heads, eng.c.inter) == (32 // world, 8 // world, 14336 // world)
+        assert eng.c.vocab_n in (51760 // world, 51760 // world + 1)
         t_m = lap()
         name = setup_tensor_parallel(eng, rank, world, dev, backend="gloo", collective="ipc")
         t_tp = lap()
@@ -191,13 +193,13 @@ def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
         torch.cuda.synchronize()
         t_dec = lap()
         if rank == 0:
-            print(f"[realgeom] TP = 8 rank 0: weights {t_w:.1f}s, model {t_m:.1f}s, collective bring-up {t_tp:.1f}s, encoders + splice "
+            print(f"[realgeom] TP = {world} rank 0: weights {t_w:.1f}s, model {t_m:.1f}s, collective bring-up {t_tp:.1f}s, encoders + splice "
                   f"{t_enc:.1f}s, prefill {t_pf:.1f}s, {TP8_NEW - 1} decode steps {t_dec:.1f}s", flush=True)
         lg = eng.logits_all[:TP8_NEW].cpu()
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
         c = getattr(eng, "_comm", None)
         ret[rank] = (name, eng.generated(), lg.numpy() if rank == 0 else None, c.status() if c is not None else None,
-                     eng.decode_exchange, int(emb.shape[1]), lg.numpy().tobytes() if rank > 0 else None)
+                     eng.decode_exchange, int(emb.shape[1]), lg.numpy().tobytes() if rank > 0 else None, eng.decode_schedule())
         dist.barrier()
         eng.close()
     finally:
@@ -205,22 +207,24 @@ def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
 
 
 @pytest.mark.timeout(1500)
-def test_tp8_full_depth_omni_matches_oracle(run, oracle_ref, tmp_path):
-    """BASELINE configs[3] (VERDICT r04 #1a): world 8 — eight engine processes on ONE GPU — at the released shard shapes, ALL
-    layers, the omni request of make_request() (encoders + splice + prefill S = 552 + 8 greedy steps) over the IPC all-reduce:
-    64 all-reduces per forward of re-ordered fp32 sums in front of a discontinuous router.  Greedy ids == the streamed fp32
+@pytest.mark.parametrize("world", [8, 2])
+def test_tp_full_depth_omni_matches_oracle(run, oracle_ref, tmp_path, world):
+    """BASELINE configs[3] (world 8) and the reference's OWN deployment degree (world 2: web_demo/web_ability_demo.py:340-348,
+    web_demo/web_interactive_demo.py:942-996; 2 x TP = 4 is configs[4]) — `world` engine processes on ONE GPU — at the released
+    shard shapes, ALL layers, the omni request of make_request() (encoders + splice + prefill S = 552 + 8 greedy steps) over the
+    IPC all-reduce: 64 all-reduces per forward of re-ordered fp32 sums in front of a discontinuous router, the decode steps on
+    the schedule a tensor-parallel rank runs by default (fused attention-block launch).  Greedy ids == the streamed fp32
     oracle's and logits within 1e-3 (the oracle pass is the one test_backbone_32_layers_prefill_and_greedy paid for: same
     request, and the tokens must agree), every rank bit-identical, no spin time-out."""
     import torch.multiprocessing as mp
     cfg = run["cfg"]
     L = cfg.text.num_hidden_layers
-    world = 8
     t0 = time.time()
     enc_path = str(tmp_path / "encoders.pt")
     torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in run["sd_enc"].items()}, enc_path)
     ret = mp.Manager().dict()
     mp.spawn(_tp8_omni_worker, args=(world, _free_port(), L, enc_path, ret), nprocs=world, join=True)
-    print(f"[realgeom] TP = 8 ranks done in {time.time() - t0:.1f}s")
+    print(f"[realgeom] TP = {world} ranks done in {time.time() - t0:.1f}s")
     names = {ret[r][0] for r in range(world)}
     assert len(names) == 1, {r: ret[r][0] for r in range(world)}
     if names != {"ipc"}:
@@ -238,7 +242,8 @@ def test_tp8_full_depth_omni_matches_oracle(run, oracle_ref, tmp_path):
     ref_lg = oracle_ref["logits"][:TP8_NEW]
     ref_ids = ref_lg.argmax(-1).tolist()
     err = float(np.abs(lg0 - ref_lg).max())
-    print(f"TP = 8, {L} layers, S = 552 omni request: ids {toks}, oracle {ref_ids}, TP = 1 device {run['toks'][:TP8_NEW]}, "
-          f"max |logit diff| {err:.2e}, exchange form {ret[0][4]}")
+    print(f"TP = {world}, {L} layers, S = 552 omni request: ids {toks}, oracle {ref_ids}, TP = 1 device {run['toks'][:TP8_NEW]}, "
+          f"max |logit diff| {err:.2e}, exchange form {ret[0][4]}, decode schedule {ret[0][7]}")
+    assert all(ret[r][7] == "fused-attention-block" for r in range(world)), {r: ret[r][7] for r in range(world)}
     assert toks == ref_ids
     assert err < 1e-3

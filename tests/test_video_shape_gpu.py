@@ -5,10 +5,13 @@ duplex demo feeds the same shape, web_demo/web_interactive_demo.py:284-366) at t
   8 frames of 448 x 448 -> ONE batch of n = 8 tiles through the 24-layer InternViT + projector: 8 x 256 image tokens
   10 s of audio (998 fbank frames) -> 24-layer Whale + adapter: 124 audio tokens
   S = 1 + 139 + 2048 + 32 + 124 = 2344 prompt rows (experts see ~586 rows each: four m-tiles per expert in the streaming GEMM,
-  the longest prefill any test runs) through VITA_VIDEO_LAYERS backbone layers (default 8), 6 greedy steps.
-  (r05 tried 16 layers by default: ONE of the 37 504 router decisions — row 2272 at layer 10 — sits on a tie of the oracle's own 2nd / 3rd expert
-  logits; the device takes the other expert, and the 71 rows behind it that attend to it move by up to 1.7e-2 at layer 15, above the hidden-state
-  bar.  The full-depth corners of the suite are the S = 552 request (32 layers, also under TP = 8) and the reference's assets (S = 1496, 32 layers).)
+  the longest prefill any test runs) through VITA_VIDEO_LAYERS backbone layers (default 16; the 32-layer run of r06 is
+  profiles/r06_video_shape_parity_32.txt), 6 greedy steps.
+  ONE of the 37 504 router decisions of the first 16 layers — row 2272 at layer 10 — sits on a tie of the oracle's own 2nd / 3rd expert logits
+  (margin below fp32 re-association noise); the device takes the other expert there, that row's MoE output differs from layer 10 on, and from
+  layer 11 on every LATER row (they attend to its K / V) moves with it — by up to 1.7e-2 at layer 15.  The check below names the tie, requires the
+  oracle's margin to be one, and excuses exactly those rows from the hidden-state bar (it used to excuse the tied row alone); logits
+  of the last row and the greedy ids keep the north-star bar whatever happened upstream.
 
 against the fp64 encoder restatements and the layer-streamed fp32 oracle: encoder outputs, spliced embeddings, every router
 decision, hidden states, logits < 1e-3, ids ==.  (n = 5 tiles: tests/test_assets_gpu.py; n = 1: tests/test_realgeom_gpu.py.)"""
@@ -27,7 +30,7 @@ from vita_amd.host.synthetic import make_request
 
 pytestmark = pytest.mark.gpu
 T_NEW, SEED, FRAMES = 6, 0, 8
-LAYERS = int(os.environ.get("VITA_VIDEO_LAYERS", "8"))
+LAYERS = int(os.environ.get("VITA_VIDEO_LAYERS", "16"))
 
 
 @pytest.mark.timeout(1800)
@@ -85,21 +88,31 @@ def test_eight_frame_video_prompt_matches_oracle(dev):
     # margin between its 2nd and 3rd expert is a tie at fp32 re-association noise (< TIE): the device then legitimately follows the
     # other expert and that row's hidden state goes its own way (r05: at 16 layers one row of 37 504 decisions, row 2272 at layer 10).
     # Every other decision must be the oracle's, and the last-row logits / greedy ids keep the north-star bar.
-    TIE, MAX_TIED_ROWS = 3e-4, 4
+    TIE, MAX_TIES = 3e-4, 4
     diff = (np.sort(route, -1) != np.sort(ref["route"][:, :S], -1)).any(-1)             # [L, S]
-    tied_rows = np.flatnonzero(diff.any(0))
-    print(f"router top-2 sets: {route.shape[0] * S} decisions, {int(diff.sum())} differ in {len(tied_rows)} row(s)")
-    for r in tied_rows:
-        l0 = int(np.argmax(diff[:, r]))
-        mg = float(ref["margin"][l0, r])
-        print(f"  row {int(r)}: first differs at layer {l0}, oracle margin (2nd - 3rd expert logit) {mg:.2e}")
-        assert mg < TIE, f"row {int(r)} layer {l0}: the device took another expert where the oracle's margin is {mg:.2e} (not a tie)"
-    assert len(tied_rows) <= MAX_TIED_ROWS and S - 1 not in tied_rows
-    keep = np.ones(S, bool)
-    keep[tied_rows] = False
+    # a row that comes AFTER a tied row attends to it from the next layer on: its later decisions may legitimately differ too.  Only
+    # decisions that are not downstream of an earlier tie count as independent events; each must be a tie of the oracle itself.
+    ties = []                                                                          # (layer, row), in layer order
+    for l0 in range(diff.shape[0]):
+        for r in np.flatnonzero(diff[l0]):
+            downstream = any((lt < l0 and r >= rt) or (lt <= l0 and r == rt) for lt, rt in ties)
+            if downstream:
+                continue
+            mg = float(ref["margin"][l0, r])
+            print(f"  row {int(r)}: decision differs at layer {l0}, oracle margin (2nd - 3rd expert logit) {mg:.2e}")
+            assert mg < TIE, f"row {int(r)} layer {l0}: the device took another expert where the oracle's margin is {mg:.2e} (not a tie)"
+            ties.append((l0, int(r)))
+    print(f"router top-2 sets: {route.shape[0] * S} decisions, {int(diff.sum())} differ, {len(ties)} independent tie(s) {ties}")
+    assert len(ties) <= MAX_TIES
     for l in sorted(d_hid):
+        keep = np.ones(S, bool)
+        for lt, rt in ties:
+            if l >= lt:
+                keep[rt] = False              # the tied row itself: its MoE output of layer lt differs
+            if l > lt:
+                keep[rt:] = False             # every later row has attended to it since layer lt + 1
         h_ref = ref["hidden"][l][:S]
-        assert_close(f"hidden after layer {l} ({int(keep.sum())} rows)", d_hid[l][keep], h_ref[keep], atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
+        assert_close(f"hidden after layer {l} ({int(keep.sum())} of {S} rows)", d_hid[l][keep], h_ref[keep], atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
     ref_ids = ref["logits"].argmax(-1).tolist()
     print("device ids", toks, "oracle ids", ref_ids)
     print(report(f"logits of the {T_NEW} steps", logits, ref["logits"]))

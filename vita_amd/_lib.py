@@ -145,6 +145,7 @@ SIGNATURES = {
     "vh_rccl_unique_id": (c_int, [c_void_p]),
     "vh_mixtral_init_rccl": (c_int, [c_void_p, c_void_p]),
     "vh_comm_create": (c_void_p, [c_int, c_int, c_size_t, c_void_p]),
+    "vh_comm_create_loopback": (c_void_p, [c_int, c_int, c_size_t]),
     "vh_comm_connect": (c_int, [c_void_p, c_void_p]),
     "vh_comm_capacity": (c_size_t, [c_void_p]),
     "vh_comm_allreduce": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
@@ -162,7 +163,7 @@ SIGNATURES = {
     "vh_mixtral_counters": (c_void_p, [c_void_p]),
     "vh_mixtral_logits": (c_void_p, [c_void_p]),
     "vh_mixtral_reset": (c_int, [c_void_p, c_void_p]),
-    "vh_mixtral_decode_overlap_state": (c_int, [c_void_p]),
+    "vh_mixtral_decode_schedule": (c_int, [c_void_p]),
     "vh_mixtral_seq_alloc": (c_int, [c_void_p]),
     "vh_mixtral_seq_free": (c_int, [c_void_p, c_int]),
     "vh_mixtral_seq_prefill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

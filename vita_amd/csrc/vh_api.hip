@@ -56,7 +56,8 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }
     if (!strcmp(key, "tp_fuse")) { g_tuning.tp_fuse = value; return VH_OK; }
     if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
-    if (!strcmp(key, "dec_overlap")) { g_tuning.dec_overlap = value; return VH_OK; }
+    if (!strcmp(key, "comm_ranks_per_device")) { g_tuning.comm_ranks_per_device = value; return VH_OK; }
+    if (!strcmp(key, "dec_fused")) { g_tuning.dec_fused = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -414,10 +415,6 @@ struct vh_mixtral {
         counters = cv.take<int>(4);  // {pos, n_generated, attn_done (monotonic), device error flag}
         g_qkv = cv.take<unsigned long long>(nqkv);
         g_attn = cv.take<unsigned long long>(vh_gran_gemv_len(nq * hd));
-        g_dattn = cv.take<unsigned long long>(vh_gran_gemv_len(H));
-        g_part = cv.take<unsigned long long>(vh_gran_gemv_len(H));
-        g_gate = cv.take<unsigned long long>(2);
-        probe = cv.take<int>(4);
         // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
         part_o = cv.take<float>((size_t)nq * max_splits * hd);
@@ -450,6 +447,7 @@ struct vh_mixtral {
         return al(cv.off, 256);
     }
     int hist_rows() const { return c.logit_rows > 1 ? c.logit_rows : 1; }
+    int cand_world() const { return c.tp_world > 1 ? c.tp_world : 1; }   // slots of the vocab-sharded head's candidate vector (loop-back: this rank's only)
     void derive() {
         nq = c.n_q_heads; nkv = c.n_kv_heads; hd = c.head_dim; H = c.hidden; I = c.inter; E = c.n_experts;
         V = c.vocab; nqkv = (nq + 2 * nkv) * hd;
@@ -460,17 +458,12 @@ struct vh_mixtral {
         if (lm_grid > 1024) lm_grid = 1024;
         if (lm_grid < c.tp_world) lm_grid = c.tp_world;   // blk_val / blk_idx also hold the gathered candidates
     }
-    // ---- overlapped decode schedule: attention on sA, O projection on sC, the rest on the caller's stream ----
-    hipStream_t sA = nullptr, sC = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_joinA = nullptr, ev_joinC = nullptr;
-    unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_dattn = nullptr, *g_part = nullptr;   // granule vectors (VhGranVec)
-    unsigned long long* g_gate = nullptr;            // "this layer's fused-QKV kernel has started" (opens the side streams' gate kernels)
-    int* probe = nullptr;                            // 4 words of the stream-concurrency probe
+    // ---- fused attention-block launch (k_dec_ablk): q|k|v and the attention output travel between its work items as
+    // tagged granules; a tag is used once per (step, layer, vector)
+    unsigned long long *g_qkv = nullptr, *g_attn = nullptr;   // granule vectors (VhGranVec)
     unsigned gran_epoch = 0;                         // last granule tag handed out (0 = never written)
-    int streams_state = -1;                          // side streams: -1 not probed yet, 0 they do not run concurrently here, 1 verified
-    int overlap_state = -1;                          // schedule of the last decode call: -1 none yet, 0 one stream, 1 overlapped
+    int schedule_state = -1;                         // attention block of the last decode call: -1 none yet, 0 three launches, 1 one fused launch
     unsigned next_tag() { if (++gran_epoch == 0) ++gran_epoch; return gran_epoch; }
-    int ensure_overlap_streams(hipStream_t st);
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
     hipStream_t cs = nullptr;    // communication stream of the overlapped tensor-parallel prefill
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // half computed / half reduced
@@ -484,8 +477,10 @@ struct vh_mixtral {
                 hipEventCreateWithFlags(&ev_r[i], hipEventDisableTiming) != hipSuccess) return -1;
         return 0;
     }
+    // exchanges run: a tensor-parallel rank, a test that forces the hook, or a loop-back communicator (one rank playing them all)
+    bool exchanges() const { return c.tp_world > 1 || vh_tuning()->force_allreduce || (comm && vh_comm_is_loopback(comm)); }
     int allreduce(float* buf, long count, hipStream_t st) {
-        if (c.tp_world <= 1 && !vh_tuning()->force_allreduce) return 0;
+        if (!exchanges()) return 0;
         if (comm && (size_t)count <= vh_comm_capacity(comm)) return vh_comm_allreduce(comm, buf, count, st) == VH_OK ? 0 : -1;
         if (!ar_fn) return -1;
         return ar_fn(ar_user, buf, count, st);
@@ -559,9 +554,6 @@ void vh_mixtral_destroy(vh_mixtral_t* m) {
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (m->ev_c[i]) (void)hipEventDestroy(m->ev_c[i]); if (m->ev_r[i]) (void)hipEventDestroy(m->ev_r[i]); }
     if (m->cs) (void)hipStreamDestroy(m->cs);
-    for (hipEvent_t e : {m->ev_fork, m->ev_joinA, m->ev_joinC}) if (e) (void)hipEventDestroy(e);
-    if (m->sA) (void)hipStreamDestroy(m->sA);
-    if (m->sC) (void)hipStreamDestroy(m->sC);
     if (m->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->rccl_comm);
     delete m;
 }
@@ -1033,123 +1025,51 @@ int vh_mixtral_prefill(vh_mixtral_t* m, const float* embeds, int Sn, int pos0, f
 // the full row is assembled by an all-reduce of the zero-filled slices.
 static int head_and_select(vh_mixtral* m, hipStream_t st, const float* x_in, const float* delta, int mode, int set_pos,
                            const VhXchg* cx) {
-    const bool sharded = m->c.vocab_n > 0 && m->c.tp_world > 1;
+    const bool sharded = m->c.vocab_n > 0 && (m->c.tp_world > 1 || (m->comm && vh_comm_is_loopback(m->comm)));
     VH_TRY(vhk_dec_lmhead(st, x_in, delta, m->final_norm, m->c.rms_eps, m->lm_head, m->Vn, m->H, m->logits, m->blk_val,
                           m->blk_idx, m->lm_grid, m->counters + 1, m->hist_rows(), m->v0, m->V, cx), "lm_head");
     int nblk = m->lm_grid;
     if (sharded) {
-        VH_TRY(vhk_dec_cand(st, m->blk_val, m->blk_idx, m->lm_grid, m->cand, m->c.tp_rank, m->c.tp_world), "candidates");
-        if (m->allreduce(m->cand, 2L * m->c.tp_world, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
-        VH_TRY(vhk_dec_cand_unpack(st, m->cand, m->c.tp_world, m->blk_val, m->blk_idx), "candidates");
-        nblk = m->c.tp_world;
+        const int cw = m->cand_world();
+        VH_TRY(vhk_dec_cand(st, m->blk_val, m->blk_idx, m->lm_grid, m->cand, m->c.tp_rank, cw), "candidates");
+        if (m->allreduce(m->cand, 2L * cw, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
+        VH_TRY(vhk_dec_cand_unpack(st, m->cand, cw, m->blk_val, m->blk_idx), "candidates");
+        nblk = cw;
     }
     VH_TRY(vhk_dec_select(st, m->blk_val, m->blk_idx, nblk, m->embed, m->H, m->V, m->xa, m->counters, m->counters + 1,
                           m->out_tokens, m->c.max_new, mode, set_pos), "select");
     return VH_OK;
 }
 
-// ---- overlapped decode schedule ----------------------------------------------------------------------------------------------
-// A batch-1 decode layer is five dependent launches; QKV (50 MB), attention and the O projection (34 MB) are short enough that the
-// head and tail of each launch — dispatch, first-byte latency of the weight / K-V loads, prologue, drain, the boundary — cost as
-// much as their bytes (r04: 28.5 us per layer for 84 MB that the stream moves in 14).  The schedule below keeps the five kernels
-// and takes the attention and the O projection OFF the stream order: they run on two side streams, each behind a one-wave GATE
-// kernel that ends when this layer's fused-QKV kernel has started, so both are resident — K / V tiles and O weights in flight or
-// landed, prologues done — while QKV still streams; gate|up (caller's stream, right behind QKV) likewise has its router weights in
-// registers when the O projection finishes.  The data dependency travels with the data: qkv, attn_out and delta_attn are tagged
-// granules (VhGranVec) that the consumer waves poll.  Everything else (xb, route, hbuf, delta_moe, xa, the KV cache) stays plain
-// memory ordered by a stream.  What was measured on the way (profiles/EXPERIMENTS.md r05): cross-stream EVENTS release their
-// waiter 7-12 us late and cost 4-5 us per marker / completion event on the main stream (199 against 210 tok/s); launches
-// without the barrier bit (hipExtAnyOrderLaunch) are not honoured on gfx950 (they serialise); a run-time granule switch inside
-// the serial kernels doubled their registers (174 tok/s).
-// Deadlock freedom: a waiting kernel never holds what its producer needs — every producer is enqueued before its consumers and is
-// resident when they start (the gates open after QKV's blocks were dispatched); attention is <= nkv * splits blocks, the O
-// projection 2 and gate|up 1.5 blocks per CU of 120 / 128 registers against 512 per SIMD; every wait is bounded (error word,
-// counters[3]).  Tensor parallel (IPC transport, one kernel per exchange): the attention exchange takes granules in and out and
-// rides the O projection's stream (vh_comm_allreduce_gran); the MoE exchange stays on the main stream between the down projection and
-// the next QKV.  The fused form (VhXchg), RCCL and the callback collective keep the serial schedule.
-int vh_mixtral::ensure_overlap_streams(hipStream_t st) {
-    if (streams_state >= 0) return streams_state;
-    streams_state = 0;
-    if (hipStreamCreateWithFlags(&sA, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sC, hipStreamNonBlocking) != hipSuccess)
-        return 0;
-    auto mk = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    if (!mk(&ev_fork) || !mk(&ev_joinA) || !mk(&ev_joinC)) return 0;
-    // probe every PAIR of the three streams (HIP may multiplex streams onto fewer hardware queues: two streams of one queue run
-    // in enqueue order, and a consumer enqueued first would wait for a producer queued behind it): two kernels, one per stream,
-    // each raises its flag and waits (bounded) for the other's
-    hipStream_t pair[3][2] = {{st, sA}, {st, sC}, {sA, sC}};
-    for (int i = 0; i < 3; ++i) {
-        if (hipMemsetAsync(probe, 0, 4 * sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
-        vhk_dec_probe(pair[i][0], probe + 0, probe + 1, probe + 2);
-        vhk_dec_probe(pair[i][1], probe + 1, probe + 0, probe + 3);
-        int h[4] = {0, 0, 0, 0};
-        if (hipStreamSynchronize(pair[i][0]) != hipSuccess || hipStreamSynchronize(pair[i][1]) != hipSuccess ||
-            hipMemcpy(h, probe, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
-        if (h[2] != 1 || h[3] != 1) return 0;
-    }
-    streams_state = 1;
-    return streams_state;
+int vh_mixtral_decode_schedule(const vh_mixtral_t* m) { return m ? m->schedule_state : -1; }
+
+// Attention block of a decode layer as one fused launch (k_dec_ablk) or as three (QKV, attention, O projection): vh_tune("dec_fused").
+static bool fused_wanted(const vh_mixtral* m) {
+    const int want = vh_tuning()->dec_fused;        // -1 auto, 0 never, 1 wherever the kernel has an instantiation
+    if (want == 0) return false;
+    return vhk_dec_ablk_supported(m->H, m->nq, m->nkv) != 0;
 }
-static bool overlap_wanted(const vh_mixtral* m) {
-    const int want = vh_tuning()->dec_overlap;       // -1 auto, 0 never, 1 wherever the schedule is available
-    if (want == 0 || vh_tuning()->force_allreduce || m->nq * m->hd > 4096 || m->H > 4096) return false;
-    // auto: a single-rank engine whose expert slices have <= 7168 columns, where it measured a gain (one rank's shard of a TP = 2 / 4 / 8
-    // layer, collective skipped: 2.6 / 4.7 / 6.9 % faster, profiles/r05_emulated_tp*.json — the five launch ramps are most of such a layer).
-    // One rank's layer of the released model (I = 14336: 789 MB, 144 us) is a tie (211.5 against 211.4 tok/s,
-    // profiles/r05_bench_driver_line*.json): its two expert kernels already run at the copy ceiling, and the serial schedule keeps the
-    // dominant kernel's time free of in-kernel waits
-    if (want < 0 && (m->c.tp_world > 1 || m->I > 7168)) return false;
-    if (m->c.tp_world <= 1) return true;
-    // (tensor parallel: only on request.  The path is tested at world 2 on one device with small kernels; two full-size ranks SHARING a
-    // device starve each other — waiting gate|up blocks of both ranks fill the registers the other rank's O projection needs, r05 call 10
-    // — and a node where each rank owns its device was never available to try it)
-    // tensor parallel: with the library's IPC transport in its one-kernel-per-exchange form the attention exchange takes granules in
-    // and out (vh_comm_allreduce_gran) and rides the O projection's side stream; every other collective keeps the serial schedule
-    // Ranks SHARING one device (tests) keep it only at world 2: the waiting gate|up blocks of eight ranks (8 x 384 x 4 waves) would not
-    // even fit the chip, and the O projection of a rank that lags would find no slot while the others spin on its partial.
-    return m->comm != nullptr && vh_tuning()->tp_fuse == 0 && (size_t)m->H <= vh_comm_capacity(m->comm) && m->H <= 32768 &&
-           (!vh_comm_ranks_share_device(m->comm) || m->c.tp_world <= 2);
-}
-// the side streams start behind everything already queued on st (prefill: KV cache, residual stream) ...
-static bool overlap_begin(vh_mixtral* m, hipStream_t st) {
-    m->overlap_state = 0;
-    if (!overlap_wanted(m) || m->ensure_overlap_streams(st) != 1) return false;
-    if (hipEventRecord(m->ev_fork, st) != hipSuccess || hipStreamWaitEvent(m->sA, m->ev_fork, 0) != hipSuccess ||
-        hipStreamWaitEvent(m->sC, m->ev_fork, 0) != hipSuccess) {
-        (void)hipGetLastError();                     // nothing of the step is on a side stream yet: the serial schedule runs
-        return false;
-    }
-    m->overlap_state = 1;
-    return true;
-}
-// ... and st ends behind them: a caller that synchronises st has the whole step.  If the join cannot be enqueued the side streams are
-// drained here (the caller's stream would otherwise run ahead of them) and the engine refuses further steps.
-static int overlap_end(vh_mixtral* m, hipStream_t st) {
-    if (hipEventRecord(m->ev_joinA, m->sA) == hipSuccess && hipEventRecord(m->ev_joinC, m->sC) == hipSuccess &&
-        hipStreamWaitEvent(st, m->ev_joinA, 0) == hipSuccess && hipStreamWaitEvent(st, m->ev_joinC, 0) == hipSuccess)
-        return VH_OK;
-    const hipError_t e = hipGetLastError();
-    (void)hipStreamSynchronize(m->sA);
-    (void)hipStreamSynchronize(m->sC);
-    m->poisoned = 1;
-    return fail(VH_E_HIP, "decode: joining the side streams failed: %s", hipGetErrorString(e));
-}
-int vh_mixtral_decode_overlap_state(const vh_mixtral_t* m) { return m ? m->overlap_state : -1; }
 
 // One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
 // mirror of the position (host_pos) is advanced by the CALLER only after the step was enqueued without error.
-// ov: the overlapped schedule (the caller ran overlap_begin and runs overlap_end after its last step).
-static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
+// Three launches per layer: the attention block (k_dec_ablk: fused QKV -> attention -> O projection; three launches with
+// vh_tune("dec_fused", 0)), gate|up, down.
+// Tensor parallel over the library's IPC transport: the two all-reduces of a layer are either FUSED into the kernels around
+// them (VhXchg, vh_kernels.h: the O-projection items / the MoE down projection push their partial outputs straight into the
+// peers' receive slots, the first blocks of the next launch — gate|up, the next layer's attention block, the LM head — sum the
+// slots in rank order and every block of it waits for that sum behind its own weight loads: "all-reduce over xGMI overlapped
+// with the expert GEMMs", web_demo/vllm_tools/vllm_file/mixtral.py:405-414,470-476; no launch per exchange) — the form the ranks
+// vote for when each owns its device — or one small all-reduce kernel per exchange (ranks sharing a device: a waiting consumer
+// grid would hold the CUs a peer's producer needs).
+static int decode_one_step(vh_mixtral* m, hipStream_t st) {
     const int H = m->H, I = m->I, E = m->E, nq = m->nq, nkv = m->nkv, hd = m->hd;
     const float scale = 1.0f / sqrtf((float)hd);
     const float eps = m->c.rms_eps;
-    // Tensor parallel over the library's IPC transport: the two all-reduces of a layer are FUSED into the kernels around
-    // them (VhXchg, vh_kernels.h): the O projection / MoE down projection push their partial outputs straight into the
-    // peers' receive slots, the first blocks of the next kernel (gate|up, next layer's QKV, LM head) sum the slots and every
-    // block of it waits for that sum behind its own weight loads — "all-reduce over xGMI overlapped with the expert GEMMs"
-    // (web_demo/vllm_tools/vllm_file/mixtral.py:405-414,470-476), 65 kernel launches per token fewer than r02.
-    const bool fuse = m->comm != nullptr && m->c.tp_world > 1 && vh_tuning()->tp_fuse != 0 && (H % 2) == 0 &&
+    const bool fuse = m->comm != nullptr && m->exchanges() && vh_tuning()->tp_fuse != 0 && (H % 2) == 0 &&
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
+    const bool fused_attn = fused_wanted(m);
+    m->schedule_state = fused_attn ? 1 : 0;
+    int* err = m->counters + 3;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
     bool have_xm = false;
     for (int l = 0; l < m->c.n_layers; ++l) {
@@ -1157,61 +1077,37 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st, bool ov) {
         float* kc = m->kcache + (size_t)l * nkv * m->c.max_ctx * hd;
         float* vc = m->vcache + (size_t)l * nkv * m->c.max_ctx * hd;
         const bool prof = m->prof_stride > 0 && (l % m->prof_stride) == 0 && m->prof_used + 2 <= m->prof_ev.size();
-        if (ov) {
-            int* err = m->counters + 3;
-            const bool tp = m->c.tp_world > 1;
-            const VhGranVec gq{m->g_qkv, m->next_tag(), err}, ga{m->g_attn, m->next_tag(), err}, gd{m->g_dattn, m->next_tag(), err},
-                            gp{m->g_part, m->next_tag(), err};     // gp: this rank's PARTIAL attention delta (tensor parallel only)
-            // Gates (one wave each; they only time the launches, the data dependencies are the granule tags):
-            //   attention   (sA): QKV(l) has STARTED — its K / V tiles are 5 MB, they load under the QKV stream;
-            //   O projection (sC): QKV's LAST block has published — its 34 MB of weights would slow the QKV stream (r05: 11.4 -> 15.6 us
-            //                      with the gate on the first block), they load under the attention instead;
-            //   gate|up   (main): the attention has published — its 384 PERSISTENT blocks split the expert rows statically, so they
-            //                      must be placed evenly: dispatched while attention blocks still hold 72 CUs and O blocks arrive, the
-            //                      late ones landed two and three to a CU and the kernel took 99 us for its 73 (r05 timeline).  Without
-            //                      this gate the schedule is 0.8 % faster WHEN gate|up wins the dispatch race against O (~1 us margin).
-            //                      A SAMPLED layer (live timing of gate|up alone) waits for the O projection's last block instead.
-            VH_TRY(vhk_dec_gate(m->sA, m->g_gate, gq.tag, err), "dec gate");
-            VH_TRY(vhk_dec_attn(m->sA, nullptr, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
-                                m->attn_cnt, nullptr, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1, scale, m->table,
-                                &gq, &ga), "dec attn");
-            VH_TRY(vhk_dec_gate(m->sC, m->g_qkv + (m->nqkv - 1), gq.tag, err), "dec gate");
-            VH_TRY(vhk_dec_oproj(m->sC, nullptr, w.wo, H, nq * hd, nullptr, nullptr, &ga, tp ? &gp : &gd), "dec oproj");
-            // tensor parallel: the all-reduce of the partial (RowParallel o_proj, vllm_file/mixtral.py:470-476) behind the O projection
-            // on its stream, granules in and out: it pushes an element to the peers as soon as the O projection has published it
-            if (tp && vh_comm_allreduce_gran(m->comm, &gp, &gd, H, m->sC) != VH_OK)
-                return fail(VH_E_COMM, "all-reduce failed: %s", vh_comm_last_error());
-            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
-                               nullptr, nullptr, &gq, m->g_gate), "dec qkv");
-            if (prof) {
-                VH_TRY(vhk_dec_gate(st, m->g_dattn, gd.tag, err, H >= 64 ? H / 64 : 1, H), "dec gate");
-                (void)hipEventRecord(m->prof_ev[m->prof_used], st);
-            } else {
-                VH_TRY(vhk_dec_gate(st, m->g_attn, ga.tag, err), "dec gate");
-            }
-            VH_TRY(vhk_dec_gateup(st, m->xb, nullptr, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H, m->route, m->hbuf, 0,
-                                  nullptr, &gd), "dec gateup");
-            if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            VH_TRY(vhk_dec_down(st, m->hbuf, m->route, w.w2, H, I, m->delta_moe, nullptr), "dec down");
-            if (tp && m->allreduce(m->delta_moe, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");     // FusedMoE reduce_results (:405-414)
-            continue;
-        }
-        VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
-                           m->qkv, have_xm ? &xm : nullptr), "dec qkv");
-        VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
-                            m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
-                            scale, m->table), "dec attn");
         if (fuse && vh_comm_xchg_next(m->comm, H, 0, vhk_dec_consumer_blocks(1, 0, H, I), &xa, st) != VH_OK)
             return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
-        VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
+        if (fused_attn) {
+            VhDecAblk a{};
+            a.x_in = m->xa; a.delta = l == 0 ? nullptr : m->delta_moe; a.x_out = m->xb; a.norm_w = w.attn_norm; a.eps = eps;
+            a.Wqkv = w.wqkv; a.nqkv = m->nqkv; a.H = H;
+            a.kcache = kc; a.vcache = vc; a.pos = m->host_pos; a.table = m->table; a.rope_cos = m->rope_cos; a.rope_sin = m->rope_sin;
+            a.part_o = m->part_o; a.part_ml = m->part_ml; a.cnt = m->attn_cnt; a.nq = nq; a.nkv = nkv; a.max_ctx = m->c.max_ctx;
+            a.max_splits = m->max_splits; a.nsplit = (m->host_pos + 1 + 63) / 64; a.scale = scale;
+            a.Wo = w.wo; a.out = m->delta_attn;
+            a.gq = VhGranVec{m->g_qkv, m->next_tag(), err}; a.ga = VhGranVec{m->g_attn, m->next_tag(), err};
+            if (have_xm) a.cx = xm;
+            if (fuse) a.px = xa;
+            VH_TRY(vhk_dec_ablk(st, a), "dec attention block");
+        } else {
+            VH_TRY(vhk_dec_qkv(st, m->xa, l == 0 ? nullptr : m->delta_moe, m->xb, w.attn_norm, eps, w.wqkv, m->nqkv, H,
+                               m->qkv, have_xm ? &xm : nullptr), "dec qkv");
+            VH_TRY(vhk_dec_attn(st, m->qkv, kc, vc, m->counters, m->rope_cos, m->rope_sin, m->part_o, m->part_ml,
+                                m->attn_cnt, m->attn_out, nq, nkv, m->c.max_ctx, m->max_splits, m->host_pos + 1,
+                                scale, m->table), "dec attn");
+            VH_TRY(vhk_dec_oproj(st, m->attn_out, w.wo, H, nq * hd, m->delta_attn, fuse ? &xa : nullptr), "dec oproj");
+        }
         if (!fuse && m->allreduce(m->delta_attn, H, st) != 0) return fail(VH_E_COMM, "all-reduce failed");
         if (prof) (void)hipEventRecord(m->prof_ev[m->prof_used], st);
         VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
                               m->route, m->hbuf, 0, fuse ? &xa : nullptr), "dec gateup");
         if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
         if (fuse) {
-            // the consumer of this exchange is the next layer's QKV GEMV, or the LM head after the last layer
-            const int blocks = l + 1 < m->c.n_layers ? vhk_dec_consumer_blocks(0, m->nqkv, H, I) : m->lm_grid;
+            // the consumer of this exchange is the next layer's attention block (or fused-QKV GEMV), or the LM head after the last layer
+            const int blocks = l + 1 < m->c.n_layers ? (fused_attn ? vhk_dec_consumer_blocks(3, (H + 7) / 8, H, I) : vhk_dec_consumer_blocks(0, m->nqkv, H, I))
+                                                      : m->lm_grid;
             if (vh_comm_xchg_next(m->comm, H, 1, blocks, &xm, st) != VH_OK)
                 return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
             have_xm = true;
@@ -1234,11 +1130,10 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
     if (m->poisoned) return fail(VH_E_ARG, "decode: a previous step failed; prefill or reset first");
     if (m->live_seqs() > 0) return fail(VH_E_ARG, "vh_mixtral_decode: sequences own pages of the KV pool (use vh_mixtral_seq_decode)");
     if (n_steps <= 0) return VH_OK;
-    const bool ov = overlap_begin(m, st);
     int rc = VH_OK;
     for (int step = 0; step < n_steps; ++step) {
         if (m->host_pos + 1 >= m->c.max_ctx) { rc = fail(VH_E_SHAPE, "decode: KV cache full (%d)", m->c.max_ctx); break; }
-        rc = decode_one_step(m, st, ov);
+        rc = decode_one_step(m, st);
         if (rc != VH_OK) {
             // the step was not (fully) enqueued: host_pos keeps its value, i.e. it describes the
             // last COMPLETE step; the device state of the partial step is discarded by the next prefill / reset
@@ -1246,10 +1141,6 @@ int vh_mixtral_decode(vh_mixtral_t* m, int n_steps, void* stream) {
             break;
         }
         m->host_pos += 1;
-    }
-    if (ov) {
-        const int rj = overlap_end(m, st);
-        if (rc == VH_OK) rc = rj;
     }
     return rc;
 }
@@ -1477,7 +1368,6 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         }
     }
     if (n <= 0) return VH_OK;
-    const bool ov = overlap_begin(m, st);
     int rc = VH_OK;
     for (int i = 0; i < n; ++i) {
         const int s = ids[i];
@@ -1485,15 +1375,11 @@ int vh_mixtral_seq_decode(vh_mixtral_t* m, const int* ids, int n, void* stream) 
         if (pr == -1) { rc = fail(VH_E_FULL, "KV pool exhausted at sequence %d (%d of the batch advanced)", s, i); break; }
         if (pr != 0) { rc = fail(VH_E_HIP, "page table upload failed"); break; }
         m->bind(s);
-        rc = decode_one_step(m, st, ov);
+        rc = decode_one_step(m, st);
         if (rc != VH_OK) m->poisoned = 1;
         else m->host_pos += 1;
         m->unbind();
         if (rc != VH_OK) break;
-    }
-    if (ov) {
-        const int rj = overlap_end(m, st);
-        if (rc == VH_OK) rc = rj;
     }
     return rc;
 }

@@ -49,7 +49,8 @@ struct vh_comm {
     uint32_t generation;                     // tag wraps survived (barrier tags)
     bool connected;
     bool fine_grained;                       // the receive buffer is uncached / coherent for peer stores
-    bool same_device;                        // declared at creation (vh_tune("comm_allow_coarse", 1)): every rank drives THIS device (tests)
+    int ranks_per_device;                    // declared at creation (vh_tune("comm_ranks_per_device", n)): ranks that drive THIS rank's device
+    bool loopback;                           // one rank plays all `world` ranks into its own slots (vh_comm_create_loopback)
     // exchanges fused into the decode kernels (VhXchg): two result vectors (attention / MoE sub-block), the reducers' arrival counter
     float* reduced[2];
     int* counter;
@@ -90,37 +91,15 @@ struct Peers { uint64_t* p[VH_COMM_MAX_WORLD]; };
 
 // region layout (granules): one-shot: slot r at [r * cap, ...)
 __global__ __launch_bounds__(256) void k_ar_oneshot(float* __restrict__ buf, long count, Peers peers, uint64_t* local,
-                                                    size_t cap, int rank, int world, uint32_t tag, int* err) {
+                                                    size_t cap, int rank, int world, uint32_t tag, int* err, int loopback) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
         const float v = buf[i];
-        for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)rank * cap + i, tag, v);
+        // loopback: this rank plays all of them — its value into slot `rank`, the peers' (zero) contributions into theirs
+        if (loopback) for (int p = 0; p < world; ++p) put(local + (size_t)p * cap + i, tag, p == rank ? v : 0.f);
+        else for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)rank * cap + i, tag, v);
         float s = 0.f;
         for (int r = 0; r < world; ++r) s += get(local + (size_t)r * cap + i, tag, err, 1);   // rank order: same sum everywhere
         buf[i] = s;
-    }
-}
-
-// The same exchange with its INPUT and OUTPUT as GEMV-layout granule vectors (VhGranVec, vh_kernels.h): the overlapped decode schedule
-// under tensor parallelism.  The O projection (side stream, possibly still running) publishes this rank's partial as tagged
-// granules; element i is pushed to the peers as soon as it has arrived, summed over the ranks in rank order, and handed to the
-// gate|up kernel (main stream, already resident) as a granule again — no kernel boundary on either side of the collective.
-__global__ __launch_bounds__(256) void k_ar_oneshot_gran(const VhGranVec gin, const VhGranVec gout, long count, Peers peers, uint64_t* local,
-                                                         size_t cap, int rank, int world, uint32_t tag, int* err) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-        const size_t pos = vhk_gran_pos_gemv((int)i);
-        float v = 0.f;
-        for (unsigned spins = 0;;) {                             // my partial element (agent scope: this device's O projection)
-            const u64 x = __hip_atomic_load(reinterpret_cast<const u64*>(gin.g) + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(x >> 32) == gin.tag) { v = __uint_as_float((uint32_t)x); break; }
-            if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            if (++spins > VH_COMM_SPIN_LIMIT) { __hip_atomic_store(err, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)rank * cap + i, tag, v);
-        float s = 0.f;
-        for (int r = 0; r < world; ++r) s += get(local + (size_t)r * cap + i, tag, err, 1);   // rank order: same sum everywhere
-        __hip_atomic_store(reinterpret_cast<u64*>(gout.g) + pos, ((u64)gout.tag << 32) | (u64)__float_as_uint(s), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -275,7 +254,9 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     }
     vh_comm* c = new vh_comm{};
     c->rank = rank; c->world = world; c->cap = cap_elems;
-    c->same_device = vh_tuning()->comm_allow_coarse != 0;
+    c->ranks_per_device = vh_tuning()->comm_ranks_per_device;
+    if (c->ranks_per_device < 1) c->ranks_per_device = 1;
+    if (c->ranks_per_device > world) c->ranks_per_device = world;
     // one-shot needs world * cap granules; bulk (8-byte units): A and B of world * slice_pad fp32 each + two flag arrays
     c->oneshot_units = ((size_t)world * (cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX) + 1) & ~size_t(1);
     c->maxchunk = (int)(cap_elems / ((size_t)world * VH_COMM_CHUNK)) + 2;
@@ -338,6 +319,21 @@ int vh_comm_connect(vh_comm_t* c, const void* handles) {
     return VH_OK;
 }
 
+/* A single-process communicator that plays `world` ranks (bench.py --emulate-tp N --loopback): every peer region is the local one,
+ * a push writes this rank's value into slot `rank` and a zero into each of the other world - 1 slots, the reduction polls and sums
+ * the world slots in rank order — the stores, polls, tags, parity regions and launches of a real exchange with no link in between,
+ * and sums that equal the inputs (the tokens stay those of this rank's shard alone).  One-shot (decode-sized) messages only. */
+vh_comm_t* vh_comm_create_loopback(int rank, int world, size_t cap_elems) {
+    if (cap_elems == 0 || cap_elems > VH_COMM_ONESHOT_MAX) { cfail(VH_E_ARG, "vh_comm_create_loopback: capacity outside (0, 32768]"); return nullptr; }
+    char handle[64];
+    vh_comm* c = vh_comm_create(rank, world, cap_elems, handle);
+    if (!c) return nullptr;
+    for (int r = 0; r < world; ++r) c->peer[r] = c->local;
+    c->loopback = true;
+    c->connected = true;
+    return c;
+}
+
 size_t vh_comm_capacity(const vh_comm_t* c) { return c ? c->cap : 0; }
 
 int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
@@ -358,11 +354,12 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
     uint64_t* local = c->local + par * c->region;
     Peers peers{};
     for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r] + par * c->region;
+    if (c->loopback && count > VH_COMM_ONESHOT_MAX) return cfail(VH_E_SHAPE, "vh_comm_allreduce: a loop-back communicator carries one-shot (decode) messages only");
     if (count <= VH_COMM_ONESHOT_MAX) {
         const size_t cap1 = c->cap < VH_COMM_ONESHOT_MAX ? c->cap : VH_COMM_ONESHOT_MAX;
         const int grid = (int)((count + 255) / 256);
         hipLaunchKernelGGL(k_ar_oneshot, dim3(grid), dim3(256), 0, st, buf, count, peers, local, cap1, c->rank, c->world,
-                           tag, c->err);
+                           tag, c->err, c->loopback ? 1 : 0);
     } else {
         BulkGeom g{};
         g.slice = (((count + c->world - 1) / c->world) + 3) & ~3L;         // multiple of 4: chunks start on 16-byte boundaries
@@ -383,8 +380,8 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
         // slowest rank's GEMM finds no empty CU while the other ranks' blocks spin on its contribution (r05: world 8 at 32 layers,
         // S = 552, timed out in phase 3 with 8 x 128 spinning blocks): the cap is divided by the ranks on the device.
         int cap_blocks = 128;
-        if (c->same_device) {
-            cap_blocks = vh_num_cus() / 2 / c->world;
+        if (c->ranks_per_device > 1) {
+            cap_blocks = vh_num_cus() / 2 / c->ranks_per_device;
             if (cap_blocks < 1) cap_blocks = 1;
             if (cap_blocks > 128) cap_blocks = 128;
         }
@@ -400,32 +397,8 @@ int vh_comm_allreduce(vh_comm_t* c, float* buf, long count, void* stream) {
 
 }  // extern "C"
 
-int vh_comm_ranks_share_device(const vh_comm* c) { return c && c->same_device ? 1 : 0; }
-
-// The one-shot all-reduce between two granule vectors (k_ar_oneshot_gran): same call counter, tag and parity discipline as
-// vh_comm_allreduce (the kinds interleave freely; every rank issues them in the same order).  Not part of the public C ABI.
-int vh_comm_allreduce_gran(vh_comm* c, const VhGranVec* gin, const VhGranVec* gout, long count, void* stream) {
-    if (!c || !gin || !gout || !gin->g || !gout->g || !c->connected) return cfail(VH_E_COMM, "vh_comm_allreduce_gran: not connected / null vector");
-    const size_t cap1 = c->cap < VH_COMM_ONESHOT_MAX ? c->cap : VH_COMM_ONESHOT_MAX;
-    if (count < 1 || (size_t)count > cap1) return cfail(VH_E_SHAPE, "vh_comm_allreduce_gran: message above the one-shot capacity");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    c->calls += 1;
-    uint32_t tag = (uint32_t)c->calls;
-    if (tag == 0) {
-        const int rc = comm_rewind(c, st);
-        if (rc != VH_OK) return rc;
-        c->calls += 1;
-        tag = (uint32_t)c->calls;
-    }
-    const size_t par = (size_t)(c->calls & 1);
-    Peers peers{};
-    for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r] + par * c->region;
-    hipLaunchKernelGGL(k_ar_oneshot_gran, dim3((int)((count + 255) / 256)), dim3(256), 0, st, *gin, *gout, count, peers,
-                       c->local + par * c->region, cap1, c->rank, c->world, tag, c->err);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return cfail(VH_E_HIP, "vh_comm_allreduce_gran: launch", e);
-    return VH_OK;
-}
+int vh_comm_ranks_per_device(const vh_comm* c) { return c ? c->ranks_per_device : 1; }
+int vh_comm_is_loopback(const vh_comm* c) { return c && c->loopback ? 1 : 0; }
 
 // One all-reduce fused into the decode kernels: advances the call counter exactly as vh_comm_allreduce does (the two kinds
 // interleave freely) and describes the exchange for the producer and the consumer launch.  `which` picks the result vector
@@ -458,6 +431,7 @@ int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, Vh
     c->arrivals += x.nred;
     x.target = (int)c->arrivals;                 // compared modulo 2^32 on the device
     x.count = (int)count;
+    x.loopback = c->loopback ? 1 : 0;
     *out = x;
     return VH_OK;
 }
@@ -468,7 +442,7 @@ int vh_comm_status(vh_comm_t* c) {
     if (!c) return -1;
     int v = 0;
     if (hipMemcpy(&v, c->err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;   // 0 = no spin ever timed out; 1 = one-shot, 2 / 3 = bulk reduce / gather phase, 4 = barrier, 5 / 6 = fused exchange, 7 = granule input
+    return v;   // 0 = no spin ever timed out; 1 = one-shot, 2 / 3 = bulk reduce / gather phase, 4 = barrier, 5 / 6 = fused exchange
 }
 
 void vh_comm_destroy(vh_comm_t* c) {

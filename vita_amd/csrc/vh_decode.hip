@@ -25,11 +25,11 @@
 // prologue ("delta" buffers) so that under tensor parallelism the same kernels run
 // unchanged with an all-reduce on the delta buffer between them.
 //
-// r05: every kernel of the attention block also exists as a GR ("granule") instantiation for the OVERLAPPED schedule
-// (vh_api.hip: decode_one_step): its inputs / outputs are tagged 8-byte {tag, fp32} granules polled with agent-scope
-// atomics (VhGranVec), so that attention and the O projection can be resident on side streams — K / V tiles and weights in
-// flight — while the kernel that feeds them still runs; k_dec_gate is the one-wave kernel that times their launch.  Same
-// per-thread arithmetic and reduction order as the serial instantiations: the two schedules are bit-identical.
+// r06: the attention block of a layer (fused QKV -> attention -> O projection) is ONE launch, k_dec_ablk: its rows and tiles are
+// work items of 2 persistent blocks per CU, taken in a fixed order (item i on block i mod grid); an item that needs another
+// item's output polls it as tagged 8-byte {tag, fp32} granules (VhGranVec, agent-scope atomics) with its own weights / K-V tile
+// already in flight.  The per-thread arithmetic and the reduction order are those of the three separate kernels (k_dec_gemv<NORM>,
+// k_dec_attn, k_dec_gemv<!NORM>, kept as the per-operator entries and as vh_tune("dec_fused", 0)): the two forms are bit-identical.
 //
 // Reference semantics restated: transformers/models/mixtral/modeling_mixtral.py
 // (MixtralRMSNorm, MixtralAttention + apply_rotary_pos_emb, MixtralTopKRouter,
@@ -45,6 +45,12 @@ typedef unsigned long long xu64;
 // producer: element n of my partial vector -> slot `rank` of every rank's receive region (the data is the flag)
 __device__ __forceinline__ void xchg_put(const VhXchg& px, int n, float v) {
     const xu64 g = ((xu64)px.tag << 32) | (xu64)__float_as_uint(v);
+    if (px.loopback) {       // one rank plays them all: my value into slot `rank`, the peers' (zero) contributions into theirs
+        const xu64 z = (xu64)px.tag << 32;
+        for (int p = 0; p < px.world; ++p)
+            __hip_atomic_store(reinterpret_cast<xu64*>(px.local + (size_t)p * px.cap + n), p == px.rank ? g : z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     for (int p = 0; p < px.world; ++p)
         __hip_atomic_store(reinterpret_cast<xu64*>(px.peer[p] + (size_t)px.rank * px.cap + n), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -108,7 +114,7 @@ __device__ __forceinline__ f32x4 xchg_ld4(const float* p) {
     return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
 }
 
-// ---- granule vectors between concurrently resident kernels (VhGranVec, vh_kernels.h) -----------------------------------------
+// ---- granule vectors between the work items of the fused attention-block launch (VhGranVec, vh_kernels.h) ---------------------
 // Every wait below is WAVE-collective (all 64 lanes run the same number of polls; exits are decided with __all) and bounded: a
 // producer that never publishes ends in the engine's error word (code 7), not in a hang.
 __device__ __forceinline__ size_t gran_pos_gemv(int n) { return vhk_gran_pos_gemv(n); }
@@ -262,46 +268,6 @@ __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, c
     return ss;
 }
 
-// load_add_norm with the delta vector arriving as granules from a kernel that may still be running (the O projection under the
-// overlapped schedule): the block waits for its granules, then reads x_in / norm_w.  Same arithmetic as above.
-template <int NJ>
-__device__ __forceinline__ float load_add_norm_g(const float* __restrict__ x_in, const VhGranVec& gd,
-                                                 const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
-                                                 float (&xr)[NJ][8]) {
-    // (x_in is read AFTER the wait: 16 KB that every block reads, L2-resident — holding it in registers across the wait, next to the
-    // router weights a gate|up block already holds, pushed the 128-register instantiation into scratch)
-    float dv[NJ][8];
-    gran_read_gemv<NJ>(gd, K, dv);
-    f32x4 xa[NJ][2];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = threadIdx.x + j * 256;
-        const int cc = (c * 8 < K) ? c : 0;
-        xa[j][0] = reinterpret_cast<const f32x4*>(x_in)[cc * 2];
-        xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int c = threadIdx.x + j * 256;
-        const bool ok = c * 8 < K;
-        const int cc = ok ? c : 0;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const f32x4 nw = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + hh];       // (L2-resident: loaded where it is used)
-            f32x4 v = xa[j][hh] + f32x4{dv[j][hh * 4], dv[j][hh * 4 + 1], dv[j][hh * 4 + 2], dv[j][hh * 4 + 3]};
-            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (x_out && blockIdx.x == 0 && ok) reinterpret_cast<f32x4*>(x_out)[c * 2 + hh] = v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ss = fmaf(v[i], v[i], ss);
-                xr[j][hh * 4 + i] = v[i] * nw[i];
-            }
-        }
-    }
-    return ss;
-}
-
 // R rows of W (bf16) against the register-resident x, in two phases so the weight loads are in
 // flight BEFORE the (L2-resident) activation loads and prologue math.  rows[r] must be valid
 // pointers (callers clamp out-of-range rows and drop the result).
@@ -330,22 +296,15 @@ __device__ __forceinline__ void gemv_fma(const uint4 (&w)[R][NJ], const float (&
 // ---- K_A / K_C: (residual add + RMSNorm +) row-parallel GEMV -------------------------------
 // NORM=true : out = rsqrt(mean(x^2)+eps) * W (x*w_norm), x = x_in + delta      (fused QKV)
 // NORM=false: out = W x_in                                                    (O projection)
-// GR (overlapped schedules, one rank): granule I/O compiled in — NORM = true (fused QKV): outputs leave as LINEAR granules for the
-// attention kernel; NORM = false (O projection): x_in arrives and the outputs leave as GEMV-layout granules (attention -> O ->
-// gate|up).  A separate instantiation, so the serial schedule's kernels keep their r04 register counts (a run-time switch made the
-// O projection 252 VGPRs: one block per CU); capped at 128 registers so that its blocks sit beside the waiting gate|up blocks.
-template <int NJ, int R, bool NORM, bool GR>
-__global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
+// (the per-operator form; inside a decode step the same arithmetic runs as items of k_dec_ablk below)
+template <int NJ, int R, bool NORM>
+__global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                   float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                   float eps, const uint16_t* __restrict__ W, int N, int K,
-                                                  float* __restrict__ out, const VhXchg xc, const VhGranVec gin,
-                                                  const VhGranVec gout, unsigned long long* __restrict__ gate) {
+                                                  float* __restrict__ out, const VhXchg xc) {
     // xc: NORM = true: consumer of a fused exchange (delta = xc.reduced); NORM = false: producer (outputs are pushed)
-    // gate (GR, fused QKV): "this layer's QKV kernel has started" — opens the gate kernels in front of the side-stream kernels
     __shared__ float red[4 * (R + 1)];
-    if (GR && NORM && gate && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(gate, ((xu64)gout.tag << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (NORM && !GR) xchg_reduce(xc);
+    if (NORM) xchg_reduce(xc);
     const int n0 = blockIdx.x * R;
     const uint16_t* rows[R];
 #pragma unroll
@@ -356,11 +315,10 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gemv(const float* __res
     float xr[NJ][8];
     float vals[R + 1];
     if (NORM) {
-        if (!GR) xchg_wait(xc);
-        vals[R] = load_add_norm<NJ>(x_in, (!GR && xc.world) ? xc.reduced : delta, norm_w, x_out, K, xr, !GR && xc.world != 0);
+        xchg_wait(xc);
+        vals[R] = load_add_norm<NJ>(x_in, xc.world ? xc.reduced : delta, norm_w, x_out, K, xr, xc.world != 0);
     } else {
-        if (GR) gran_read_gemv<NJ>(gin, K, xr);
-        else load_x<NJ>(x_in, K, xr);
+        load_x<NJ>(x_in, K, xr);
         vals[R] = 0.f;
     }
     float acc[R];
@@ -373,8 +331,7 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gemv(const float* __res
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) if (threadIdx.x == r) v = vals[r];
-        if (GR) gran_put(gout, NORM ? (size_t)(n0 + threadIdx.x) : gran_pos_gemv(n0 + threadIdx.x), v * inv);
-        else if (!NORM && xc.world) xchg_put(xc, n0 + threadIdx.x, v * inv);
+        if (!NORM && xc.world) xchg_put(xc, n0 + threadIdx.x, v * inv);
         else out[n0 + threadIdx.x] = v * inv;
     }
 }
@@ -384,26 +341,55 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gemv(const float* __res
 // tile, shared by the G = nq/nkv query heads of that KV head (wave w < G serves head h*G + w;
 // lanes index keys for QK^T and head dims, 2 per lane, for PV).  The host sizes nsplit from its
 // mirror of the position, so no block is empty.  Each block publishes (m, l, o) partials; the
-// LAST block to arrive for a KV head merges them (agent-scope release -> ticket -> acquire, guide
-// §6 G16 counter form) and writes the attention output, so the O-projection reads 16 KB instead of
-// re-merging the partials in each of its blocks.  head_dim is 128 (config.json:16-44).
+// LAST block to arrive for a KV head merges them and writes the attention output, so the
+// O-projection reads 16 KB instead of re-merging the partials in each of its blocks.
+// Hand-off of the partials (r06): every partial word is written with an 8-byte agent-scope atomic store (write-through) and
+// read by the merging block with 8-byte agent-scope atomic loads (L1-bypassing) — guide G16 "8-B agent atomics both sides":
+// every storing wave drains (vmcnt(0)), one relaxed ticket per block, NO release / acquire fence (r01-r05 paid one of each,
+// ~1.7 us apiece on the critical path of a kernel that is pure latency).  head_dim is 128 (config.json:16-44).
 #define DA_KT 64
 #define DA_KSTR 132
-// Body of one attention block (h, sp of nsplit).  Returns true in the block that merged the partials
-// of its KV head and wrote attn_out rows [h*G*128, (h+1)*G*128) (block-uniform).
+struct DecAttnTile { f32x4 k[8], v[8]; };      // one 64-key K / V tile in flight: 8 x 16 B of each per thread
 // `table` (nullable): paged KV cache — logical 64-key block sp of this sequence lives in physical page table[sp] of the
 // pool (one page = one tile of this kernel); null = the contiguous single-sequence layout (page sp).
+// Step 1 of an attention block: put the K/V tile loads in flight (8 x 16 B each per thread).  Unconditional loads from
+// clamped rows into NATIVE vector registers: with the loads under a branch and the HIP float4 struct
+// as the staging type, hipcc parked the K registers in scratch memory and waited after every K/V pair
+// (8 dependent round trips instead of 16 loads in flight).  Rows that do not exist are zeroed in step 3.
+__device__ __forceinline__ void dec_attn_issue(const int h, const int sp, const float* __restrict__ kcache,
+                                               const float* __restrict__ vcache, const int* __restrict__ table, int max_ctx,
+                                               DecAttnTile& t) {
+    const int p0 = (table ? table[sp] : sp) * DA_KT;                 // first physical row of this tile's page
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int row = idx >> 5, c4 = idx & 31;
+        const int key = min(p0 + row, max_ctx - 1);
+        t.k[i] = reinterpret_cast<const f32x4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
+        t.v[i] = reinterpret_cast<const f32x4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
+    }
+}
+__device__ __forceinline__ void part_store2(float* p, float a, float b) {
+    __hip_atomic_store(reinterpret_cast<xu64*>(p), ((xu64)__float_as_uint(b) << 32) | (xu64)__float_as_uint(a), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 part_load2(const float* p) {
+    const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)x), __uint_as_float((unsigned)(x >> 32)));
+}
+// Steps 2-5 of one attention block (h, sp of nsplit) whose tile loads were issued by dec_attn_issue.  Returns true in the block
+// that merged the partials of its KV head and wrote attn_out rows [h*G*128, (h+1)*G*128) (block-uniform).
+// GR: qkv arrives as LINEAR granules (gq) from fused-QKV items of the same launch that may still be running; the merged
+// output leaves as GEMV-layout granules (gout) for the O-projection items.
 template <bool GR>
-__device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const int nsplit,
-                                               const float* __restrict__ qkv, float* __restrict__ kcache,
-                                               float* __restrict__ vcache, const int pos, const int* __restrict__ table,
-                                               const float* __restrict__ rope_cos,
-                                               const float* __restrict__ rope_sin, float* __restrict__ part_o,
-                                               float* __restrict__ part_ml, int* __restrict__ cnt,
-                                               float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
-                                               int max_splits, float scale, const VhGranVec gq, const VhGranVec gout) {
-    // gq.g: qkv arrives as LINEAR granules from a fused-QKV kernel that may still be running (this block's K / V tile loads are
-    // already in flight when it starts to wait); gout.g: the merged output leaves as GEMV-layout granules for the O projection
+__device__ __forceinline__ bool dec_attn_finish(const int h, const int sp, const int nsplit, const DecAttnTile& tile,
+                                                const float* __restrict__ qkv, float* __restrict__ kcache,
+                                                float* __restrict__ vcache, const int pos, const int* __restrict__ table,
+                                                const float* __restrict__ rope_cos,
+                                                const float* __restrict__ rope_sin, float* __restrict__ part_o,
+                                                float* __restrict__ part_ml, int* __restrict__ cnt,
+                                                float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
+                                                int max_splits, float scale, const VhGranVec gq, const VhGranVec gout) {
     __shared__ __attribute__((aligned(16))) float q_s[4][128];
     __shared__ __attribute__((aligned(16))) float kn_s[128];
     __shared__ __attribute__((aligned(16))) float vn_s[128];
@@ -418,20 +404,6 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     const int k1 = min(pos + 1, k0 + DA_KT);
     const int head = h * G + wid;
     const int p0 = (table ? table[sp] : sp) * DA_KT;                 // first physical row of this tile's page
-
-    // 1. put the K/V tile loads in flight first (8 x 16 B each per thread).  Unconditional loads from
-    // clamped rows into NATIVE vector registers: with the loads under a branch and the HIP float4 struct
-    // as the staging type, hipcc parked the K registers in scratch memory and waited after every K/V pair
-    // (8 dependent round trips instead of 16 loads in flight).  Rows that do not exist are zeroed in step 3.
-    f32x4 kreg[8], vreg[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx >> 5, c4 = idx & 31;
-        const int key = min(p0 + row, max_ctx - 1);
-        kreg[i] = reinterpret_cast<const f32x4*>(kcache + ((size_t)h * max_ctx + key) * 128)[c4];
-        vreg[i] = reinterpret_cast<const f32x4*>(vcache + ((size_t)h * max_ctx + key) * 128)[c4];
-    }
 
     // 2. rotate-half RoPE (modeling_mixtral.py:203-241): out = x*cos + rotate_half(x)*sin
     const float c = rope_cos[(size_t)pos * 64 + lane], s = rope_sin[(size_t)pos * 64 + lane];
@@ -477,7 +449,7 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
         const int idx = tid + i * 256;
         const int row = idx >> 5, c4 = idx & 31;
         const int key = k0 + row;
-        f32x4 kv = kreg[i], vv = vreg[i];
+        f32x4 kv = tile.k[i], vv = tile.v[i];
         if (key == pos) {
             kv = reinterpret_cast<const f32x4*>(kn_s)[c4];
             vv = reinterpret_cast<const f32x4*>(vn_s)[c4];
@@ -516,41 +488,34 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
             o.x = fmaf(pk, vv.x, o.x);
             o.y = fmaf(pk, vv.y, o.y);
         }
-        reinterpret_cast<float2*>(part_o + ((size_t)head * max_splits + sp) * 128)[lane] = o;
-        if (lane == 0) {
-            part_ml[((size_t)head * max_splits + sp) * 2] = m;
-            part_ml[((size_t)head * max_splits + sp) * 2 + 1] = l;
-        }
+        part_store2(part_o + ((size_t)head * max_splits + sp) * 128 + 2 * lane, o.x, o.y);
+        if (lane == 0) part_store2(part_ml + ((size_t)head * max_splits + sp) * 2, m, l);
     }
 
-    // 5. publish; the last arriver of this KV head merges (placement-independent hand-off)
+    // 5. publish; the last arriver of this KV head merges (placement-independent hand-off: write-through stores, every wave
+    // drained, one relaxed ticket; the merger reads with L1-bypassing loads)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int ticket = __hip_atomic_fetch_add(&cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = (ticket == nsplit - 1) ? 1 : 0;
+        if (ticket == nsplit - 1) __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
     if (!last_s) return false;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    }
-    __syncthreads();
     if (wid < G) {
         const float* ml = part_ml + (size_t)head * max_splits * 2;
         const float* po = part_o + (size_t)head * max_splits * 128;
         float M = -INFINITY;
-        for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, ml[sidx * 2]);
+        for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, part_load2(ml + sidx * 2).x);
         float den = 0.f;
         float2 num = make_float2(0.f, 0.f);
 #pragma unroll 4
         for (int sidx = 0; sidx < nsplit; ++sidx) {
-            const float wgt = __expf(ml[sidx * 2] - M);
-            den = fmaf(wgt, ml[sidx * 2 + 1], den);
-            const float2 ov = reinterpret_cast<const float2*>(po + (size_t)sidx * 128)[lane];
+            const float2 mlv = part_load2(ml + sidx * 2);
+            const float wgt = __expf(mlv.x - M);
+            den = fmaf(wgt, mlv.y, den);
+            const float2 ov = part_load2(po + (size_t)sidx * 128 + 2 * lane);
             num.x = fmaf(wgt, ov.x, num.x);
             num.y = fmaf(wgt, ov.y, num.y);
         }
@@ -565,16 +530,139 @@ __device__ __forceinline__ bool dec_attn_block(const int h, const int sp, const 
     return true;
 }
 
-template <bool GR>
 __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv, float* __restrict__ kcache,
                                                   float* __restrict__ vcache, const int pos, const int* __restrict__ table,
                                                   const float* __restrict__ rope_cos,
                                                   const float* __restrict__ rope_sin, float* __restrict__ part_o,
                                                   float* __restrict__ part_ml, int* __restrict__ cnt,
                                                   float* __restrict__ attn_out, int nq, int nkv, int max_ctx,
-                                                  int max_splits, float scale, const VhGranVec gq, const VhGranVec gout) {
-    dec_attn_block<GR>(blockIdx.x, blockIdx.y, gridDim.y, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
-                       part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, gq, gout);
+                                                  int max_splits, float scale) {
+    DecAttnTile tile;
+    dec_attn_issue(blockIdx.x, blockIdx.y, kcache, vcache, table, max_ctx, tile);
+    dec_attn_finish<false>(blockIdx.x, blockIdx.y, gridDim.y, tile, qkv, kcache, vcache, pos, table, rope_cos, rope_sin, part_o,
+                           part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
+}
+
+// ---- the attention block of a layer as ONE launch: fused QKV GEMV -> split-KV attention -> O projection ----------------------------
+// A batch-1 decode layer used to be five dependent launches; QKV, attention and the O projection are short enough that the head
+// and tail of each launch — dispatch, first-byte latency of the weight / K-V loads, prologue, drain, the boundary — cost as
+// much as their bytes (TP = 1: 28.5 us for 84 MB that the stream moves in 14; one rank of TP = 8: 18 us for 10.5 MB).  Here the three
+// are WORK ITEMS of one launch of 2 persistent blocks per CU (grid G):
+//   QKV item q        RQ rows of the fused q|k|v matrix               -> q|k|v as LINEAR granules (gq)         block q mod G
+//   attention item i  one 64-key tile of one KV head (h, split)       -> partials; the last arriver of a head
+//                                                                        merges -> GEMV-layout granules (ga)   block G - 1 - (i mod G)
+//   O item o          8 rows of the O projection                      -> out (stored, or pushed to the peers)  block o mod G
+// Every block runs its QKV items, then its attention items, then its O items.  Phases only wait for EARLIER phases (attention
+// for q|k|v, O for the merged attention output) and nothing in a phase waits for the same phase, so every block gets through
+// its QKV items unconditionally, then through its attention items, then through its O items: no circular wait whatever the
+// placement, provided every block is eventually dispatched (grid <= 2 per CU = the launch bounds; every wait is bounded and ends
+// in the error word).  Attention sits on the HIGHEST block ids: with fewer QKV items than blocks (tensor-parallel shards) those
+// blocks have no QKV item and their K / V tiles load from the first cycle.  What the fusion buys: ONE launch ramp and boundary
+// instead of three; the loads of a block's next item are issued before the current item's block reduction and BEFORE the wait for
+// their own input granules, so O weights and K / V tiles are in flight or landed when the data they wait for is published.
+// Three loops with small bodies (one loop over a type switch made hipcc hoist every body's address arithmetic in front of it:
+// 256 registers and 765 spills).  Arithmetic: exactly k_dec_gemv<NORM> / k_dec_attn / k_dec_gemv<!NORM> (same per-thread
+// accumulation, same reduction tree).
+template <int NJ, int R, int WN>
+__device__ __forceinline__ void ablk_issue_rows(const uint16_t* __restrict__ W, const int n0, const int N, const int K, uint4 (&w)[WN]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint16_t* row = W + (size_t)min(n0 + r, N - 1) * K;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = threadIdx.x + j * 256;
+            w[r * NJ + j] = (c * 8 < K) ? ld_weight16(row + (size_t)c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+template <int NJ, int NJO, int RQ>
+__global__ __launch_bounds__(256, 2) void k_dec_ablk(const VhDecAblk a) {
+    constexpr int RO = 8;
+    constexpr int WN = (RQ * NJ > RO * NJO) ? RQ * NJ : RO * NJO;
+    constexpr int RM = RQ > RO ? RQ : RO;
+    __shared__ float red[4 * (RM + 1)];
+    const int KO = a.nq * 128;
+    const int nQ = (a.nqkv + RQ - 1) / RQ, nA = a.nkv * a.nsplit, nO = (a.H + RO - 1) / RO;
+    const int G = gridDim.x;
+    xchg_reduce(a.cx);                          // fused exchange: the first nred blocks sum the previous layer's MoE partials
+
+    uint4 w[WN];                                // weights of the GEMV item in flight (QKV: [RQ][NJ], O: [RO][NJO])
+    DecAttnTile tile;                           // K / V tile of the attention item in flight
+    int q = blockIdx.x, ai = G - 1 - (int)blockIdx.x, oi = blockIdx.x;
+    const bool had_q = q < nQ;
+    // the first item of the block's first non-empty phase goes out before anything else
+    if (q < nQ) ablk_issue_rows<NJ, RQ, WN>(a.Wqkv, q * RQ, a.nqkv, a.H, w);
+    else if (ai < nA) dec_attn_issue(ai / a.nsplit, ai % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
+    else if (oi < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, oi * RO, a.H, KO, w);
+
+    // ---- phase 1: fused-QKV rows ----
+    if (q < nQ) {
+        float xr[NJ][8];
+        xchg_wait(a.cx);
+        const float ss = load_add_norm<NJ>(a.x_in, a.cx.world ? a.cx.reduced : a.delta, a.norm_w, a.x_out, a.H, xr, a.cx.world != 0);
+        float inv = 0.f;
+        bool first = true;
+        for (; q < nQ; q += G) {
+            float vals[RQ + 1];
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc += dot8_bf16_f32(w[r * NJ + j], xr[j]);
+                vals[r] = acc;
+            }
+            // next GEMV item of this block: its loads go out before the block reduction (a K / V tile would be waited for and
+            // spilled here — the tile registers on top of this phase's: it goes out at the head of phase 2 instead)
+            if (q + G < nQ) ablk_issue_rows<NJ, RQ, WN>(a.Wqkv, (q + G) * RQ, a.nqkv, a.H, w);
+            else if (ai >= nA && oi < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, oi * RO, a.H, KO, w);
+            vals[RQ] = first ? ss : 0.f;
+            block256_sum<RQ + 1>(vals, red);
+            if (first) { inv = rsqrtf(vals[RQ] / (float)a.H + a.eps); first = false; }
+            const int n0 = q * RQ;
+            if (threadIdx.x < RQ && n0 + threadIdx.x < a.nqkv) {
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < RQ; ++r) if (threadIdx.x == r) v = vals[r];
+                gran_put(a.gq, (size_t)(n0 + threadIdx.x), v * inv);
+            }
+        }
+    }
+    // ---- phase 2: attention tiles ----
+    if (had_q && ai < nA) dec_attn_issue(ai / a.nsplit, ai % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
+    for (; ai < nA; ai += G) {
+        // the block's first O item goes out first when this is its last tile (the usual case: its weights do not depend on
+        // anything this item waits for, and they live in `w`, not in the tile registers)
+        const bool more = ai + G < nA;
+        if (!more && oi < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, oi * RO, a.H, KO, w);
+        dec_attn_finish<true>(ai / a.nsplit, ai % a.nsplit, a.nsplit, tile, nullptr, a.kcache, a.vcache, a.pos, a.table, a.rope_cos,
+                              a.rope_sin, a.part_o, a.part_ml, a.cnt, nullptr, a.nq, a.nkv, a.max_ctx, a.max_splits, a.scale, a.gq, a.ga);
+        if (more) dec_attn_issue((ai + G) / a.nsplit, (ai + G) % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
+    }
+    // ---- phase 3: O-projection rows ----
+    if (oi < nO) {
+        float xo[NJO][8];
+        gran_read_gemv<NJO>(a.ga, KO, xo);      // waits for the merged attention output (this item's weights are in flight)
+        for (; oi < nO; oi += G) {
+            float vals[RO];
+#pragma unroll
+            for (int r = 0; r < RO; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJO; ++j) acc += dot8_bf16_f32(w[r * NJO + j], xo[j]);
+                vals[r] = acc;
+            }
+            if (oi + G < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, (oi + G) * RO, a.H, KO, w);
+            block256_sum<RO>(vals, red);
+            const int n0 = oi * RO;
+            if (threadIdx.x < RO && n0 + threadIdx.x < a.H) {
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < RO; ++r) if (threadIdx.x == r) v = vals[r];
+                if (a.px.world) xchg_put(a.px, n0 + threadIdx.x, v);
+                else a.out[n0 + threadIdx.x] = v;
+            }
+        }
+    }
 }
 
 // ---- K_D: residual add + RMSNorm + router + gate|up GEMV + SiLU*up ------------------
@@ -584,19 +672,18 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
 // loops over 2*RP-row groups (RP gate + RP up rows of one expert) and relies on the co-resident
 // blocks of its CU for the overlap of one block's reduction with another's loads (a second register
 // buffer per block measured slower, 91 vs 84 us: it costs two waves per SIMD of occupancy; r01, git history).
-template <int NJ, int RP, bool GR>
-__global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gateup(const float* __restrict__ x_in, const float* __restrict__ delta,
+template <int NJ, int RP>
+__global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                     float* __restrict__ x_out, const float* __restrict__ norm_w,
                                                     float eps, const uint16_t* __restrict__ Wg, int E,
                                                     const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3,
                                                     int I, int K, int* __restrict__ route_out,
-                                                    float* __restrict__ hbuf, const VhXchg cx, const VhGranVec gd) {
-    // GR (overlapped schedule): the attention delta arrives as granules (gd) from an O projection that may still be running
+                                                    float* __restrict__ hbuf, const VhXchg cx) {
     __shared__ float red[4 * 9];
     float xr[NJ][8];
     float inv;
     int e0 = 0, e1 = 0;
-    if (!GR) xchg_reduce(cx);
+    xchg_reduce(cx);
     {
         const uint16_t* rrows[8];
 #pragma unroll
@@ -604,9 +691,8 @@ __global__ __launch_bounds__(256, GR ? 4 : 1) void k_dec_gateup(const float* __r
         uint4 wr[8][NJ];
         gemv_issue<NJ, 8>(rrows, K, wr);
         float vals[9];
-        if (!GR) xchg_wait(cx);
-        if (GR) vals[8] = load_add_norm_g<NJ>(x_in, gd, norm_w, x_out, K, xr);
-        else vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
+        xchg_wait(cx);
+        vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
 #pragma unroll
@@ -825,35 +911,6 @@ __global__ __launch_bounds__(256) void k_dec_select(const float* __restrict__ bl
     }
 }
 
-// ---- do two streams of this process really run at the same time?  Each side raises its own flag and waits (bounded, ~50 ms) for
-// the other's: both succeed only when the two kernels were resident together (the overlapped decode schedule relies on it)
-__global__ void k_dec_probe(int* mine, int* theirs, int* ok) {
-    if (threadIdx.x != 0) return;
-    __hip_atomic_store(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (unsigned spins = 0; spins < (1u << 17); ++spins) {
-        if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) { *ok = 1; return; }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    *ok = 0;
-}
-
-// ---- gate of a side stream (overlapped decode schedule): one wave that ends when `gate` carries `tag`, i.e. when this layer's
-// fused-QKV kernel has started.  The kernel BEHIND it in its stream (attention, O projection) then starts one in-queue kernel boundary
-// later (~2 us) — a cross-stream event takes 7-12 us to release its waiter on this platform (profiles/r05 timelines), and any
-// marker or completion event on the main stream costs 4-5 us of its critical path.  A gate only times the launch; the data
-// dependencies are the granule tags.  Bounded like every wait.
-// stride > 0: lane l looks at GEMV-layout element (l + 1) * stride - 1 instead (64 elements spread over the producer's blocks: "the
-// whole vector has been published", used in front of a gate|up launch whose time is sampled).
-__global__ void k_dec_gate(const unsigned long long* gate, unsigned tag, int* err, int stride, int n) {
-    const size_t pos = stride > 0 ? gran_pos_gemv(min(((int)threadIdx.x + 1) * stride, n) - 1) : 0;
-    unsigned spins = 0;
-    for (;;) {
-        const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(gate) + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((unsigned)(x >> 32) == tag)) return;
-        if (gran_spin_fail(spins, err)) return;
-    }
-}
-
 // ---- the global argmax alone (per-operator entry vh_lmhead_argmax): lowest index on ties, as torch.argmax ------------
 __global__ __launch_bounds__(256) void k_dec_pick(const float* __restrict__ blk_val, const int* __restrict__ blk_idx, int nblk,
                                                   int vocab, int* __restrict__ token_out, float* __restrict__ value_out) {
@@ -969,8 +1026,10 @@ __global__ __launch_bounds__(256) void k_decb_attn(const VhDecBatchAttn bt, floa
     const int b = blockIdx.z;
     const int nsplit = (bt.pos[b] + 1 + DA_KT - 1) / DA_KT;
     if ((int)blockIdx.y >= nsplit) return;
-    dec_attn_block<false>(blockIdx.x, blockIdx.y, nsplit, bt.qkv[b], kcache, vcache, bt.pos[b], bt.table[b], rope_cos, rope_sin,
-                          bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
+    DecAttnTile tile;
+    dec_attn_issue(blockIdx.x, blockIdx.y, kcache, vcache, bt.table[b], max_ctx, tile);
+    dec_attn_finish<false>(blockIdx.x, blockIdx.y, nsplit, tile, bt.qkv[b], kcache, vcache, bt.pos[b], bt.table[b], rope_cos, rope_sin,
+                           bt.part_o[b], bt.part_ml[b], bt.cnt[b], bt.attn_out[b], nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
 }
 
 // final RMSNorm + LM head + per-block argmax for every sequence of the batch (the 424 MB table is read once)
@@ -1059,30 +1118,14 @@ static inline VhXchg xchg_or_none(const VhXchg* x) {
     VhXchg z{};
     return x ? *x : z;            // world == 0: no exchange
 }
-static inline VhGranVec gran_or_none(const VhGranVec* g) {
-    VhGranVec z{};
-    return g ? *g : z;            // g == nullptr: plain buffers
-}
 
 template <int R, bool NORM>
 static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w,
-                           float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc, const VhGranVec* gin,
-                           const VhGranVec* gout, unsigned long long* gate = nullptr) {
-    const bool gr = NORM ? (gout != nullptr) : (gin != nullptr && gout != nullptr);
-    if ((gin || gout) && !gr) return -1;                 // the O projection takes granules on both sides or on neither
+                           float eps, const uint16_t* W, int N, int K, float* out, const VhXchg* xc) {
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        const dim3 grid((N + R - 1) / R);
-        if (gr) {
-            // the granule instantiations exist for K <= 4096 (two chunk slots per thread): beyond that the 128-register cap spills
-            if constexpr (NJ <= 2)
-                hipLaunchKernelGGL((k_dec_gemv<NJ, R, NORM, true>), grid, dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, W, N, K, out,
-                                   VhXchg{}, gran_or_none(gin), gran_or_none(gout), gate);
-            else return -1;
-        } else {
-            hipLaunchKernelGGL((k_dec_gemv<NJ, R, NORM, false>), grid, dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, W, N, K, out,
-                               xchg_or_none(xc), VhGranVec{}, VhGranVec{}, (unsigned long long*)nullptr);
-        }
+        hipLaunchKernelGGL((k_dec_gemv<NJ, R, NORM>), dim3((N + R - 1) / R), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, W, N, K, out,
+                           xchg_or_none(xc));
         return 0;
     });
 }
@@ -1101,43 +1144,74 @@ static int dec_gateup_grid(int I) {
     const int grid = 3 * cus / 2;
     return grid > n_iter ? n_iter : grid;
 }
+// grid of the fused attention-block launch: 2 persistent blocks per CU (its launch bounds), never more than it has items
+static int dec_ablk_grid(int total_items) {
+    const int g = 2 * vh_num_cus();
+    return total_items < g ? total_items : g;
+}
 // blocks of a consumer launch: the fused exchange's reducers are its first min(16, blocks) blocks
 int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
     (void)K;
     if (which == 0) return (N + DEC_GEMV_R - 1) / DEC_GEMV_R;
     if (which == 1) return dec_gateup_grid(I);
+    if (which == 3) return dec_ablk_grid(N);   // N: at least this many items (the O-projection rows / 8 alone)
     return N;   // LM head: the caller's grid
 }
 
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out, const VhXchg* cx, const VhGranVec* gout, unsigned long long* gate) {
-    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx, nullptr, gout, gate);
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx) {
+    return launch_dec_gemv<DEC_GEMV_R, true>(st, x_in, delta, x_out, norm_w, eps, W, N, K, out, cx);
+}
+
+int vhk_dec_ablk_supported(int H, int nq, int nkv) {
+    return H <= 4096 && H % 8 == 0 && nq * 128 <= 4096 && nkv >= 1 && nq % nkv == 0 && nq / nkv <= 4;
+}
+// rows per fused-QKV item: the smallest of 2 / 4 / 8 that covers the matrix in ONE round of the grid (tensor-parallel shards: the
+// highest blocks then have no QKV item and start with their attention tile); the released 6144-row matrix takes 1.5 rounds of 8 rows
+int vhk_dec_ablk(hipStream_t st, const VhDecAblk& a) {
+    if (!vhk_dec_ablk_supported(a.H, a.nq, a.nkv) || a.nsplit < 1 || a.nsplit > a.max_splits || !a.gq.g || !a.ga.g) return -1;
+    const int KO = a.nq * 128;
+    const int nA = a.nkv * a.nsplit, nO = (a.H + 7) / 8;
+    const int gmax = 2 * vh_num_cus();
+    int rq = 8;                                                     // (12 rows = the released q|k|v matrix in one round: 96 weight registers, spills)
+    for (int r : {2, 4, 8}) if ((a.nqkv + r - 1) / r <= gmax) { rq = r; break; }
+    if (a.H <= 2048) rq = 8;                                        // one chunk slot per thread: a single instantiation
+    const int total = (a.nqkv + rq - 1) / rq + nA + nO;
+    const dim3 grid(dec_ablk_grid(total));
+    auto launch = [&](auto nj, auto njo, auto r) {
+        hipLaunchKernelGGL((k_dec_ablk<decltype(nj)::value, decltype(njo)::value, decltype(r)::value>), grid, dim3(256), 0, st, a);
+        return 0;
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    auto by_o = [&](auto nj, auto r) { return KO <= 2048 ? launch(nj, I1{}, r) : launch(nj, I2{}, r); };
+    if (a.H <= 2048) return by_o(I1{}, std::integral_constant<int, 8>{});
+    switch (rq) {
+        case 2: return by_o(I2{}, std::integral_constant<int, 2>{});
+        case 4: return by_o(I2{}, std::integral_constant<int, 4>{});
+        default: return by_o(I2{}, std::integral_constant<int, 8>{});
+    }
 }
 
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table, const VhGranVec* gq, const VhGranVec* gout) {
+                 const int* table) {
     (void)pos_ptr;  // the kernel takes the position from the host mirror (ctx_host - 1)
     if (nq % nkv != 0 || nq / nkv > 4) return -1;
     const int nsplit = (ctx_host + DA_KT - 1) / DA_KT;
     if (nsplit < 1 || nsplit > max_splits || nsplit > 65535) return -1;
-    if ((gq != nullptr) != (gout != nullptr)) return -1;
-    if (gq) hipLaunchKernelGGL(k_dec_attn<true>, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
-                               rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, *gq, *gout);
-    else hipLaunchKernelGGL(k_dec_attn<false>, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
-                            rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale, VhGranVec{}, VhGranVec{});
+    hipLaunchKernelGGL(k_dec_attn, dim3(nkv, nsplit), dim3(256), 0, st, qkv, kcache, vcache, ctx_host - 1, table, rope_cos,
+                       rope_sin, part_o, part_ml, cnt, attn_out, nq, nkv, max_ctx, max_splits, scale);
     return 0;
 }
 
-int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px,
-                  const VhGranVec* gin, const VhGranVec* gout) {
-    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px, gin, gout);
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px) {
+    return launch_dec_gemv<DEC_GEMV_R, false>(st, attn_out, nullptr, nullptr, nullptr, 0.f, W, N, K, out, px);
 }
 
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cxp, const VhGranVec* gdelta) {
+                   float* hbuf, int grid, const VhXchg* cxp) {
     if (E > 8 || E < 2 || I % 4 != 0) return -1;
     const int n_iter = 2 * (I / 4);
     const VhXchg cx = xchg_or_none(cxp);
@@ -1145,15 +1219,8 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
     if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        if (gdelta) {                                    // the attention delta as granules (`delta` is ignored)
-            if constexpr (NJ <= 2)
-                hipLaunchKernelGGL((k_dec_gateup<NJ, 4, true>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
-                                   route_out, hbuf, VhXchg{}, *gdelta);
-            else return -1;
-        } else {
-            hipLaunchKernelGGL((k_dec_gateup<NJ, 4, false>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
-                               route_out, hbuf, cx, VhGranVec{});
-        }
+        hipLaunchKernelGGL((k_dec_gateup<NJ, 4>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
+                           route_out, hbuf, cx);
         return 0;
     });
 }
@@ -1193,15 +1260,6 @@ int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val
 int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out) {
     if (nblk < 1) return -1;
     hipLaunchKernelGGL(k_dec_pick, dim3(1), dim3(256), 0, st, blk_val, blk_idx, nblk, vocab, token_out, value_out);
-    return 0;
-}
-
-int vhk_dec_probe(hipStream_t st, int* mine, int* theirs, int* ok) {
-    hipLaunchKernelGGL(k_dec_probe, dim3(1), dim3(64), 0, st, mine, theirs, ok);
-    return 0;
-}
-int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err, int stride, int n) {
-    hipLaunchKernelGGL(k_dec_gate, dim3(1), dim3(64), 0, st, gate, tag, err, stride, n);
     return 0;
 }
 

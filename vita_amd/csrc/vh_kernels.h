@@ -28,14 +28,15 @@ struct VhTuning {
     int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange,
                                // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Chosen at bring-up by
                                // vita_amd.parallel (timed on the ranks' own devices; "kernel" whenever ranks share a device)
-    int dec_overlap = -1;      // batch-1 decode: 1 = overlapped schedule (attention and O projection on side streams behind gate kernels, their
-                               // inputs and outputs as tagged granules; needs streams that really run concurrently — probed once per
-                               // engine), 0 = one stream, five serial launches per layer, -1 = auto (overlapped where it measured a
-                               // gain: single-rank engines with expert slices of <= 7168 columns; serial for the full-size layer and under TP) (attention and O projection on side streams, their inputs
-                               // and outputs as tagged granules: a kernel's launch, weight / K-V loads and prologue run under its
-                               // predecessor; needs streams that really run concurrently — probed once per engine), 0 = one stream
-    int comm_allow_coarse = 0; // vh_comm_create: 1 = the ranks share ONE device, a coarse-grained receive buffer is acceptable when the
-                               // fine-grained allocation fails (same-device tests); 0 = fail loudly instead
+    int dec_fused = -1;        // batch-1 decode, attention block of a layer: 1 = ONE launch (k_dec_ablk: fused QKV GEMV -> split-KV attention -> O projection on
+                               // 2 persistent blocks per CU, q|k|v and the attention output handed over as tagged granules, the O / next weights
+                               // in flight under the attention), 0 = three launches (QKV, attention, O), -1 = auto (fused whenever H and the
+                               // heads' width are <= 4096, i.e. always for the released geometry at any TP degree)
+    int comm_allow_coarse = 0; // vh_comm_create: 1 = a coarse-grained receive buffer is acceptable when the fine-grained allocation fails (only
+                               // correct when every rank drives ONE device: same-device tests); 0 = fail loudly instead
+    int comm_ranks_per_device = 1;   // vh_comm_create: ranks that drive THIS rank's device (vita_amd.parallel counts them from the devices' PCI
+                               // identities): the bulk all-reduce divides its resident-block cap by it, and ranks that share a device
+                               // never get the exchange fused into the decode kernels (a waiting consumer grid would hold the CUs a peer's producer needs)
 };
 VhTuning* vh_tuning();
 
@@ -59,15 +60,16 @@ struct VhXchg {
     int rank, world;
     unsigned tag;
     int target, nred, count;
+    int loopback;                   // 1: one rank plays all `world` ranks (every peer[] is the local region): the value goes to slot `rank`,
+                                    // zeros to the other slots — the same stores, polls and rank-ordered sum as a real exchange, no link
 };
 
-// ---- decode activation vectors handed between kernels that are RESIDENT AT THE SAME TIME (overlapped launches) ----
-// The batch-1 decode step runs its attention and O-projection kernels on side streams so that a kernel's launch, its weight /
-// K-V-tile loads and its prologue sit under its predecessor's execution instead of behind a kernel boundary.  The stream order no
-// longer carries the data dependency; the data does: every element of the vector travels as ONE naturally aligned 8-byte
-// {tag, fp32 bits} granule written and read with agent-scope atomics (guide G16 R2: the data is the flag — no fence, no flag word;
-// the same form VhXchg uses across devices).  tag = a per-engine counter that is different for every (step, layer, vector); 0 is
-// never used (the buffers start zeroed).  g == nullptr: the plain fp32 buffer of the serial schedule.
+// ---- decode activation vectors handed between work items of ONE launch (the fused attention block, k_dec_ablk) ----------------
+// The fused-QKV rows, the split-KV attention tiles and the O-projection rows of a layer are items of one persistent launch; an item
+// that consumes another item's output is resident — its weights or K / V tile in flight — while the producer still runs.  The data
+// carries the dependency: every element travels as ONE naturally aligned 8-byte {tag, fp32 bits} granule written and read with
+// agent-scope atomics (guide G16 R2: the data is the flag — no fence, no flag word; the form VhXchg uses across devices).
+// tag = a per-engine counter that is different for every (step, layer, vector); 0 is never used (the buffers start zeroed).
 //   layout 0 (VH_GRAN_LINEAR): element n in granule n (attention reads q / k / v of a head by lane)
 //   layout 1 (VH_GRAN_GEMV):   the consumer is a GEMV block whose thread t owns the 16-byte weight chunks t + 256 j, i.e. elements
 //                              [8 (t + 256 j), + 8): element n = 8 (t + 256 j) + e sits in granule (8 j + e) * 256 + t, so that the
@@ -83,24 +85,34 @@ __host__ __device__ inline size_t vh_gran_gemv_len(int K) { return (size_t)((K +
 
 struct vh_comm;
 int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, VhXchg* out, void* stream);   // vh_comm.hip
-int vh_comm_allreduce_gran(vh_comm* c, const VhGranVec* gin, const VhGranVec* gout, long count, void* stream);   // vh_comm.hip: one-shot all-reduce, granules in and out
-int vh_comm_ranks_share_device(const vh_comm* c);   // declared at creation (tests): every rank drives this device
+int vh_comm_ranks_per_device(const vh_comm* c);   // declared at creation: ranks that drive this rank's device (1 on a node with a GPU per rank)
+int vh_comm_is_loopback(const vh_comm* c);        // a single-rank communicator that plays `world` ranks into its own slots (bench: protocol cost without links)
 
 // ---- decode (vh_decode.hip) ---------------------------------------------------------
 // cx (nullable): the delta is the result of a fused exchange (then `delta` is ignored); px (nullable): push the outputs
 int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
-                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr, const VhGranVec* gout = nullptr,   // gout: LINEAR granules instead of `out`
-                unsigned long long* gate = nullptr);   // gate (with gout): word that block 0 sets to {gout->tag, 1} when the kernel starts
-int vhk_dec_consumer_blocks(int which, int N, int K, int I);   // grid of a consumer launch (0 qkv, 1 gate|up, 2 lm head): bounds nred
+                const uint16_t* W, int N, int K, float* out, const VhXchg* cx = nullptr);
+int vhk_dec_consumer_blocks(int which, int N, int K, int I);   // grid of a consumer launch (0 qkv, 1 gate|up, 2 lm head, 3 fused attention block): bounds nred
 int vhk_dec_attn(hipStream_t st, const float* qkv, float* kcache, float* vcache, const int* pos_ptr,
                  const float* rope_cos, const float* rope_sin, float* part_o, float* part_ml, int* cnt,
                  float* attn_out, int nq, int nkv, int max_ctx, int max_splits, int ctx_host, float scale,
-                 const int* table,    // table: nullable page table of a paged KV cache (64-token pages)
-                 const VhGranVec* gq = nullptr, const VhGranVec* gout = nullptr);   // gq: qkv as linear granules; gout: attn_out as GEMV-layout granules
-int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr,
-                  const VhGranVec* gin = nullptr, const VhGranVec* gout = nullptr);   // both in the GEMV layout (of K resp. of the consumer's K = N)
-int vhk_dec_gate(hipStream_t st, const unsigned long long* gate, unsigned tag, int* err, int stride = 0, int n = 0);   // one wave that ends when *gate
-                                                              // carries tag (stride > 0: when 64 spread elements of an n-element GEMV-layout vector do)
+                 const int* table);   // table: nullable page table of a paged KV cache (64-token pages)
+int vhk_dec_oproj(hipStream_t st, const float* attn_out, const uint16_t* W, int N, int K, float* out, const VhXchg* px = nullptr);
+// The attention block of one decode layer as ONE launch (k_dec_ablk): out[H] = Wo * attention(RoPE(Wqkv * rmsnorm(x_in + delta))), the
+// new K / V row appended to the cache, x_out = x_in + delta.  cx (world > 0): delta is the result of a fused exchange; px (world > 0):
+// the outputs are pushed to the peers instead of stored.  gq / ga: granule vectors of nqkv (linear) / vh_gran_gemv_len(nq * 128)
+// (GEMV layout) elements with tags no earlier launch used.
+struct VhDecAblk {
+    const float* x_in; const float* delta; float* x_out; const float* norm_w; float eps;
+    const uint16_t* Wqkv; int nqkv, H;
+    float* kcache; float* vcache; int pos; const int* table; const float* rope_cos; const float* rope_sin;
+    float* part_o; float* part_ml; int* cnt; int nq, nkv, max_ctx, max_splits, nsplit; float scale;
+    const uint16_t* Wo; float* out;
+    VhGranVec gq, ga;
+    VhXchg cx, px;
+};
+int vhk_dec_ablk(hipStream_t st, const VhDecAblk& a);
+int vhk_dec_ablk_supported(int H, int nq, int nkv);   // 1 when k_dec_ablk has an instantiation for these widths
 // ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
 #define VH_BMAX 4
 struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
@@ -121,7 +133,7 @@ int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w
                     const VhDecBatchHead& hd, int grid, int v0);
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
-                   float* hbuf, int grid, const VhXchg* cx = nullptr, const VhGranVec* gdelta = nullptr);   // gdelta: `delta` as GEMV-layout granules
+                   float* hbuf, int grid, const VhXchg* cx = nullptr);
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,
                  const VhXchg* px = nullptr);
 int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const float* norm_w, float eps,
@@ -130,7 +142,6 @@ int vhk_dec_lmhead(hipStream_t st, const float* x_in, const float* delta, const 
 int vhk_dec_cand(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, float* cand, int rank, int world);
 int vhk_dec_cand_unpack(hipStream_t st, const float* cand, int world, float* val, int* idx);
 int vhk_dec_pick(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, int vocab, int* token_out, float* value_out);
-int vhk_dec_probe(hipStream_t st, int* mine, int* theirs, int* ok);   // stream-concurrency probe: raises *mine, waits (bounded) for *theirs
 int vhk_dec_select(hipStream_t st, const float* blk_val, const int* blk_idx, int nblk, const uint16_t* embed, int H,
                    int vocab, float* x_next, int* pos_ptr, int* ngen_ptr, int* out_tokens, int max_out, int mode, int set_pos);
 

@@ -184,10 +184,11 @@ class MixtralEngine:
         check(self.lib.vh_mixtral_decode(self.h, int(n_steps), self._stream()), "vh_mixtral_decode")
         self.n_gen += int(n_steps)
 
-    def overlap_state(self):
-        """schedule of the last decode call: -1 none yet, 0 one stream with five serial launches per layer (vh_tune("dec_overlap", 0),
-        tensor-parallel engine, or side streams that do not run concurrently), 1 overlapped (attention / O projection on gated side streams)."""
-        return int(self.lib.vh_mixtral_decode_overlap_state(self.h))
+    def decode_schedule(self):
+        """how the attention block of the last decode call ran: "fused-attention-block" (ONE launch per layer: fused QKV ->
+        split-KV attention -> O projection as work items with granule hand-offs, the default), "three-launches"
+        (vh_tune("dec_fused", 0) or widths without an instantiation) or "none" before the first decode call."""
+        return {1: "fused-attention-block", 0: "three-launches"}.get(int(self.lib.vh_mixtral_decode_schedule(self.h)), "none")
 
     def reset(self):
         """forget the current request: position and generated-token counters to zero, every KV page back to the pool

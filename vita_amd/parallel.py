@@ -64,15 +64,25 @@ class IpcComm:
     """The library's own all-reduce over IPC-mapped peer buffers (include/vita_hip.h vh_comm_*): create on every rank,
     exchange the 64-byte handles through any bootstrap channel, connect, then allreduce(tensor) in lock step."""
 
-    def __init__(self, rank, world, cap_elems, same_device=False):
+    def __init__(self, rank, world, cap_elems, same_device=False, ranks_per_device=None, loopback=False):
         """same_device: every rank runs on ONE GPU (tests): only then may the library fall back to a coarse-grained receive
-        buffer when fine-grained (peer-coherent) memory cannot be allocated; across devices it refuses instead."""
+        buffer when fine-grained (peer-coherent) memory cannot be allocated; across devices it refuses instead.
+        ranks_per_device: how many ranks drive THIS rank's GPU (default: world when same_device, else 1) — the bulk all-reduce
+        divides its resident-block cap by it.  loopback: a single-process communicator in which this rank plays all `world`
+        ranks into its own receive slots (vh_comm_create_loopback: protocol cost of the decode exchanges without a link)."""
         from . import _lib
         self.lib = _lib.load()
         _lib.tune("comm_allow_coarse", 1 if same_device else 0)
+        if ranks_per_device is None:
+            ranks_per_device = world if same_device else 1
+        _lib.tune("comm_ranks_per_device", 1 if loopback else max(1, int(ranks_per_device)))
         self._handle = ctypes.create_string_buffer(64)
-        self.rank, self.world = int(rank), int(world)
-        self.ptr = self.lib.vh_comm_create(self.rank, self.world, int(cap_elems), self._handle)
+        self.rank, self.world, self.loopback = int(rank), int(world), bool(loopback)
+        self.ranks_per_device = 1 if loopback else max(1, int(ranks_per_device))
+        if loopback:
+            self.ptr = self.lib.vh_comm_create_loopback(self.rank, self.world, int(cap_elems))
+        else:
+            self.ptr = self.lib.vh_comm_create(self.rank, self.world, int(cap_elems), self._handle)
         if not self.ptr:
             raise _lib.VitaHipError("vh_comm_create failed: " + (self.lib.vh_comm_last_error() or b"").decode())
 
@@ -132,12 +142,19 @@ def device_identity(device):
             os.environ.get("CUDA_VISIBLE_DEVICES", ""), idx)
 
 
-def ranks_share_one_device(dist, device, world):
-    """True when every rank of the group drives the same physical GPU."""
+def ranks_on_my_device(dist, device, world):
+    """(n, max_n): how many ranks of the group drive THIS rank's physical GPU, and the largest such count over the group
+    (collective).  n == world: every rank shares one device (tests); max_n == 1: a GPU per rank (a node)."""
     me = device_identity(device)
     all_ = [None] * world
     dist.all_gather_object(all_, me)
-    return all(a == all_[0] for a in all_)
+    counts = [sum(1 for b in all_ if b == a) for a in all_]
+    return counts[all_.index(me)], max(counts)
+
+
+def ranks_share_one_device(dist, device, world):
+    """True when every rank of the group drives the same physical GPU."""
+    return ranks_on_my_device(dist, device, world)[0] == world
 
 
 def vote_decode_exchange(dist, same_device, t_kernel_ms, t_fused_ms, fused_ok, device="cpu", backend="gloo", margin=0.02):
@@ -245,9 +262,12 @@ def ipc_allreduce(eng, rank, world, dist, device, backend):
     rank's self-test passed (the engine then routes its all-reduces through it)."""
     comm, ok = None, 0
     same = False
+    shared = False
     try:
-        same = ranks_share_one_device(dist, device, world)
-        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden, same_device=same)
+        mine, most = ranks_on_my_device(dist, device, world)
+        same = mine == world                  # every rank on ONE device: a coarse-grained receive buffer would still be correct
+        shared = most > 1                     # SOME ranks share a device (e.g. 8 ranks on 4 GPUs): no exchange fused into the kernels
+        comm = IpcComm(rank, world, eng.max_prefill * eng.c.hidden, same_device=same, ranks_per_device=mine)
         from . import _lib
         _lib.tune("tp_fuse", 0)                      # the self-test below and the trial start from the kernel form
         handles = [None] * world
@@ -285,7 +305,7 @@ def ipc_allreduce(eng, rank, world, dist, device, backend):
         return False
     eng.attach_comm(comm)
     # which form the batch-1 decode exchange takes is measured here, on the ranks' own devices, and agreed by all ranks
-    eng.decode_exchange = choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same)
+    eng.decode_exchange = choose_decode_exchange(eng, comm, rank, world, dist, device, backend, same or shared)
     if not _agree(dist, comm.status() == 0, device, backend):
         # a trial that timed out leaves the communicator's error word set (sticky): no IPC collective for this job
         eng.attach_comm(None)
