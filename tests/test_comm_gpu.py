@@ -172,7 +172,7 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     from oracle import mixtral as om
     from vita_amd.checkpoint import synth_state_dict
     ret = mp.Manager().dict()
-    mp.spawn(_tp_worker, args=(world, _free_port(), 1, ret), nprocs=world, join=True)
+    mp.spawn(_tp_worker, args=(world, _free_port(), 1, ret, -1), nprocs=world, join=True)   # fuse = -1: the ranks choose the exchange form
     cfg = _tp_cfg(world)
     sd = synth_state_dict(cfg, seed=3, parts=("text",))
     rng = np.random.default_rng(5)
@@ -220,9 +220,11 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
         assert ret[0][5] == ret[1][5] and ret[0][5] in ("fused", "kernel"), (ret[0][5], ret[1][5])
     else:
         assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
-    # every case runs the default decode schedule of a tensor-parallel rank: the attention block as ONE launch (k_dec_ablk), with the
-    # exchange fused into it (consumer of the MoE exchange at its head, producer of the attention exchange in its O items) or as kernels
-    assert ret[0][6] == ret[1][6] == "fused-attention-block", (ret[0][6], ret[1][6])
+    # the default decode schedule of a tensor-parallel rank is the attention block as ONE launch (k_dec_ablk); only ranks that SHARE a
+    # device with the exchange FORCED into the kernels keep the three small launches (a waiting k_dec_ablk grid owns its CUs' register
+    # files: the peer it waits for would find no CU).  The fused exchange INSIDE k_dec_ablk is covered by test_loopback_* below.
+    want = "three-launches" if ret[0][5] == "fused" else "fused-attention-block"
+    assert ret[0][6] == ret[1][6] == want, (ret[0][5], ret[0][6], ret[1][6])
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
     assert ret[0][1] == ret[1][1] == ref_ids
@@ -328,3 +330,49 @@ def test_tp_released_shard_shapes_match_oracle(dev, world, layers):
     err = float(np.abs(ret[0][2] - ref["logits"]).max())
     print(f"TP = {world} released shard shapes, {layers} layers: ids {toks} == oracle, max |logit diff| {err:.2e}")
     assert err < 1e-3
+
+
+# ---- the exchange fused into the decode kernels INCLUDING the fused attention block, in one process ----------------------------------
+@pytest.mark.parametrize("world,exchange", [(8, "fused"), (4, "fused"), (2, "fused"), (8, "kernel")])
+def test_loopback_exchange_is_bit_identical_to_no_exchange(dev, world, exchange):
+    """A loop-back communicator (vh_comm_create_loopback) makes ONE rank play `world` ranks into its own receive slots: every
+    exchange of the decode step runs — the pushes of the O-projection items of k_dec_ablk and of the down projection, the
+    rank-ordered reduction by the first blocks of gate|up / the next attention block / the LM head, tags, parity regions, arrival
+    counters; or one all-reduce kernel per exchange — and the peers' contributions are zeros, so every sum must equal its input
+    EXACTLY: ids and logits bit-identical to the same engine without a communicator.  This is the form a rank that owns its GPU
+    runs (the fused exchange inside the fused attention block); with several processes on ONE device it cannot be scheduled.
+    Released TP = 8 / 4 / 2 shard shapes (one rank's slices), 2 layers, 40-token prompt, 12 steps across a 64-key tile boundary."""
+    from vita_amd import _lib
+    from vita_amd.checkpoint import synth_mixtral_device
+    from vita_amd.config import VitaConfig
+    from vita_amd.engine import MixtralEngine
+    from vita_amd.parallel import IpcComm
+    cfg = VitaConfig()
+    cfg.text.num_hidden_layers = 2
+    packed = synth_mixtral_device(cfg, dev, seed=0, rank=0, world=world)
+    ids = np.random.default_rng(17).integers(3, cfg.text.vocab_size, size=58).tolist()
+    emb = packed["embed"][torch.as_tensor(ids, device=dev)].float()
+    runs = []
+    for loop in (False, True):
+        eng = MixtralEngine(cfg, packed, dev, max_ctx=128, max_prefill=64, max_new=16, logit_rows=16)
+        comm = None
+        if loop:
+            comm = IpcComm(0, world, cfg.text.hidden_size, loopback=True)
+            eng.attach_comm(comm)
+            _lib.tune("tp_fuse", 1 if exchange == "fused" else 0)
+        try:
+            eng.prefill(emb)
+            eng.decode(12)
+            torch.cuda.synchronize()
+            runs.append((eng.generated(), eng.logits_all[:13].clone(), eng.decode_schedule(), comm.status() if comm else 0))
+        finally:
+            _lib.tune("tp_fuse", 0)
+            eng.close()
+            if comm:
+                comm.destroy()
+    assert runs[0][2] == runs[1][2] == "fused-attention-block"
+    assert runs[1][3] == 0, f"exchange spin time-out (phase {runs[1][3]})"
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    # the vocab-sharded head: the loop-back run scores this rank's rows only; they must equal the same rows of ... the same run without
+    # a communicator scores the same shard (the engine is built from the shard's packed weights either way)
+    assert torch.equal(runs[0][1], runs[1][1])

@@ -58,6 +58,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "comm_allow_coarse")) { g_tuning.comm_allow_coarse = value; return VH_OK; }
     if (!strcmp(key, "comm_ranks_per_device")) { g_tuning.comm_ranks_per_device = value; return VH_OK; }
     if (!strcmp(key, "dec_fused")) { g_tuning.dec_fused = value; return VH_OK; }
+    if (!strcmp(key, "dec_gateup_grid")) { g_tuning.dec_gateup_grid = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -308,6 +309,7 @@ struct vh_mixtral {
     // prefill scratch
     float *px, *pxn, *pqkv, *pq, *pattn, *py, *ptmp, *pwts;
     uint16_t *pxn_hi, *pxn_lo, *ph_hi, *ph_lo;   // bf16 hi/lo planes feeding the pre-split MoE GEMMs
+    unsigned char* kv_img = nullptr; int img_tiles = 0;   // K / V tile images (VhAttnArgs::kv_img) of a one-shot prefill
     int *pids, *pgoff, *pstok, *psslot, *pnslab;
     // ---- concurrent sequences over a paged KV cache (vLLM's block tables).  The KV pool above is cut into
     // 64-token pages (= one decode-attention tile); a sequence owns a page table, a residual-stream state, its counters
@@ -401,6 +403,10 @@ struct vh_mixtral {
         pids = cv.take<int>(2 * Sm); pgoff = cv.take<int>(E + 1);
         pstok = cv.take<int>(2 * Sm); psslot = cv.take<int>(2 * Sm);
         pnslab = cv.take<int>(4);
+        // K / V tile images of a one-shot prefill for the flash attention kernel (64 KB per KV head and 64-row tile; only when the
+        // head grouping is the 4 : 1 that kernel serves)
+        img_tiles = (nq == 4 * nkv && hd == 128) ? (c.max_prefill + 63) / 64 : 0;
+        kv_img = img_tiles ? cv.take<unsigned char>((size_t)nkv * img_tiles * 65536) : nullptr;
         // ---- decode state ------------------------------------------------------------------------------------------
         xa = cv.take<float>(H); xb = cv.take<float>(H);
         delta_attn = cv.take<float>(H); delta_moe = cv.take<float>(H);
@@ -698,6 +704,13 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     // vh_tune("prefill_fuse_rows", 0) restores the separate slab-sum / combine launches
     const bool fuse_rows = !tp && vh_tuning()->prefill_fuse_rows != 0 && stream_attn;
     const bool attn_planes = stream_attn && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
+    // (r06) one-shot prefills whose attention is the flash kernel get K / V as MFMA-ready tile images from the RoPE pass
+    bool use_img = false;
+    if (stream_attn && pos0 == 0 && m->kv_img && (Sn + 63) / 64 <= m->img_tiles) {
+        VhAttnArgs q{};
+        q.Sq = Sn; q.Sk = Sn; q.d = hd; q.Hq = nq; q.Hkv = nkv; q.B = 1; q.causal = 1;
+        use_img = vhk_attn_fa_applies(q) != 0;
+    }
     bool combine_pending = false;
     int pend_nslab = 1;
     const int* pend_nslab_dev = nullptr;
@@ -725,8 +738,12 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             g.W = w.wqkv; g.ldw = H; g.C = m->py; g.ldc = m->nqkv; g.M = Sn; g.N = m->nqkv; g.K = H;
             g.ksplit = -qkv_slabs; g.c_split_stride = (long)Sm * m->nqkv; g.nslab_out = m->pnslab + 1;
             VH_TRY(vhk_gemm_ps(st, g), "qkv gemm");
-            VH_TRY(vhk_rope_kv(st, m->py, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
-                               m->c.max_ctx, m->table, m->pnslab + 1, g.c_split_stride), "rope");
+            if (use_img)   // one-shot prefill under the flash kernel: RoPE + cache write + the K / V tile images in one pass
+                VH_TRY(vhk_rope_kv_img(st, m->py, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, nq, nkv, m->c.max_ctx,
+                                       m->table, m->pnslab + 1, g.c_split_stride, m->kv_img, m->img_tiles), "rope + images");
+            else
+                VH_TRY(vhk_rope_kv(st, m->py, m->nqkv, m->pq, kc, vc, m->rope_cos, m->rope_sin, Sn, pos0, nq, nkv,
+                                   m->c.max_ctx, m->table, m->pnslab + 1, g.c_split_stride), "rope");
         } else {
             VH_TRY(vhk_rmsnorm(st, m->px, m->pxn, w.attn_norm, Sn, H, m->c.rms_eps), "rmsnorm");
             VhGemmArgs g{};
@@ -745,6 +762,7 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
             a.B = 1; a.Hq = nq; a.Hkv = nkv; a.Sq = Sn; a.Sk = pos0 + Sn; a.d = hd;
             a.causal = 1; a.q_off = pos0; a.klen = pos0 + Sn; a.chunk = 0; a.left = -1; a.scale = scale;
             a.ktable = m->table; a.kv_rows = m->c.max_ctx;
+            if (use_img) { a.kv_img = m->kv_img; a.img_tiles = m->img_tiles; }
             if (attn_planes) { a.O = nullptr; a.O_hi = m->ph_hi; a.O_lo = m->ph_lo; a.ldo_split = (long)nq * hd; }
             VH_TRY(vhk_attn(st, a), "attention");
         }
@@ -1067,7 +1085,9 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
     const float eps = m->c.rms_eps;
     const bool fuse = m->comm != nullptr && m->exchanges() && vh_tuning()->tp_fuse != 0 && (H % 2) == 0 &&
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
-    const bool fused_attn = fused_wanted(m);
+    // (ranks SHARING a device with the exchange forced into the kernels — tests — keep the three small launches: a resident k_dec_ablk
+    // grid owns its CUs' whole register files, and one that waits for a peer's pushes would leave that peer's kernels no CU to run on)
+    const bool fused_attn = fused_wanted(m) && !(fuse && vh_comm_ranks_per_device(m->comm) > 1);
     m->schedule_state = fused_attn ? 1 : 0;
     int* err = m->counters + 3;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer

@@ -537,7 +537,18 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
 // 34 us at S = 552.)  The arithmetic per 32-key half tile (products, softmax, accumulation order) is the direct kernel's.
 // Measured (profiles/r04_attn_fa_v2.jsonl): S = 552 46.8 -> 34.3 us, S = 2344 468 -> 310 us.  A d = 64 instantiation for the ViT
 // (block = one head x 64 / 128 rows) was built and measured too: 50-63 vs 47 us on one image, a tie on eight — not kept.
-template <int MODE>
+// IMG (r06): the tiles arrive as the producer's MFMA-ready images (VhAttnArgs::kv_img, written by k_rope_kv_img in this kernel's own
+// LDS layout): a tile is 8 LDS-DMA pieces of 16 B per thread straight into the buffer (global_load_lds: no staging registers, no
+// conversion, no ds_write — a third of the IMG = false kernel, profiles/r04_attn_fa_ablate.txt), issued for tile t + 1 at the head of
+// tile t into the buffer everyone left at the barrier before, waited for (counted vmcnt, inline asm: hipcc does not see these loads)
+// in front of the barrier that ends tile t.
+__device__ __forceinline__ void fa_glds16(const unsigned char* base, uint32_t off, unsigned char* lds_dst) {
+    const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+}
+template <int MODE, bool IMG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_attn_fa(const VhAttnArgs p) {
     constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
@@ -640,7 +651,18 @@ void k_attn_fa(const VhAttnArgs p) {
         }
     };
 
-    if (ntiles > 0) {
+    // IMG: tile `tile` of this KV head -> buffer `buf` (every thread moves 8 x 16 B; a wave instruction fills 1 KB of the image)
+    const unsigned char* img_head = IMG ? p.kv_img + (size_t)hk * p.img_tiles * (4 * PL) : nullptr;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    auto dma_tile = [&](int tile, unsigned char* buf) __attribute__((always_inline)) {
+        const unsigned char* src = img_head + (size_t)tile * (4 * PL);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa_glds16(src, (uint32_t)((i * 512 + tid) * 16), buf + (i * 512 + wu * 64) * 16);
+    };
+    if (IMG) {
+        if (ntiles > 0) dma_tile(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (ntiles > 0) {
         load_part(0, 0); load_part(1, 0);
         store_part(0, lds); store_part(1, lds);
         const int k1 = ntiles > 1 ? 64 : 0;
@@ -655,6 +677,7 @@ void k_attn_fa(const VhAttnArgs p) {
         unsigned char* nbuf = lds + ((t + 1) & 1) * 4 * PL;              // last read in tile t - 1: everyone is past it
         const bool more = t + 1 < ntiles;
         const int knext = min(t + 2, ntiles - 1) * 64;                  // (clamped: the last tile is simply re-read)
+        if (IMG && more) dma_tile(t + 1, nbuf);                        // lands under this tile's products and softmax
         if (kt0 < kloop) {                                            // (wave-uniform) this half tile has a visible key
             // ---- S = Q K^T for the two 16-key sub-tiles ------------------------------------------------------------------------
             f32x4 sacc[2];
@@ -677,10 +700,12 @@ void k_attn_fa(const VhAttnArgs p) {
             // conversion + LDS writes of the NEXT tile here, behind the 24 MFMAs of S that the matrix pipe is still working through, and the
             // reload for the tile after next right behind them: every load has a whole tile period to land.  (Splitting the staging in two
             // — half here, half behind the PV products — made hipcc wait vmcnt(0) here for the half reloaded a quarter tile earlier.)
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) { store_part(0, nbuf); store_part(1, nbuf); }
-            load_part(0, knext); load_part(1, knext);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!IMG) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { store_part(0, nbuf); store_part(1, nbuf); }
+                load_part(0, knext); load_part(1, knext);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- online softmax in D layout (the direct kernel's) --------------------------------------------------------------
             const bool full_tile = kt0 + AT_KT <= (CAUSAL ? min(kend, q0 + p.q_off + 1) : kend);
             float alpha[4];
@@ -727,10 +752,11 @@ void k_attn_fa(const VhAttnArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else {
+        } else if (!IMG) {
             if (more) { store_part(0, nbuf); store_part(1, nbuf); }
             load_part(0, knext); load_part(1, knext);
         }
+        if (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 1 have landed
         __syncthreads();
     }
 
@@ -785,6 +811,14 @@ void k_attn_fa(const VhAttnArgs p) {
 
 }  // namespace
 
+// would vhk_attn run the flash kernel for these arguments?  (the prefill asks before it spends a pass on the K / V tile images)
+int vhk_attn_fa_applies(const VhAttnArgs& a) {
+    if (a.Sq <= 0 || a.Sk <= 0 || a.P != nullptr || a.d != 128 || a.Hq != 4 * a.Hkv || a.chunk > 0) return 0;
+    if (vh_tuning()->attn_impl != 0 || vh_tuning()->attn_fa == 0) return 0;
+    const long blocks = (long)((a.Sq + 15) / 16) * a.Hkv * a.B;
+    return (vh_tuning()->attn_fa == 2 || blocks * 2 >= vh_num_cus()) ? 1 : 0;
+}
+
 int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
     if (a.Sq <= 0 || a.Sk <= 0 || a.Hq % a.Hkv != 0) return -1;
     const bool rel = a.P != nullptr;
@@ -822,9 +856,13 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
             if (fa != 0 && a.d == 128 && a.Hq == 4 * a.Hkv) {
                 const dim3 gf((a.Sq + 15) / 16, a.Hkv, a.B);
                 if (fa == 2 || (long)gf.x * gf.y * gf.z * 2 >= vh_num_cus()) {
-                    if (mode == 0) hipLaunchKernelGGL((k_attn_fa<0>), gf, dim3(512), 0, st, a);
-                    else if (mode == 1) hipLaunchKernelGGL((k_attn_fa<1>), gf, dim3(512), 0, st, a);
-                    else hipLaunchKernelGGL((k_attn_fa<2>), gf, dim3(512), 0, st, a);
+                    // producer-side K / V tile images: one-shot causal prefills only (every key of the call was written by this pass)
+                    const bool img = a.kv_img != nullptr && mode >= 1 && a.q_off == 0 && a.Sk == a.Sq && a.B == 1 && a.klen >= a.Sk &&
+                                     a.img_tiles >= (a.Sk + 63) / 64 && (reinterpret_cast<uintptr_t>(a.kv_img) & 15) == 0;
+                    if (img) hipLaunchKernelGGL((k_attn_fa<1, true>), gf, dim3(512), 0, st, a);
+                    else if (mode == 0) hipLaunchKernelGGL((k_attn_fa<0, false>), gf, dim3(512), 0, st, a);
+                    else if (mode == 1) hipLaunchKernelGGL((k_attn_fa<1, false>), gf, dim3(512), 0, st, a);
+                    else hipLaunchKernelGGL((k_attn_fa<2, false>), gf, dim3(512), 0, st, a);
                     return 0;
                 }
             }

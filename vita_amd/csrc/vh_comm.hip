@@ -97,8 +97,27 @@ __global__ __launch_bounds__(256) void k_ar_oneshot(float* __restrict__ buf, lon
         // loopback: this rank plays all of them — its value into slot `rank`, the peers' (zero) contributions into theirs
         if (loopback) for (int p = 0; p < world; ++p) put(local + (size_t)p * cap + i, tag, p == rank ? v : 0.f);
         else for (int p = 0; p < world; ++p) put(peers.p[p] + (size_t)rank * cap + i, tag, v);
+        // all `world` slots of the element polled TOGETHER (r01-r05: one after the other — `world` dependent round trips to the
+        // uncached receive buffer); a look that finds a tag missing re-reads every slot after a short sleep
+        u64 g[VH_COMM_MAX_WORLD];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < VH_COMM_MAX_WORLD; ++r)
+                if (r < world) g[r] = __hip_atomic_load(reinterpret_cast<const u64*>(local + (size_t)r * cap + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int r = 0; r < VH_COMM_MAX_WORLD; ++r)
+                if (r < world) ok = ok && ((uint32_t)(g[r] >> 32) == tag);
+            if (ok) break;
+            if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (++spins > VH_COMM_SPIN_LIMIT) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
         float s = 0.f;
-        for (int r = 0; r < world; ++r) s += get(local + (size_t)r * cap + i, tag, err, 1);   // rank order: same sum everywhere
+#pragma unroll
+        for (int r = 0; r < VH_COMM_MAX_WORLD; ++r)
+            if (r < world) s += __uint_as_float((uint32_t)g[r]);   // rank order: same sum everywhere
         buf[i] = s;
     }
 }

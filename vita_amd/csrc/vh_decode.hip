@@ -54,39 +54,44 @@ __device__ __forceinline__ void xchg_put(const VhXchg& px, int n, float v) {
     for (int p = 0; p < px.world; ++p)
         __hip_atomic_store(reinterpret_cast<xu64*>(px.peer[p] + (size_t)px.rank * px.cap + n), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ float xchg_get(const uint64_t* p, unsigned tag, int* err) {
-    unsigned spins = 0;
-    for (;;) {
-        const xu64 x = __hip_atomic_load(reinterpret_cast<const xu64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(x >> 32) == tag) return __uint_as_float((unsigned)x);
-        if ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0.f;
-        if (++spins > VH_XCHG_SPIN_LIMIT) { __hip_atomic_store(err, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0.f; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
 // consumer, step 1 (BEFORE the block's own weight loads, so that nothing of its own is queued in front of the polls): the
-// first nred blocks sum their slice over the ranks, in rank order, and publish it
+// first nred blocks sum their slice over the ranks, in rank order, and publish it.
+// r06: ONE element per thread and all `world` slots of it polled TOGETHER (r03-r05: a pair per thread and the 2 x world granules one
+// after the other — sixteen dependent round trips to the uncached receive buffer per exchange: the consumer kernels ran 7 us longer
+// than without an exchange, profiles/r06 call 1); a look that finds a tag missing re-reads all slots after a short sleep.
 __device__ __forceinline__ void xchg_reduce(const VhXchg& cx) {
     if (cx.world == 0 || (int)blockIdx.x >= cx.nred) return;
-    const int pairs = cx.count >> 1;
-    const int per = (pairs + cx.nred - 1) / cx.nred;
-    const int p1 = min(pairs, ((int)blockIdx.x + 1) * per);
-    for (int q = blockIdx.x * per + threadIdx.x; q < p1; q += blockDim.x) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < cx.world; ++r) {
-            s0 += xchg_get(cx.local + (size_t)r * cx.cap + 2 * q, cx.tag, cx.err);
-            s1 += xchg_get(cx.local + (size_t)r * cx.cap + 2 * q + 1, cx.tag, cx.err);
+    const int per = (cx.count + cx.nred - 1) / cx.nred;
+    const int n1 = min(cx.count, ((int)blockIdx.x + 1) * per);
+    for (int n = blockIdx.x * per + threadIdx.x; n < n1; n += blockDim.x) {
+        xu64 g[8];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < cx.world) g[r] = __hip_atomic_load(reinterpret_cast<const xu64*>(cx.local + (size_t)r * cx.cap + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < cx.world) ok = ok && ((unsigned)(g[r] >> 32) == cx.tag);
+            if (ok) break;
+            if ((spins & 1023u) == 0 && __hip_atomic_load(cx.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (++spins > VH_XCHG_SPIN_LIMIT) { __hip_atomic_store(cx.err, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        __hip_atomic_store(reinterpret_cast<xu64*>(cx.reduced) + q, ((xu64)__float_as_uint(s1) << 32) | (xu64)__float_as_uint(s0),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < cx.world) s += __uint_as_float((unsigned)g[r]);          // rank order: the same sum on every rank
+        __hip_atomic_store(reinterpret_cast<unsigned*>(cx.reduced) + n, __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my slice has left this CU
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cx.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // consumer, step 2 (AFTER the weight loads are in flight): the summed vector is complete.
-// Ordering: `reduced` is written and read ONLY with 8-byte agent-scope atomics (write-through sc1 stores, L1-bypassing sc1
-// loads: guide G16 "8-B agent atomics both sides"), every reducer wave drains its stores (vmcnt(0)) before the block's one
+// Ordering: `reduced` is written and read ONLY with agent-scope atomics (4-byte write-through sc1 stores, 8-byte L1-bypassing sc1
+// loads: guide G16 "agent atomics both sides"), every reducer wave drains its stores (vmcnt(0)) before the block's one
 // relaxed arrival, so no release / acquire fence is needed and the consumer's weight loads stay in flight.
 // Residency: the nred reducer blocks are the FIRST blocks of the consumer grid, and every consumer grid of the decode step
 // (768 / 384 / <= 1024 blocks of 256 threads) is co-resident on one device's 256 CUs, so a waiting block can never keep a
@@ -1137,11 +1142,15 @@ static int dec_gateup_grid(int I) {
     // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
     // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
     const int n_iter = 2 * (I / 4);
-    // (r05: equal shares of up to 3.5 resident blocks per CU for the few row groups of a tensor-parallel shard — 896 blocks of one
-    // group at TP = 8 instead of 384 of two or three — together with 2-row blocks for the shard's 768-row fused QKV measured SLOWER:
-    // 1.405 against 1.332 ms per token of one rank's TP = 8 shard, profiles/r05_decode_schedule_ab.txt; not kept)
     const int cus = vh_num_cus();
-    const int grid = 3 * cus / 2;
+    int grid = 3 * cus / 2;
+    if (vh_tuning()->dec_gateup_grid > 0) grid = vh_tuning()->dec_gateup_grid;
+    else if (n_iter <= 4 * grid) {
+        // (r06) the few row groups of a tensor-parallel shard (TP = 8: 896, TP = 4: 1792): EQUAL shares in as few rounds as 2 blocks per
+        // CU allow — 448 blocks x 2 groups at TP = 8 instead of 384 of which a third take 3 (the launch lasts as long as those)
+        const int rounds = (n_iter + 2 * cus - 1) / (2 * cus);
+        grid = (n_iter + rounds - 1) / rounds;
+    }
     return grid > n_iter ? n_iter : grid;
 }
 // grid of the fused attention-block launch: 2 persistent blocks per CU (its launch bounds), never more than it has items

@@ -347,6 +347,135 @@ __global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __re
     }
 }
 
+// ---- the same, tile-wise, for a ONE-SHOT prefill whose attention is the flash kernel (k_attn_fa, vh_attn.hip): besides q_out
+// and the fp32 KV cache it writes K and V as the MFMA-ready bf16 hi/lo tile images that kernel keeps in LDS, converted ONCE where
+// they are produced (r04-r05: every block of k_attn_fa converted every tile it read from fp32 — a third of that kernel).
+// grid (64-row tiles, 2 nkv): y < nkv: K / V tile of KV head y (threads 256-511 K with RoPE, 0-255 V; the image is assembled in
+// LDS with k_attn_fa's staging arithmetic and copied out in 16-byte pieces); y >= nkv: the four query heads of KV head y - nkv.
+// Image layout (64 KB per (head, tile), = the LDS buffer of k_attn_fa): K planes [half][64 keys][128 B], 16-byte chunks
+// XOR-swizzled by (key >> 1) & 7; V planes TRANSPOSED [rho(col)][64 keys], rho(d) = 16 (d % 8) + d / 8, chunks swizzled by
+// (rho >> 1) & 7.  Rows past S are zeros (finite: their probabilities are 0).  Same fp32 values as k_rope_kv (same slab order).
+#define KVI_PL 16384
+typedef __attribute__((ext_vector_type(2))) __bf16 kvi_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float kvi_f32x2;
+__device__ __forceinline__ void kvi_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const kvi_f32x2 v = {a, b};
+    const kvi_bf16x2 h = __builtin_convertvector(v, kvi_bf16x2);
+    const kvi_f32x2 r = v - __builtin_convertvector(h, kvi_f32x2);
+    const kvi_bf16x2 l = __builtin_convertvector(r, kvi_bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ f32x4 kvi_sum4(const float* src, int ns, long slab_stride) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < ns; ++k) a += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab_stride);
+    return a;
+}
+__global__ __launch_bounds__(512) void k_rope_kv_img(const float* __restrict__ qkv, long ldqkv, float* __restrict__ q_out,
+                                                     float* __restrict__ kcache, float* __restrict__ vcache,
+                                                     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int S,
+                                                     int nq, int nkv, int max_ctx, const int* __restrict__ table,
+                                                     const int* __restrict__ nslab_dev, long slab_stride,
+                                                     unsigned char* __restrict__ img, int img_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * KVI_PL];
+    const int t = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
+    const int ns = nslab_dev ? *nslab_dev : 1;
+    if (y >= nkv) {                                        // ---- q rows of the four heads of KV head y - nkv
+        const int g = y - nkv;
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int item = tid + 512 * i;
+            const int c = item & 15, hh = (item >> 4) & 3, r = item >> 6;
+            const int s = 64 * t + r;
+            if (s >= S) continue;
+            const int head = 4 * g + hh;
+            const float* src = qkv + (size_t)s * ldqkv + head * 128;
+            const f32x4 a = kvi_sum4(src + 4 * c, ns, slab_stride), b = kvi_sum4(src + 64 + 4 * c, ns, slab_stride);
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(rope_cos + (size_t)s * 64 + 4 * c);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(rope_sin + (size_t)s * 64 + 4 * c);
+            float* dst = q_out + ((size_t)s * nq + head) * 128;
+            *reinterpret_cast<f32x4*>(dst + 4 * c) = a * cs - b * sn;
+            *reinterpret_cast<f32x4*>(dst + 64 + 4 * c) = b * cs + a * sn;
+        }
+        return;
+    }
+    const int h = y;
+    if (tid >= 256) {                                      // ---- K: RoPE, cache rows, hi/lo planes
+        const int ftid = tid - 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = ftid + 256 * i;
+            const int c = item & 15, key = item >> 4;
+            const int s = 64 * t + key;
+            const bool valid = s < S;
+            const int sc = valid ? s : S - 1;
+            const float* src = qkv + (size_t)sc * ldqkv + (size_t)(nq + h) * 128;
+            const f32x4 a = kvi_sum4(src + 4 * c, ns, slab_stride), b = kvi_sum4(src + 64 + 4 * c, ns, slab_stride);
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(rope_cos + (size_t)sc * 64 + 4 * c);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(rope_sin + (size_t)sc * 64 + 4 * c);
+            f32x4 ra = a * cs - b * sn, rb = b * cs + a * sn;
+            if (valid) {
+                const int row = table ? table[s >> 6] * 64 + (s & 63) : s;
+                float* kc = kcache + ((size_t)h * max_ctx + row) * 128;
+                *reinterpret_cast<f32x4*>(kc + 4 * c) = ra;
+                *reinterpret_cast<f32x4*>(kc + 64 + 4 * c) = rb;
+            } else {
+                ra = f32x4{0.f, 0.f, 0.f, 0.f};
+                rb = ra;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 v = half ? rb : ra;
+                const int fk_c = c + 16 * half;
+                uint32_t h0, l0, h1, l1;
+                kvi_split2(v[0], v[1], h0, l0);
+                kvi_split2(v[2], v[3], h1, l1);
+                const int off = (fk_c >> 4) * 8192 + key * 128 + (((((fk_c & 15) >> 1)) ^ ((key >> 1) & 7)) << 4) + (fk_c & 1) * 8;
+                *reinterpret_cast<uint2*>(lds + off) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(lds + KVI_PL + off) = make_uint2(l0, l1);
+            }
+        }
+    } else {                                               // ---- V: cache rows, transposed hi/lo planes
+        const int fv_kg = tid >> 4, fv_cg = tid & 15;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            f32x4 st[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key = 4 * fv_kg + u;
+                const int s = 64 * t + key;
+                const bool valid = s < S;
+                const int sc = valid ? s : S - 1;
+                const int col = 4 * fv_cg + 64 * part;
+                f32x4 v = kvi_sum4(qkv + (size_t)sc * ldqkv + (size_t)(nq + nkv + h) * 128 + col, ns, slab_stride);
+                if (valid) {
+                    const int row = table ? table[s >> 6] * 64 + (s & 63) : s;
+                    *reinterpret_cast<f32x4*>(vcache + ((size_t)h * max_ctx + row) * 128 + col) = v;
+                } else {
+                    v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                st[u] = v;
+            }
+            const int cg = fv_cg + 16 * part;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t h01, l01, h23, l23;
+                kvi_split2(st[0][j], st[1][j], h01, l01);
+                kvi_split2(st[2][j], st[3][j], h23, l23);
+                const int d = 4 * cg + j;
+                const int rho = 16 * (d % 8) + d / 8;
+                const int off = rho * 128 + ((((fv_kg >> 1)) ^ ((rho >> 1) & 7)) << 4) + (fv_kg & 1) * 8;
+                *reinterpret_cast<uint2*>(lds + 2 * KVI_PL + off) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(lds + 3 * KVI_PL + off) = make_uint2(l01, l23);
+            }
+        }
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(img + ((size_t)h * img_tiles + t) * (4 * KVI_PL));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i * 512 + tid] = reinterpret_cast<const uint4*>(lds)[i * 512 + tid];
+}
+
 // ---- embedding gather + multimodal splice (vita_arch.py:237-321) ------------------------
 // host builds, per destination row, kind (0 text / 1 image / 2 audio) and source index.
 __global__ __launch_bounds__(256) void k_embed_splice(const int* __restrict__ kind, const int* __restrict__ idx,
@@ -557,6 +686,16 @@ int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, floa
     if (S == 0) return 0;
     hipLaunchKernelGGL(k_rope_kv, dim3(grid_for((long)S * (nq + 2 * nkv) * 64, 256)), dim3(256), 0, st, qkv, ldqkv,
                        q_out, kcache, vcache, rope_cos, rope_sin, S, pos0, nq, nkv, max_ctx, table, nslab_dev, slab_stride);
+    return 0;
+}
+int vhk_rope_kv_img(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
+                    const float* rope_cos, const float* rope_sin, int S, int nq, int nkv, int max_ctx,
+                    const int* table, const int* nslab_dev, long slab_stride, unsigned char* img, int img_tiles) {
+    if (S == 0) return 0;
+    const int tiles = (S + 63) / 64;
+    if (nq != 4 * nkv || !img || tiles > img_tiles || (ldqkv % 4) != 0 || (slab_stride % 4) != 0) return -1;
+    hipLaunchKernelGGL(k_rope_kv_img, dim3(tiles, 2 * nkv), dim3(512), 0, st, qkv, ldqkv, q_out, kcache, vcache, rope_cos, rope_sin, S,
+                       nq, nkv, max_ctx, table, nslab_dev, slab_stride, img, img_tiles);
     return 0;
 }
 int vhk_embed_splice(hipStream_t st, const int* src_kind, const int* src_idx, const uint16_t* embed,

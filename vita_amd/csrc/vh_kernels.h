@@ -32,6 +32,7 @@ struct VhTuning {
                                // 2 persistent blocks per CU, q|k|v and the attention output handed over as tagged granules, the O / next weights
                                // in flight under the attention), 0 = three launches (QKV, attention, O), -1 = auto (fused whenever H and the
                                // heads' width are <= 4096, i.e. always for the released geometry at any TP degree)
+    int dec_gateup_grid = 0;   // debug: blocks of the batch-1 gate|up launch (0 = auto: 1.5 per CU, equal shares in few rounds for small shards)
     int comm_allow_coarse = 0; // vh_comm_create: 1 = a coarse-grained receive buffer is acceptable when the fine-grained allocation fails (only
                                // correct when every rank drives ONE device: same-device tests); 0 = fail loudly instead
     int comm_ranks_per_device = 1;   // vh_comm_create: ranks that drive THIS rank's device (vita_amd.parallel counts them from the devices' PCI
@@ -212,8 +213,14 @@ struct VhAttnArgs {
     float scale;
     const int* ktable;                    // nullable: keys / values live in 64-row pages, logical block j>>6 -> page ktable[j>>6]
     long kv_rows;                         // rows a page-table entry may address (the pool); 0 = Sk.  Bounds the 32-bit offsets of k_attn_x3
+    // (r06) optional: K and V of this call as MFMA-READY bf16 hi/lo tile images written by the producer (vhk_rope_kv_img): image of
+    // (kv head h, 64-key tile t) = 64 KB at kv_img + (h * img_tiles + t) * 65536 in exactly k_attn_fa's LDS layout (K hi | K lo |
+    // V hi transposed | V lo transposed, 16-byte chunks XOR-swizzled; rows past Sk are zeros).  Used by the flash kernel for one-shot
+    // causal prefills (q_off == 0, Sk == Sq, B == 1); ignored otherwise (K / V must always be valid too).
+    const unsigned char* kv_img; int img_tiles;
 };
 int vhk_attn(hipStream_t st, const VhAttnArgs& a);
+int vhk_attn_fa_applies(const VhAttnArgs& a);    // 1 when vhk_attn would run the flash kernel (k_attn_fa) for these arguments
 
 // ---- element-wise / index kernels (vh_elem.hip) -------------------------------------
 int vhk_layernorm(hipStream_t st, const float* x, long ldx, float* y, long ldy, const float* w, const float* b,
@@ -230,6 +237,11 @@ int vhk_audio_conv1(hipStream_t st, const float* feats, const float* mean, const
 int vhk_rope_kv(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
                 const float* rope_cos, const float* rope_sin, int S, int pos0, int nq, int nkv, int max_ctx,
                 const int* table, const int* nslab_dev, long slab_stride);   // nslab_dev: qkv is *nslab_dev partial slabs
+// the same for a one-shot prefill (positions 0 .. S-1) whose attention is the flash kernel: additionally writes the K / V tile images
+// (VhAttnArgs::kv_img) — one block per (64-row tile, KV head) converts the tile once, where it is produced (nq == 4 * nkv)
+int vhk_rope_kv_img(hipStream_t st, const float* qkv, long ldqkv, float* q_out, float* kcache, float* vcache,
+                    const float* rope_cos, const float* rope_sin, int S, int nq, int nkv, int max_ctx,
+                    const int* table, const int* nslab_dev, long slab_stride, unsigned char* img, int img_tiles);
 int vhk_gather_rows(hipStream_t st, float* seq_x, const int* slots, int n, int H, float* rows);   // rows[b] = xa[b] = xb[b] + delta_attn[b]
 int vhk_sum_slabs(hipStream_t st, float* dst, long ldd, const float* src, long lds, int rows, int cols,
                   const int* nslab_dev, int nslab, long stride, int accumulate);
