@@ -59,6 +59,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "comm_ranks_per_device")) { g_tuning.comm_ranks_per_device = value; return VH_OK; }
     if (!strcmp(key, "dec_fused")) { g_tuning.dec_fused = value; return VH_OK; }
     if (!strcmp(key, "dec_gateup_grid")) { g_tuning.dec_gateup_grid = value; return VH_OK; }
+    if (!strcmp(key, "attn_img")) { g_tuning.attn_img = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 
@@ -706,7 +707,7 @@ static int prefill_impl(vh_mixtral* m, const float* embeds, int Sn, int pos0, fl
     const bool attn_planes = stream_attn && vh_tuning()->prefill_fuse_rows != 0 && (hd == 64 || hd == 128);
     // (r06) one-shot prefills whose attention is the flash kernel get K / V as MFMA-ready tile images from the RoPE pass
     bool use_img = false;
-    if (stream_attn && pos0 == 0 && m->kv_img && (Sn + 63) / 64 <= m->img_tiles) {
+    if (stream_attn && pos0 == 0 && m->kv_img && (Sn + 63) / 64 <= m->img_tiles && vh_tuning()->attn_img != 0) {
         VhAttnArgs q{};
         q.Sq = Sn; q.Sk = Sn; q.d = hd; q.Hq = nq; q.Hkv = nkv; q.B = 1; q.causal = 1;
         use_img = vhk_attn_fa_applies(q) != 0;
@@ -1126,7 +1127,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
         if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
         if (fuse) {
             // the consumer of this exchange is the next layer's attention block (or fused-QKV GEMV), or the LM head after the last layer
-            const int blocks = l + 1 < m->c.n_layers ? (fused_attn ? vhk_dec_consumer_blocks(3, (H + 7) / 8, H, I) : vhk_dec_consumer_blocks(0, m->nqkv, H, I))
+            const int blocks = l + 1 < m->c.n_layers ? (fused_attn ? vhk_dec_ablk_qkv_blocks(m->nqkv, H) : vhk_dec_consumer_blocks(0, m->nqkv, H, I))
                                                       : m->lm_grid;
             if (vh_comm_xchg_next(m->comm, H, 1, blocks, &xm, st) != VH_OK)
                 return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());

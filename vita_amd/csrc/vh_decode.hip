@@ -37,6 +37,10 @@
 #include "vh_common.h"
 #include "vh_kernels.h"
 
+#ifndef VH_GATEUP_EARLY
+#define VH_GATEUP_EARLY 1      // gate|up: the next row group's loads right behind the FMAs (1) or behind the block reduction (0: r01-r05); A/B builds only
+#endif
+
 namespace {
 
 // ---- tensor-parallel exchange fused into the kernels (VhXchg, vh_kernels.h) ---------------------------------------------
@@ -552,120 +556,84 @@ __global__ __launch_bounds__(256) void k_dec_attn(const float* __restrict__ qkv,
 // A batch-1 decode layer used to be five dependent launches; QKV, attention and the O projection are short enough that the head
 // and tail of each launch — dispatch, first-byte latency of the weight / K-V loads, prologue, drain, the boundary — cost as
 // much as their bytes (TP = 1: 28.5 us for 84 MB that the stream moves in 14; one rank of TP = 8: 18 us for 10.5 MB).  Here the three
-// are WORK ITEMS of one launch of 2 persistent blocks per CU (grid G):
-//   QKV item q        RQ rows of the fused q|k|v matrix               -> q|k|v as LINEAR granules (gq)         block q mod G
-//   attention item i  one 64-key tile of one KV head (h, split)       -> partials; the last arriver of a head
-//                                                                        merges -> GEMV-layout granules (ga)   block G - 1 - (i mod G)
-//   O item o          8 rows of the O projection                      -> out (stored, or pushed to the peers)  block o mod G
-// Every block runs its QKV items, then its attention items, then its O items.  Phases only wait for EARLIER phases (attention
-// for q|k|v, O for the merged attention output) and nothing in a phase waits for the same phase, so every block gets through
-// its QKV items unconditionally, then through its attention items, then through its O items: no circular wait whatever the
-// placement, provided every block is eventually dispatched (grid <= 2 per CU = the launch bounds; every wait is bounded and ends
-// in the error word).  Attention sits on the HIGHEST block ids: with fewer QKV items than blocks (tensor-parallel shards) those
-// blocks have no QKV item and their K / V tiles load from the first cycle.  What the fusion buys: ONE launch ramp and boundary
-// instead of three; the loads of a block's next item are issued before the current item's block reduction and BEFORE the wait for
-// their own input granules, so O weights and K / V tiles are in flight or landed when the data they wait for is published.
-// Three loops with small bodies (one loop over a type switch made hipcc hoist every body's address arithmetic in front of it:
-// 256 registers and 765 spills).  Arithmetic: exactly k_dec_gemv<NORM> / k_dec_attn / k_dec_gemv<!NORM> (same per-thread
-// accumulation, same reduction tree).
-template <int NJ, int R, int WN>
-__device__ __forceinline__ void ablk_issue_rows(const uint16_t* __restrict__ W, const int n0, const int N, const int K, uint4 (&w)[WN]) {
+// are the blocks of ONE launch, by block index:
+//   [0, nQ)               RQ rows of the fused q|k|v matrix each           -> q|k|v as LINEAR granules (gq)
+//   [nQ, nQ + nA)         one 64-key tile of one KV head each (h, split)   -> partials; the last arriver of a head merges -> GEMV-layout granules (ga)
+//   [nQ + nA, grid)       8 rows of the O projection each                  -> out (stored, or pushed to the peers: px)
+// A block waits only for blocks with a LOWER index (attention for the QKV rows, O for the merged attention output), and the
+// hardware dispatches a launch's blocks in index order: whatever else occupies the chip — another rank or another engine
+// process on the same device included — the waited-for blocks were dispatched before the waiting one and depend on nothing
+// behind them, so every wait ends (it is bounded anyway and ends in the error word).  A first form with persistent multi-role
+// blocks (2 per CU, attention on the highest block ids) deadlocked when four ranks shared one device: every rank's resident
+// O-phase blocks waited for attention blocks that found no free slot (r06 calls 1-2).  What the fusion buys: ONE launch ramp and
+// boundary instead of three; a block's weights / K-V tile are requested the moment it starts, BEFORE it waits for its input
+// granules: O blocks are dispatched as QKV blocks retire and have their weights in flight or landed when the attention publishes.
+// Arithmetic: exactly k_dec_gemv<NORM> / k_dec_attn / k_dec_gemv<!NORM> (same per-thread accumulation, same reduction tree).
+template <int NJ, int R>
+__device__ __forceinline__ void ablk_issue_rows(const uint16_t* __restrict__ W, const int n0, const int N, const int K, uint4 (&w)[R][NJ]) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint16_t* row = W + (size_t)min(n0 + r, N - 1) * K;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int c = threadIdx.x + j * 256;
-            w[r * NJ + j] = (c * 8 < K) ? ld_weight16(row + (size_t)c * 8) : make_uint4(0, 0, 0, 0);
+            w[r][j] = (c * 8 < K) ? ld_weight16(row + (size_t)c * 8) : make_uint4(0, 0, 0, 0);
         }
     }
 }
 template <int NJ, int NJO, int RQ>
 __global__ __launch_bounds__(256, 2) void k_dec_ablk(const VhDecAblk a) {
     constexpr int RO = 8;
-    constexpr int WN = (RQ * NJ > RO * NJO) ? RQ * NJ : RO * NJO;
     constexpr int RM = RQ > RO ? RQ : RO;
     __shared__ float red[4 * (RM + 1)];
     const int KO = a.nq * 128;
-    const int nQ = (a.nqkv + RQ - 1) / RQ, nA = a.nkv * a.nsplit, nO = (a.H + RO - 1) / RO;
-    const int G = gridDim.x;
-    xchg_reduce(a.cx);                          // fused exchange: the first nred blocks sum the previous layer's MoE partials
-
-    uint4 w[WN];                                // weights of the GEMV item in flight (QKV: [RQ][NJ], O: [RO][NJO])
-    DecAttnTile tile;                           // K / V tile of the attention item in flight
-    int q = blockIdx.x, ai = G - 1 - (int)blockIdx.x, oi = blockIdx.x;
-    const bool had_q = q < nQ;
-    // the first item of the block's first non-empty phase goes out before anything else
-    if (q < nQ) ablk_issue_rows<NJ, RQ, WN>(a.Wqkv, q * RQ, a.nqkv, a.H, w);
-    else if (ai < nA) dec_attn_issue(ai / a.nsplit, ai % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
-    else if (oi < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, oi * RO, a.H, KO, w);
-
-    // ---- phase 1: fused-QKV rows ----
-    if (q < nQ) {
+    const int nQ = (a.nqkv + RQ - 1) / RQ, nA = a.nkv * a.nsplit;
+    const int b = blockIdx.x;
+    if (b < nQ) {
+        // ---- fused-QKV rows (the first nred of these blocks also reduce a fused exchange) ----
+        xchg_reduce(a.cx);
+        uint4 w[RQ][NJ];
+        ablk_issue_rows<NJ, RQ>(a.Wqkv, b * RQ, a.nqkv, a.H, w);
         float xr[NJ][8];
         xchg_wait(a.cx);
-        const float ss = load_add_norm<NJ>(a.x_in, a.cx.world ? a.cx.reduced : a.delta, a.norm_w, a.x_out, a.H, xr, a.cx.world != 0);
-        float inv = 0.f;
-        bool first = true;
-        for (; q < nQ; q += G) {
-            float vals[RQ + 1];
+        float vals[RQ + 1];
+        vals[RQ] = load_add_norm<NJ>(a.x_in, a.cx.world ? a.cx.reduced : a.delta, a.norm_w, a.x_out, a.H, xr, a.cx.world != 0);
+        float acc[RQ];
+        gemv_fma<NJ, RQ>(w, xr, acc);
 #pragma unroll
-            for (int r = 0; r < RQ; ++r) {
-                float acc = 0.f;
+        for (int r = 0; r < RQ; ++r) vals[r] = acc[r];
+        block256_sum<RQ + 1>(vals, red);
+        const float inv = rsqrtf(vals[RQ] / (float)a.H + a.eps);
+        const int n0 = b * RQ;
+        if (threadIdx.x < RQ && n0 + threadIdx.x < a.nqkv) {
+            float v = 0.f;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc += dot8_bf16_f32(w[r * NJ + j], xr[j]);
-                vals[r] = acc;
-            }
-            // next GEMV item of this block: its loads go out before the block reduction (a K / V tile would be waited for and
-            // spilled here — the tile registers on top of this phase's: it goes out at the head of phase 2 instead)
-            if (q + G < nQ) ablk_issue_rows<NJ, RQ, WN>(a.Wqkv, (q + G) * RQ, a.nqkv, a.H, w);
-            else if (ai >= nA && oi < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, oi * RO, a.H, KO, w);
-            vals[RQ] = first ? ss : 0.f;
-            block256_sum<RQ + 1>(vals, red);
-            if (first) { inv = rsqrtf(vals[RQ] / (float)a.H + a.eps); first = false; }
-            const int n0 = q * RQ;
-            if (threadIdx.x < RQ && n0 + threadIdx.x < a.nqkv) {
-                float v = 0.f;
-#pragma unroll
-                for (int r = 0; r < RQ; ++r) if (threadIdx.x == r) v = vals[r];
-                gran_put(a.gq, (size_t)(n0 + threadIdx.x), v * inv);
-            }
+            for (int r = 0; r < RQ; ++r) if (threadIdx.x == r) v = vals[r];
+            gran_put(a.gq, (size_t)(n0 + threadIdx.x), v * inv);
         }
-    }
-    // ---- phase 2: attention tiles ----
-    if (had_q && ai < nA) dec_attn_issue(ai / a.nsplit, ai % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
-    for (; ai < nA; ai += G) {
-        // the block's first O item goes out first when this is its last tile (the usual case: its weights do not depend on
-        // anything this item waits for, and they live in `w`, not in the tile registers)
-        const bool more = ai + G < nA;
-        if (!more && oi < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, oi * RO, a.H, KO, w);
+    } else if (b < nQ + nA) {
+        // ---- one attention tile ----
+        const int ai = b - nQ;
+        DecAttnTile tile;
+        dec_attn_issue(ai / a.nsplit, ai % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
         dec_attn_finish<true>(ai / a.nsplit, ai % a.nsplit, a.nsplit, tile, nullptr, a.kcache, a.vcache, a.pos, a.table, a.rope_cos,
                               a.rope_sin, a.part_o, a.part_ml, a.cnt, nullptr, a.nq, a.nkv, a.max_ctx, a.max_splits, a.scale, a.gq, a.ga);
-        if (more) dec_attn_issue((ai + G) / a.nsplit, (ai + G) % a.nsplit, a.kcache, a.vcache, a.table, a.max_ctx, tile);
-    }
-    // ---- phase 3: O-projection rows ----
-    if (oi < nO) {
+    } else {
+        // ---- O-projection rows ----
+        const int n0 = (b - nQ - nA) * RO;
+        uint4 w[RO][NJO];
+        ablk_issue_rows<NJO, RO>(a.Wo, n0, a.H, KO, w);
         float xo[NJO][8];
-        gran_read_gemv<NJO>(a.ga, KO, xo);      // waits for the merged attention output (this item's weights are in flight)
-        for (; oi < nO; oi += G) {
-            float vals[RO];
+        gran_read_gemv<NJO>(a.ga, KO, xo);      // waits for the merged attention output (this block's weights are in flight)
+        float vals[RO];
+        gemv_fma<NJO, RO>(w, xo, vals);
+        block256_sum<RO>(vals, red);
+        if (threadIdx.x < RO && n0 + threadIdx.x < a.H) {
+            float v = 0.f;
 #pragma unroll
-            for (int r = 0; r < RO; ++r) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJO; ++j) acc += dot8_bf16_f32(w[r * NJO + j], xo[j]);
-                vals[r] = acc;
-            }
-            if (oi + G < nO) ablk_issue_rows<NJO, RO, WN>(a.Wo, (oi + G) * RO, a.H, KO, w);
-            block256_sum<RO>(vals, red);
-            const int n0 = oi * RO;
-            if (threadIdx.x < RO && n0 + threadIdx.x < a.H) {
-                float v = 0.f;
-#pragma unroll
-                for (int r = 0; r < RO; ++r) if (threadIdx.x == r) v = vals[r];
-                if (a.px.world) xchg_put(a.px, n0 + threadIdx.x, v);
-                else a.out[n0 + threadIdx.x] = v;
-            }
+            for (int r = 0; r < RO; ++r) if (threadIdx.x == r) v = vals[r];
+            if (a.px.world) xchg_put(a.px, n0 + threadIdx.x, v);
+            else a.out[n0 + threadIdx.x] = v;
         }
     }
 }
@@ -736,9 +704,21 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
             rows[RP + r] = W3 + ((size_t)e * I + i0 + r) * K;
         }
     };
-    auto finish = [&](int it, const uint4 (&w)[2 * RP][NJ]) {
+    int it = blockIdx.x;
+    if (it >= n_iter) return;
+    const uint16_t* rows[2 * RP];
+    uint4 w[2 * RP][NJ];
+    rows_of(it, rows);
+    gemv_issue<NJ, 2 * RP>(rows, K, w);
+    while (it < n_iter) {
+        // (r06) the next group's loads go out right behind this group's FMAs — the weight registers are free — and land under the
+        // block reduction and the store (r01-r05 issued them after the reduction and relied on the CU's other blocks for the overlap)
         float acc[2 * RP];
         gemv_fma<NJ, 2 * RP>(w, xr, acc);
+        const int nxt = it + gridDim.x;
+#if VH_GATEUP_EARLY
+        if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, w); }
+#endif
         block256_sum<2 * RP>(acc, red);
         if (threadIdx.x < RP) {
             float g = 0.f, u = 0.f;
@@ -748,15 +728,10 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
             const int i0 = (it - slot * per_slot) * RP;
             hbuf[(size_t)slot * I + i0 + threadIdx.x] = silu_f(g * inv) * (u * inv);
         }
-    };
-    int it = blockIdx.x;
-    if (it >= n_iter) return;
-    const uint16_t* rows[2 * RP];
-    for (; it < n_iter; it += gridDim.x) {
-        uint4 w[2 * RP][NJ];
-        rows_of(it, rows);
-        gemv_issue<NJ, 2 * RP>(rows, K, w);
-        finish(it, w);
+#if !VH_GATEUP_EARLY
+        if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, w); }
+#endif
+        it = nxt;
     }
 }
 
@@ -1153,17 +1128,12 @@ static int dec_gateup_grid(int I) {
     }
     return grid > n_iter ? n_iter : grid;
 }
-// grid of the fused attention-block launch: 2 persistent blocks per CU (its launch bounds), never more than it has items
-static int dec_ablk_grid(int total_items) {
-    const int g = 2 * vh_num_cus();
-    return total_items < g ? total_items : g;
-}
 // blocks of a consumer launch: the fused exchange's reducers are its first min(16, blocks) blocks
 int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
     (void)K;
     if (which == 0) return (N + DEC_GEMV_R - 1) / DEC_GEMV_R;
     if (which == 1) return dec_gateup_grid(I);
-    if (which == 3) return dec_ablk_grid(N);   // N: at least this many items (the O-projection rows / 8 alone)
+    if (which == 3) return N;   // fused attention block: at least the fused-QKV blocks (N = their count) come first
     return N;   // LM head: the caller's grid
 }
 
@@ -1175,18 +1145,22 @@ int vhk_dec_qkv(hipStream_t st, const float* x_in, const float* delta, float* x_
 int vhk_dec_ablk_supported(int H, int nq, int nkv) {
     return H <= 4096 && H % 8 == 0 && nq * 128 <= 4096 && nkv >= 1 && nq % nkv == 0 && nq / nkv <= 4;
 }
-// rows per fused-QKV item: the smallest of 2 / 4 / 8 that covers the matrix in ONE round of the grid (tensor-parallel shards: the
-// highest blocks then have no QKV item and start with their attention tile); the released 6144-row matrix takes 1.5 rounds of 8 rows
+// rows per fused-QKV block: 8 (the per-operator kernel's), fewer for a tensor-parallel shard's short matrix so that its blocks still
+// cover the chip (768 rows at TP = 8: 384 blocks of 2)
+static int dec_ablk_rq(int nqkv, int H) {
+    if (H <= 2048) return 8;                                          // one chunk slot per thread: a single instantiation
+    const int cus = vh_num_cus();
+    for (int r : {8, 4, 2}) if ((nqkv + r - 1) / r >= cus + cus / 2) return r;
+    return 2;
+}
+int vhk_dec_ablk_qkv_blocks(int nqkv, int H) { const int r = dec_ablk_rq(nqkv, H); return (nqkv + r - 1) / r; }
 int vhk_dec_ablk(hipStream_t st, const VhDecAblk& a) {
     if (!vhk_dec_ablk_supported(a.H, a.nq, a.nkv) || a.nsplit < 1 || a.nsplit > a.max_splits || !a.gq.g || !a.ga.g) return -1;
     const int KO = a.nq * 128;
-    const int nA = a.nkv * a.nsplit, nO = (a.H + 7) / 8;
-    const int gmax = 2 * vh_num_cus();
-    int rq = 8;                                                     // (12 rows = the released q|k|v matrix in one round: 96 weight registers, spills)
-    for (int r : {2, 4, 8}) if ((a.nqkv + r - 1) / r <= gmax) { rq = r; break; }
-    if (a.H <= 2048) rq = 8;                                        // one chunk slot per thread: a single instantiation
-    const int total = (a.nqkv + rq - 1) / rq + nA + nO;
-    const dim3 grid(dec_ablk_grid(total));
+    const int rq = dec_ablk_rq(a.nqkv, a.H);
+    const long total = (long)(a.nqkv + rq - 1) / rq + (long)a.nkv * a.nsplit + (a.H + 7) / 8;
+    if (total > 1000000) return -1;
+    const dim3 grid((unsigned)total);
     auto launch = [&](auto nj, auto njo, auto r) {
         hipLaunchKernelGGL((k_dec_ablk<decltype(nj)::value, decltype(njo)::value, decltype(r)::value>), grid, dim3(256), 0, st, a);
         return 0;

@@ -32,6 +32,8 @@ struct VhTuning {
                                // 2 persistent blocks per CU, q|k|v and the attention output handed over as tagged granules, the O / next weights
                                // in flight under the attention), 0 = three launches (QKV, attention, O), -1 = auto (fused whenever H and the
                                // heads' width are <= 4096, i.e. always for the released geometry at any TP degree)
+    int attn_img = 1;          // one-shot prefills under the flash attention kernel: 1 = K / V as MFMA-ready tile images written by the RoPE pass
+                               // (k_rope_kv_img -> LDS-DMA in k_attn_fa), 0 = fp32 K / V staged and converted by every attention block (r04-r05)
     int dec_gateup_grid = 0;   // debug: blocks of the batch-1 gate|up launch (0 = auto: 1.5 per CU, equal shares in few rounds for small shards)
     int comm_allow_coarse = 0; // vh_comm_create: 1 = a coarse-grained receive buffer is acceptable when the fine-grained allocation fails (only
                                // correct when every rank drives ONE device: same-device tests); 0 = fail loudly instead
@@ -114,6 +116,7 @@ struct VhDecAblk {
 };
 int vhk_dec_ablk(hipStream_t st, const VhDecAblk& a);
 int vhk_dec_ablk_supported(int H, int nq, int nkv);   // 1 when k_dec_ablk has an instantiation for these widths
+int vhk_dec_ablk_qkv_blocks(int nqkv, int H);         // its fused-QKV blocks (the first of the launch: a fused exchange's reducers are among them)
 // ---- batched decode (one iteration of up to VH_BMAX concurrent sequences; vh_decode.hip) -------------------------------
 #define VH_BMAX 4
 struct VhDecBatchVec {       // a GEMV-shaped step over the batch: out[b] = f(W, x_in[b] (+ delta[b]))
