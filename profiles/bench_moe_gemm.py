@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--I", type=int, default=14336)
     ap.add_argument("--E", type=int, default=8)
     ap.add_argument("--ab", default="", help="comma list of ps_cfg values to A/B in interleaved rounds, e.g. 1,2")
+    ap.add_argument("--abtune", default="", help="interleaved A/B of one vh_tune key over values, e.g. ps_xcd=0,1,3 (r06); parity of every value first")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--layers", type=int, default=2, help="distinct weight sets cycled through (defeats cache reuse)")
     args = ap.parse_args()
@@ -160,6 +161,32 @@ def main():
                 gu, dn = time_pair(-4)
                 report(f"round {rnd} cfg={cfg}", gu, dn)
         _lib.tune("ps_cfg", -1)
+    if args.abtune:
+        key, vals = args.abtune.split("=")
+        vals = [int(v) for v in vals.split(",")]
+        for v in vals:
+            _lib.tune(key, v)
+            hh, hl, y = run_ps(layers[0], -4)
+            torch.cuda.synchronize()
+            h = hh.float() + hl.float()
+            ysum = y.sum(0)
+            e_h = e_y = 0.0
+            for pp in list(range(0, 2 * S, max(1, (2 * S) // 48))) + [2 * S - 1] + [int(c) - 1 for c in np.cumsum(rows) if c > 0]:
+                slot = int(order[pp]); e = int(flat[slot]); t = slot // 2
+                xr = x[t].double()
+                gg = L["w1"][e].double() @ xr
+                uu = L["w3"][e].double() @ xr
+                href = gg / (1 + torch.exp(-gg)) * uu
+                e_h = max(e_h, float(torch.nan_to_num((h[pp].double() - href).abs(), nan=1e30).max()))
+                e_y = max(e_y, float(torch.nan_to_num((ysum[slot].double() - L["w2"][e].double() @ h[pp].double()).abs(), nan=1e30).max()))
+            print(f"{key}={v}: max |err| gate/up {e_h:.3e}   down {e_y:.3e}   (K split {int(nslab.item())})", flush=True)
+            assert args.nocheck or (e_h < 5e-4 and e_y < 5e-4), f"parity failure {key}={v}"
+        for rnd in range(args.rounds):
+            for v in vals:
+                _lib.tune(key, v)
+                gu, dn = time_pair(-4)
+                report(f"round {rnd} {key}={v}", gu, dn)
+        _lib.tune(key, -1)
     if args.sweep:
         gu, dn = time_pair(1)
         report("stream ksplit=1", gu, dn)

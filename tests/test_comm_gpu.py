@@ -141,6 +141,10 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
                      eng.decode_schedule())
         dist.barrier()
         eng.close()
+    except BaseException:
+        import traceback
+        ret[("error", rank)] = traceback.format_exc()      # mp.spawn reports ONE failing process: keep every rank's own reason
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -172,7 +176,12 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     from oracle import mixtral as om
     from vita_amd.checkpoint import synth_state_dict
     ret = mp.Manager().dict()
-    mp.spawn(_tp_worker, args=(world, _free_port(), 1, ret, -1), nprocs=world, join=True)   # fuse = -1: the ranks choose the exchange form
+    try:
+        mp.spawn(_tp_worker, args=(world, _free_port(), 1, ret, -1), nprocs=world, join=True)   # fuse = -1: the ranks choose the exchange form
+    except Exception:
+        for k in sorted(k for k in ret.keys() if isinstance(k, tuple)):
+            print(f"---- rank {k[1]} ----\n{ret[k]}")
+        raise
     cfg = _tp_cfg(world)
     sd = synth_state_dict(cfg, seed=3, parts=("text",))
     rng = np.random.default_rng(5)

@@ -51,6 +51,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "prefill_fuse_rows")) { g_tuning.prefill_fuse_rows = value; return VH_OK; }
     if (!strcmp(key, "ps_cfg")) { g_tuning.ps_cfg = value; return VH_OK; }
     if (!strcmp(key, "ps_nt")) { g_tuning.ps_nt = value; return VH_OK; }
+    if (!strcmp(key, "ps_xcd")) { g_tuning.ps_xcd = value; return VH_OK; }
     if (!strcmp(key, "tp_overlap")) { g_tuning.tp_overlap = value; return VH_OK; }
     if (!strcmp(key, "moe_ksplit")) { g_tuning.moe_ksplit = value; return VH_OK; }
     if (!strcmp(key, "force_allreduce")) { g_tuning.force_allreduce = value; return VH_OK; }

@@ -37,10 +37,6 @@
 #include "vh_common.h"
 #include "vh_kernels.h"
 
-#ifndef VH_GATEUP_EARLY
-#define VH_GATEUP_EARLY 1      // gate|up: the next row group's loads right behind the FMAs (1) or behind the block reduction (0: r01-r05); A/B builds only
-#endif
-
 namespace {
 
 // ---- tensor-parallel exchange fused into the kernels (VhXchg, vh_kernels.h) ---------------------------------------------
@@ -402,8 +398,8 @@ __device__ __forceinline__ bool dec_attn_finish(const int h, const int sp, const
     __shared__ __attribute__((aligned(16))) float q_s[4][128];
     __shared__ __attribute__((aligned(16))) float kn_s[128];
     __shared__ __attribute__((aligned(16))) float vn_s[128];
-    __shared__ __attribute__((aligned(16))) float Kt[DA_KT * DA_KSTR];
-    __shared__ __attribute__((aligned(16))) float Vt[DA_KT * 128];
+    __shared__ __attribute__((aligned(16))) float Kt[DA_KT * DA_KSTR];     // the K tile, then (r06) the V tile: 36 KB per block instead of 69,
+    float* const Vt = Kt;                                                  // so four blocks of the fused attention-block launch fit a CU
     __shared__ int last_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -452,7 +448,9 @@ __device__ __forceinline__ bool dec_attn_finish(const int h, const int sp, const
     }
     __syncthreads();
 
-    // 3. tiles -> LDS (the new token's row comes from LDS, not from the cache; rows past the context are 0)
+    // 3. K tile -> LDS (the new token's row comes from LDS, not from the cache; rows past the context are 0); the V tile waits in
+    // registers until the scores are done with the buffer
+    f32x4 vtile[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * 256;
@@ -467,11 +465,12 @@ __device__ __forceinline__ bool dec_attn_finish(const int h, const int sp, const
             vv = kv;
         }
         *reinterpret_cast<f32x4*>(&Kt[row * DA_KSTR + c4 * 4]) = kv;
-        *reinterpret_cast<f32x4*>(&Vt[row * 128 + c4 * 4]) = vv;
+        vtile[i] = vv;
     }
     __syncthreads();
 
-    // 4. scores, softmax statistics and PV for this tile
+    // 4. scores and softmax statistics for this tile; then the V tile takes the K tile's place; then PV
+    float p = 0.f, m = 0.f, l = 0.f;
     if (wid < G) {
         const bool valid = (k0 + lane) < k1;
         float sc = 0.f;
@@ -486,9 +485,18 @@ __device__ __forceinline__ bool dec_attn_finish(const int h, const int sp, const
             sc = fmaf(qq.w, kk.w, sc);
         }
         sc = valid ? sc * scale : -INFINITY;
-        const float m = wave_max(sc);                    // finite: the host never launches an empty tile
-        const float p = valid ? __expf(sc - m) : 0.f;
-        const float l = wave_sum(p);
+        m = wave_max(sc);                                // finite: the host never launches an empty tile
+        p = valid ? __expf(sc - m) : 0.f;
+        l = wave_sum(p);
+    }
+    __syncthreads();                                     // every wave is done with the K tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256;
+        *reinterpret_cast<f32x4*>(&Vt[(idx >> 5) * 128 + (idx & 31) * 4]) = vtile[i];
+    }
+    __syncthreads();
+    if (wid < G) {
         float2 o = make_float2(0.f, 0.f);
 #pragma unroll
         for (int kk = 0; kk < DA_KT; ++kk) {
@@ -582,7 +590,7 @@ __device__ __forceinline__ void ablk_issue_rows(const uint16_t* __restrict__ W, 
     }
 }
 template <int NJ, int NJO, int RQ>
-__global__ __launch_bounds__(256, 2) void k_dec_ablk(const VhDecAblk a) {
+__global__ __launch_bounds__(256, 4) void k_dec_ablk(const VhDecAblk a) {
     constexpr int RO = 8;
     constexpr int RM = RQ > RO ? RQ : RO;
     __shared__ float red[4 * (RM + 1)];
@@ -707,18 +715,15 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
     int it = blockIdx.x;
     if (it >= n_iter) return;
     const uint16_t* rows[2 * RP];
-    uint4 w[2 * RP][NJ];
-    rows_of(it, rows);
-    gemv_issue<NJ, 2 * RP>(rows, K, w);
-    while (it < n_iter) {
-        // (r06) the next group's loads go out right behind this group's FMAs — the weight registers are free — and land under the
-        // block reduction and the store (r01-r05 issued them after the reduction and relied on the CU's other blocks for the overlap)
+    // (r06: issuing the NEXT group's loads right behind this group's FMAs — they would land under the block reduction — was measured
+    // and lost: the kernel grew from 118 to 162 registers (hipcc keeps both weight sets live) and 78.5 -> 82.7 us at TP = 1,
+    // 19.2 -> 20.3 at one rank's TP = 8 shard; the CU's other resident blocks already provide that overlap)
+    for (; it < n_iter; it += gridDim.x) {
+        uint4 w[2 * RP][NJ];
+        rows_of(it, rows);
+        gemv_issue<NJ, 2 * RP>(rows, K, w);
         float acc[2 * RP];
         gemv_fma<NJ, 2 * RP>(w, xr, acc);
-        const int nxt = it + gridDim.x;
-#if VH_GATEUP_EARLY
-        if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, w); }
-#endif
         block256_sum<2 * RP>(acc, red);
         if (threadIdx.x < RP) {
             float g = 0.f, u = 0.f;
@@ -728,10 +733,6 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
             const int i0 = (it - slot * per_slot) * RP;
             hbuf[(size_t)slot * I + i0 + threadIdx.x] = silu_f(g * inv) * (u * inv);
         }
-#if !VH_GATEUP_EARLY
-        if (nxt < n_iter) { rows_of(nxt, rows); gemv_issue<NJ, 2 * RP>(rows, K, w); }
-#endif
-        it = nxt;
     }
 }
 

@@ -387,7 +387,11 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     }
     // specialised waves (vh_gemm_sp.hip).  Weight loads WITHOUT the non-temporal hint unless forced (ps_nt = 1): same time (527 vs 530 us gate|up,
     // prefill 8.64-8.71 ms per 8 layers either way) and 6 % fewer fabric-side fetches (2.35 vs 2.49 GB: profiles/r04_fetch_nt_ab.txt)
-    if (cfg == 2) return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt > 0);
+    if (cfg == 2) {
+        const int px = vh_tuning()->ps_xcd < 0 ? 0 : vh_tuning()->ps_xcd;
+        a.xcd_group = (a.W_up ? (px >> 1) : px) & 1;
+        return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt > 0);
+    }
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
     // round is M-split relies on L2 for the second reader of each weight tile (gate|up: +5 % with nt)
     bool nt = vh_tuning()->ps_nt > 0;

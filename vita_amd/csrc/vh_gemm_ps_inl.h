@@ -254,7 +254,11 @@ __device__ __forceinline__ void for_each_tile(const VhGemmPsArgs& p, F&& f) {
     // (r04: giving XCD x the contiguous chunk [x nb, (x + 1) nb) of every round instead — one expert's activation planes per XCD
     // per round — changed neither the time (583 vs 584 us uniform, 635-649 vs 634-636 skewed) nor FETCH_SIZE (2.436 vs 2.431 GB per
     // launch): profiles/r04_sched_map_ab.txt.)
-    const int jj = (nb & 1) ? (int)blockIdx.x : (((j >> 1) << 4) | (xcd << 1) | (j & 1));
+    // (r06) p.xcd_group: XCD x takes the CONTIGUOUS positions [x nb, (x + 1) nb) of the round instead — with the list expert-major, K slice,
+    // n-tile, m-tile fastest, these are the n-tiles of one or two (expert, K slice) groups: they stream the SAME activation rows stage by
+    // stage, so a line of the h planes (63 MB at S = 552: far beyond the L2s) is filled into ONE L2 and hit by the group's other tiles,
+    // where the interleaved placement has every XCD fetch every group's rows.
+    const int jj = (nb & 1) ? (int)blockIdx.x : (p.xcd_group ? (xcd * nb + j) : (((j >> 1) << 4) | (xcd << 1) | (j & 1)));
     const int g0 = 0, Tx = T;
 #else
     const int g0 = (int)(((long)T * xcd) >> 3), g1 = (int)(((long)T * (xcd + 1)) >> 3);

@@ -21,6 +21,8 @@ struct VhTuning {
     int prefill_fuse_rows = 1; // single-rank prefill: K-split slabs summed by the consuming norm kernel (VhRowUpdate); 0 = separate slab-sum / combine launches
     int ps_cfg = -1;           // vh_gemm_ps variant: -1 = by rows per group (0 up to 64 rows, else 2), 0 = 64 rows / 8-slot weight DMA ring, 1 = 192 rows / register-staged weights,
                                // 2 = 192 rows, 12 specialised waves (8 MFMA-only + 2 weight stagers + 2 activation DMA: vh_gemm_sp.hip)
+    int ps_xcd = -1;           // specialised streaming GEMM: bit 0 = the down projection / plain GEMMs, bit 1 = gate|up take the XCD-contiguous placement
+                               // of a round's tiles (VhGemmPsArgs::xcd_group); -1 = auto
     int ps_nt = -1;            // vh_gemm_ps non-temporal weight loads: -1 = default (8-wave kernels: unless the last round is M-split; specialised kernel: off), 0 = never, 1 = always
     int tp_overlap = 1;        // tensor-parallel prefill: all-reduce of one column half on a comm stream under the GEMM of the other half
     int moe_ksplit = -4;       // K split of the prefill MoE down projection (partial slabs, summed by the combine kernel); < 0: chosen on device up to -n
@@ -193,6 +195,8 @@ struct VhGemmPsArgs {
                                                              // ksplit < 0: the kernel picks 1 .. -ksplit from the group sizes
     int* nslab_out;                                          // device int: the split the kernel used (required when ksplit < 0)
     int rt_cap;                                              // 0 = tile rows up to the kernel's maximum (192); n: m-tiles of at most 16 n rows (plain GEMMs at M ~ 1000: more, smaller tiles fill the chip)
+    int xcd_group;                                           // specialised kernel, set by the launcher: 1 = XCD x takes the CONTIGUOUS positions [x nb, (x+1) nb) of every round of the
+                                                             // tile list (the n-tiles of one (expert, K slice) on ONE XCD: they read the same activation rows in step, one L2 fill serves them)
 };
 int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a);
 int vhk_gemm_sp(hipStream_t st, const VhGemmPsArgs& a, int grid, bool nt);   // vh_gemm_sp.hip: 12-wave specialised form (arguments already checked)
