@@ -3,6 +3,7 @@ multi-GPU box is available to this repo's tests): one-shot and two-shot paths ag
 results on both ranks, several epochs back to back (double-buffer reuse), and the engine's tensor-parallel decode
 through it against the unsharded run."""
 import os
+import time
 import socket
 
 import numpy as np
@@ -71,6 +72,7 @@ def _worker(rank, world, port, ret):
         out[("fine_grained",)] = (0.0, bytes([int(comm.fine_grained)]))
         ret[rank] = out
         dist.barrier()
+        time.sleep(0.5)                          # gloo: a rank that leaves the barrier first must not close its sockets under the others
         comm.destroy()
     finally:
         dist.destroy_process_group()
@@ -140,6 +142,7 @@ def _tp_worker(rank, world, port, overlap, ret, fuse=1, collective="ipc"):
         ret[rank] = (name, eng.generated(), lg.numpy(), (eng.c.vocab_lo, eng.c.vocab_n), comm_status(eng), eng.decode_exchange,
                      eng.decode_schedule())
         dist.barrier()
+        time.sleep(0.5)                          # gloo: a rank that leaves the barrier first must not close its sockets under the others
         eng.close()
     except BaseException:
         import traceback
@@ -299,6 +302,7 @@ def _tp_real_worker(rank, world, port, ret, layers=2):
         dist.all_reduce(lg)                      # vocab-sharded head: rows hold this rank's slice, zeros elsewhere
         ret[rank] = (name, eng.generated(), lg.numpy(), comm_status(eng), eng.decode_exchange, eng.decode_schedule())
         dist.barrier()
+        time.sleep(0.5)                          # gloo: a rank that leaves the barrier first must not close its sockets under the others
         eng.close()
     finally:
         dist.destroy_process_group()

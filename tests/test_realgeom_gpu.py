@@ -201,6 +201,7 @@ def _tp8_omni_worker(rank, world, port, layers, enc_path, ret):
         ret[rank] = (name, eng.generated(), lg.numpy() if rank == 0 else None, c.status() if c is not None else None,
                      eng.decode_exchange, int(emb.shape[1]), lg.numpy().tobytes() if rank > 0 else None, eng.decode_schedule())
         dist.barrier()
+        time.sleep(0.5)                          # gloo: a rank that leaves the barrier first must not close its sockets under the others
         eng.close()
     finally:
         dist.destroy_process_group()

@@ -4,6 +4,7 @@ SamplingParams(temperature=0.01) == greedy — must produce the tokens of the OR
 oracle/mixtral.py on the same state dict and inputs), and the same tokens as the HF-flavour boundary."""
 import json
 import os
+import time
 
 import numpy as np
 import pytest

@@ -51,10 +51,8 @@ struct vh_comm {
     bool fine_grained;                       // the receive buffer is uncached / coherent for peer stores
     int ranks_per_device;                    // declared at creation (vh_tune("comm_ranks_per_device", n)): ranks that drive THIS rank's device
     bool loopback;                           // one rank plays all `world` ranks into its own slots (vh_comm_create_loopback)
-    // exchanges fused into the decode kernels (VhXchg): two result vectors (attention / MoE sub-block), the reducers' arrival counter
-    float* reduced[2];
-    int* counter;
-    unsigned arrivals;                       // host mirror: reducer blocks that will have arrived when every issued exchange is done
+    // exchanges fused into the decode kernels (VhXchg): two result vectors (attention / MoE sub-block) as tagged granules in the GEMV layout
+    unsigned long long* reduced_g[2];
 };
 // buffer layout (granules): [2 parity regions][2 barrier rows of VH_COMM_MAX_WORLD].  The 32-bit tag of a call is the low
 // word of the call counter (0 is skipped: "never written"); the parity region is the counter's low bit, tracked
@@ -246,7 +244,8 @@ int comm_rewind(vh_comm* c, hipStream_t st) {
         for (int r = 0; r < c->world; ++r) bars.p[r] = c->peer[r] + 2 * c->region + (size_t)phase * VH_COMM_MAX_WORLD;
         hipLaunchKernelGGL(k_comm_barrier, dim3(1), dim3(64), 0, st, bars, c->local + 2 * c->region + (size_t)phase * VH_COMM_MAX_WORLD,
                            c->rank, c->world, c->generation, c->err);
-        if (phase == 0 && hipMemsetAsync(c->local, 0, 2 * c->region * sizeof(uint64_t), st) != hipSuccess)
+        if (phase == 0 && (hipMemsetAsync(c->local, 0, 2 * c->region * sizeof(uint64_t), st) != hipSuccess ||
+                           hipMemsetAsync(c->reduced_g[0], 0, (size_t)(c->reduced_g[1] - c->reduced_g[0]) * 2 * sizeof(unsigned long long), st) != hipSuccess))
             return cfail(VH_E_HIP, "vh_comm: re-zero at the tag wrap failed");
     }
     return VH_OK;
@@ -301,24 +300,23 @@ vh_comm_t* vh_comm_create(int rank, int world, size_t cap_elems, void* handle_ou
     const size_t red_elems = cap_elems < VH_COMM_ONESHOT_MAX ? cap_elems : VH_COMM_ONESHOT_MAX;
     if ((e = hipMemset(c->local, 0, bytes)) != hipSuccess || (e = hipMalloc(reinterpret_cast<void**>(&c->err), 2 * sizeof(int))) != hipSuccess ||
         (e = hipMemset(c->err, 0, 2 * sizeof(int))) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->reduced[0]), 2 * ((red_elems + 63) & ~size_t(63)) * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->reduced_g[0]), 2 * vh_gran_gemv_len((int)red_elems) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->reduced_g[0], 0, 2 * vh_gran_gemv_len((int)red_elems) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipDeviceSynchronize()) != hipSuccess) {
         cfail(VH_E_HIP, "vh_comm_create: initialisation", e);
-        (void)hipFree(c->local); (void)hipFree(c->err); (void)hipFree(c->reduced[0]); delete c; return nullptr;   // (null pointers are no-ops)
+        (void)hipFree(c->local); (void)hipFree(c->err); (void)hipFree(c->reduced_g[0]); delete c; return nullptr;   // (null pointers are no-ops)
     }
     hipIpcMemHandle_t h;
     if ((e = hipIpcGetMemHandle(&h, c->local)) != hipSuccess) {
         cfail(VH_E_HIP, "vh_comm_create: hipIpcGetMemHandle", e);
-        (void)hipFree(c->local); (void)hipFree(c->err); (void)hipFree(c->reduced[0]); delete c; return nullptr;
+        (void)hipFree(c->local); (void)hipFree(c->err); (void)hipFree(c->reduced_g[0]); delete c; return nullptr;
     }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     memcpy(handle_out, &h, sizeof(h));
     c->peer[rank] = c->local;
     c->calls = 0;
     c->generation = 0;
-    c->reduced[1] = c->reduced[0] + ((red_elems + 63) & ~size_t(63));
-    c->counter = c->err + 1;
-    c->arrivals = 0;
+    c->reduced_g[1] = c->reduced_g[0] + vh_gran_gemv_len((int)red_elems);
     return c;
 }
 
@@ -440,15 +438,12 @@ int vh_comm_xchg_next(vh_comm* c, long count, int which, int consumer_blocks, Vh
     VhXchg x{};
     for (int r = 0; r < c->world; ++r) x.peer[r] = c->peer[r] + par * c->region;
     x.local = c->local + par * c->region;
-    x.reduced = c->reduced[which];
-    x.counter = c->counter;
+    x.reduced_g = c->reduced_g[which];
     x.err = c->err;
     x.cap = cap1;
     x.rank = c->rank; x.world = c->world; x.tag = tag;
     x.nred = consumer_blocks < 16 ? consumer_blocks : 16;
     if (x.nred > (int)(count / 2)) x.nred = (int)(count / 2);
-    c->arrivals += x.nred;
-    x.target = (int)c->arrivals;                 // compared modulo 2^32 on the device
     x.count = (int)count;
     x.loopback = c->loopback ? 1 : 0;
     *out = x;
@@ -470,7 +465,7 @@ void vh_comm_destroy(vh_comm_t* c) {
         if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     (void)hipFree(c->local);
     (void)hipFree(c->err);
-    (void)hipFree(c->reduced[0]);
+    (void)hipFree(c->reduced_g[0]);
     delete c;
 }
 

@@ -83,41 +83,16 @@ __device__ __forceinline__ void xchg_reduce(const VhXchg& cx) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             if (r < cx.world) s += __uint_as_float((unsigned)g[r]);          // rank order: the same sum on every rank
-        __hip_atomic_store(reinterpret_cast<unsigned*>(cx.reduced) + n, __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // published as a tagged granule in the GEMV layout: the readers' sweep (gran_read_gemv) needs neither a counter nor a drain
+        __hip_atomic_store(reinterpret_cast<xu64*>(cx.reduced_g) + vhk_gran_pos_gemv(n), ((xu64)cx.tag << 32) | (xu64)__float_as_uint(s),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my slice has left this CU
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cx.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// consumer, step 2 (AFTER the weight loads are in flight): the summed vector is complete.
-// Ordering: `reduced` is written and read ONLY with agent-scope atomics (4-byte write-through sc1 stores, 8-byte L1-bypassing sc1
-// loads: guide G16 "agent atomics both sides"), every reducer wave drains its stores (vmcnt(0)) before the block's one
-// relaxed arrival, so no release / acquire fence is needed and the consumer's weight loads stay in flight.
-// Residency: the nred reducer blocks are the FIRST blocks of the consumer grid, and every consumer grid of the decode step
-// (768 / 384 / <= 1024 blocks of 256 threads) is co-resident on one device's 256 CUs, so a waiting block can never keep a
-// reducer from being scheduled when each rank owns its GPU; ranks SHARING a device (tests) can starve each other, which is
-// why the spin is bounded and ends in the sticky error word rather than a hang.
-__device__ __forceinline__ void xchg_wait(const VhXchg& cx) {
-    if (cx.world == 0) return;
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while ((int)((unsigned)__hip_atomic_load(cx.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)cx.target) < 0) {   // modulo 2^32
-            if ((spins & 1023u) == 1023u && __hip_atomic_load(cx.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // someone else failed: keep ITS code
-            if (++spins > VH_XCHG_SPIN_LIMIT) {                       // this block's own time-out
-                __hip_atomic_store(cx.err, 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-}
-// 4 floats of a vector another CU (possibly on another XCD) published with agent-scope atomics: two 8-byte agent-scope loads
-__device__ __forceinline__ f32x4 xchg_ld4(const float* p) {
-    const xu64 a = __hip_atomic_load(reinterpret_cast<const xu64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const xu64 b = __hip_atomic_load(reinterpret_cast<const xu64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
-}
+// consumer, step 2 (AFTER the block's weight loads are in flight): load_add_norm reads the summed vector with gran_read_gemv.
+// Residency: the nred reducer blocks are the FIRST blocks of the consumer grid (lowest indices: dispatched first, and they wait
+// only for the peers' pushes), so a reading block never keeps a reducer from being scheduled when each rank owns its GPU; ranks
+// SHARING a device (tests) can starve each other — a waiting consumer grid holds the CUs a peer's producer needs —, which is why
+// they take one all-reduce kernel per exchange instead, and why every spin is bounded and ends in the sticky error word.
 
 // ---- granule vectors between the work items of the fused attention-block launch (VhGranVec, vh_kernels.h) ---------------------
 // Every wait below is WAVE-collective (all 64 lanes run the same number of polls; exits are decided with __all) and bounded: a
@@ -232,7 +207,11 @@ __device__ __forceinline__ void load_x(const float* __restrict__ x, int K, float
 template <int NJ>
 __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, const float* __restrict__ delta,
                                                const float* __restrict__ norm_w, float* __restrict__ x_out, int K,
-                                               float (&xr)[NJ][8], const bool coherent = false) {
+                                               float (&xr)[NJ][8], const VhXchg* cx = nullptr) {
+    // cx (world > 0): `delta` is the result of a fused exchange — read as granules (block barrier inside: every thread calls this)
+    float dg[NJ][8];
+    const bool fused = cx != nullptr && cx->world != 0;          // block-uniform
+    if (fused) gran_read_gemv<NJ>(VhGranVec{cx->reduced_g, cx->tag, cx->err}, K, dg);
     f32x4 xa[NJ][2], da[NJ][2], na[NJ][2];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -242,9 +221,9 @@ __device__ __forceinline__ float load_add_norm(const float* __restrict__ x_in, c
         xa[j][1] = reinterpret_cast<const f32x4*>(x_in)[cc * 2 + 1];
         na[j][0] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2];
         na[j][1] = reinterpret_cast<const f32x4*>(norm_w)[cc * 2 + 1];
-        if (delta && coherent) {   // block-uniform: the vector was published by other CUs of this launch (xchg_reduce)
-            da[j][0] = xchg_ld4(delta + (size_t)cc * 8);
-            da[j][1] = xchg_ld4(delta + (size_t)cc * 8 + 4);
+        if (fused) {
+            da[j][0] = f32x4{dg[j][0], dg[j][1], dg[j][2], dg[j][3]};
+            da[j][1] = f32x4{dg[j][4], dg[j][5], dg[j][6], dg[j][7]};
         } else if (delta) {
             da[j][0] = reinterpret_cast<const f32x4*>(delta)[cc * 2];
             da[j][1] = reinterpret_cast<const f32x4*>(delta)[cc * 2 + 1];
@@ -320,8 +299,7 @@ __global__ __launch_bounds__(256) void k_dec_gemv(const float* __restrict__ x_in
     float xr[NJ][8];
     float vals[R + 1];
     if (NORM) {
-        xchg_wait(xc);
-        vals[R] = load_add_norm<NJ>(x_in, xc.world ? xc.reduced : delta, norm_w, x_out, K, xr, xc.world != 0);
+        vals[R] = load_add_norm<NJ>(x_in, delta, norm_w, x_out, K, xr, &xc);
     } else {
         load_x<NJ>(x_in, K, xr);
         vals[R] = 0.f;
@@ -603,9 +581,8 @@ __global__ __launch_bounds__(256, 4) void k_dec_ablk(const VhDecAblk a) {
         uint4 w[RQ][NJ];
         ablk_issue_rows<NJ, RQ>(a.Wqkv, b * RQ, a.nqkv, a.H, w);
         float xr[NJ][8];
-        xchg_wait(a.cx);
         float vals[RQ + 1];
-        vals[RQ] = load_add_norm<NJ>(a.x_in, a.cx.world ? a.cx.reduced : a.delta, a.norm_w, a.x_out, a.H, xr, a.cx.world != 0);
+        vals[RQ] = load_add_norm<NJ>(a.x_in, a.delta, a.norm_w, a.x_out, a.H, xr, &a.cx);
         float acc[RQ];
         gemv_fma<NJ, RQ>(w, xr, acc);
 #pragma unroll
@@ -672,8 +649,7 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
         uint4 wr[8][NJ];
         gemv_issue<NJ, 8>(rrows, K, wr);
         float vals[9];
-        xchg_wait(cx);
-        vals[8] = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, x_out, K, xr, cx.world != 0);
+        vals[8] = load_add_norm<NJ>(x_in, delta, norm_w, x_out, K, xr, &cx);
         float lg[8];
         gemv_fma<NJ, 8>(wr, xr, lg);
 #pragma unroll
@@ -811,8 +787,7 @@ __global__ __launch_bounds__(256) void k_dec_lmhead(const float* __restrict__ x_
     const uint16_t* rows[LM_R];
     if (it < n_iter) { rows_of(it, rows); gemv_issue<NJ, LM_R>(rows, K, wa); }
     float xr[NJ][8];
-    xchg_wait(cx);
-    const float ss = load_add_norm<NJ>(x_in, cx.world ? cx.reduced : delta, norm_w, nullptr, K, xr, cx.world != 0);
+    const float ss = load_add_norm<NJ>(x_in, delta, norm_w, nullptr, K, xr, &cx);
     float inv = 0.f;
     float best = -INFINITY;
     int besti = 0x7fffffff;

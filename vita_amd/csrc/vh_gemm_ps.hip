@@ -388,7 +388,8 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     // specialised waves (vh_gemm_sp.hip).  Weight loads WITHOUT the non-temporal hint unless forced (ps_nt = 1): same time (527 vs 530 us gate|up,
     // prefill 8.64-8.71 ms per 8 layers either way) and 6 % fewer fabric-side fetches (2.35 vs 2.49 GB: profiles/r04_fetch_nt_ab.txt)
     if (cfg == 2) {
-        const int px = vh_tuning()->ps_xcd < 0 ? 0 : vh_tuning()->ps_xcd;
+        // auto = both (r06, profiles/r06_moe_xcd_ab.txt: down 258 -> 250 us, gate|up 505 -> 497 at uniform routing; 287 -> 286 / 537 -> 523 skewed)
+        const int px = vh_tuning()->ps_xcd < 0 ? 3 : vh_tuning()->ps_xcd;
         a.xcd_group = (a.W_up ? (px >> 1) : px) & 1;
         return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt > 0);
     }

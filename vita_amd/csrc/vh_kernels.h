@@ -47,24 +47,25 @@ VhTuning* vh_tuning();
 
 // ---- tensor-parallel exchange fused into the batch-1 decode kernels (vh_comm.hip fills it, vh_decode.hip uses it) -------
 // One all-reduce(sum) of a `count`-element fp32 vector = one VhXchg, used twice:
-//   * the PRODUCER kernel (O projection, MoE down projection) pushes every output element straight into slot `rank` of every
-//     peer's receive region as an 8-byte {value, tag} granule instead of storing it locally (no separate push pass);
-//   * the CONSUMER kernel (gate|up, next layer's QKV, LM head) needs the whole summed vector in every block (RMSNorm):
-//     its first `nred` blocks poll the world slots of their slice in THIS rank's region, sum them in rank order (bit-identical
-//     on all ranks) and publish the slice to `reduced` with 8-byte agent-scope atomic stores, then count themselves in;
-//     every block puts its weight loads in flight first, waits for `counter` to reach `target`, and reads `reduced` with
-//     8-byte agent-scope atomic loads (guide G16 "8-B agent atomics both sides": no fence, the weight loads stay in flight).
+//   * the PRODUCER (O-projection blocks of the attention-block launch, MoE down projection) pushes every output element straight
+//     into slot `rank` of every peer's receive region as an 8-byte {value, tag} granule instead of storing it locally;
+//   * the CONSUMER launch (gate|up, the next layer's attention block, the LM head) needs the whole summed vector in every block
+//     (RMSNorm): its first `nred` blocks poll the world slots of their slice in THIS rank's region — all slots of an element at
+//     once —, sum them in rank order (bit-identical on all ranks) and publish the slice to `reduced_g` as tagged granules again
+//     (GEMV layout, the exchange's tag); every block puts its weight loads in flight first and then reads the vector with the
+//     granule sweep of the fused attention block (vh_decode.hip gran_read_gemv: one wave polls one granule, then every wave sweeps
+//     its own) — the data is the flag: no counter, no fence, no drain between reducers and readers (r03-r05 published plain floats
+//     behind an arrival counter: one write-through drain + barrier + atomic + counter poll more per exchange).
 // world == 0: no exchange (plain local delta buffers, the single-GPU path).
 struct VhXchg {
     uint64_t* peer[8];              // every rank's receive region of this call's parity (peer[rank] == local)
     uint64_t* local;
-    float* reduced;                 // this rank's summed vector (device memory of the communicator)
-    int* counter;                   // reducer-block arrivals since the communicator was created (monotonic)
+    unsigned long long* reduced_g;  // this rank's summed vector as granules in the GEMV layout (device memory of the communicator)
     int* err;                       // sticky time-out word (vh_comm_status)
     unsigned long long cap;         // slot stride in granules
     int rank, world;
     unsigned tag;
-    int target, nred, count;
+    int nred, count;
     int loopback;                   // 1: one rank plays all `world` ranks (every peer[] is the local region): the value goes to slot `rank`,
                                     // zeros to the other slots — the same stores, polls and rank-ordered sum as a real exchange, no link
 };

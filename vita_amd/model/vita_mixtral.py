@@ -87,6 +87,8 @@ class VITAMixtralForCausalLM(_HipModule):
                                     max_seqs=max_seqs, max_ctx=kv_pool_tokens)   # max_seqs > 0: paged KV pool (serving)
         self.lookahead = 8          # decode steps enqueued per host synchronisation in generate()
         self.last_timing = {}
+        self.overlap_encoders = True      # audio tower on a side stream under the vision tower (prepare_inputs_labels_for_multimodal)
+        self._enc_stream = None
 
     def default_kv_pool_tokens(self, max_seqs, gpu_memory_utilization=None, world=1):
         """Paged-KV pool for `max_seqs` concurrent requests when the caller names no size (vLLM sizes its block pool from
@@ -169,11 +171,27 @@ class VITAMixtralForCausalLM(_HipModule):
             ids = ids[attention_mask[0].bool().to(ids.device)]
         if type(images) is list or images.ndim == 5:
             images = torch.cat([im for im in images], dim=0)
-        image_features = self.encode_images(images)                       # [n_tiles, 256, H]
-        if audios is not None:
-            audio_features = self.get_audio_encoder()(audios["audios"], audios["lengths"])
-        else:
+        if audios is None:
             raise ValueError("audios must be provided (the reference passes a dummy clip for text/image prompts)")
+        if self.overlap_encoders and images.is_cuda:
+            # (r06) the two towers are independent (vita_arch.py:189 encodes one after the other) and each is a chain of short,
+            # latency-bound launches that leaves most of the chip idle: the audio tower runs on a side stream under the vision
+            # tower + projector (scratch sets are per stream, vita_amd/ops.py)
+            cur = torch.cuda.current_stream(dev)
+            if self._enc_stream is None:
+                self._enc_stream = torch.cuda.Stream(device=dev)
+            side = self._enc_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                audio_features = self.get_audio_encoder()(audios["audios"], audios["lengths"])
+            image_features = self.encode_images(images)                   # [n_tiles, 256, H]
+            cur.wait_stream(side)
+            for v in audio_features.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
+        else:
+            image_features = self.encode_images(images)                   # [n_tiles, 256, H]
+            audio_features = self.get_audio_encoder()(audios["audios"], audios["lengths"])
         ids_np = ids.detach().cpu().numpy()
         n_img, n_aud = int((ids_np == IMAGE_TOKEN_INDEX).sum()), int((ids_np == AUDIO_TOKEN_INDEX).sum())
         aud_emb = audio_features["inputs_embeds"]
