@@ -83,9 +83,20 @@ def silu(x):
     return (x / (1.0 + np.exp(-x))).astype(F32)
 
 
-def moe(x, lw, top_k=2):
-    """x [S, H].  lw: gate [E,H], w1/w3 [E,I,H], w2 [E,H,I]."""
+def moe(x, lw, top_k=2, force=None):
+    """x [S, H].  lw: gate [E,H], w1/w3 [E,I,H], w2 [E,H,I].
+    force (test infrastructure, default off): {row: (e_a, e_b)} — take THESE experts for a row instead of the router's top-k (their
+    weights are the row's own softmax probabilities, renormalised): used where the router's own margin is a tie at fp32 noise and a
+    checked implementation legitimately took the other expert, to follow that branch of the (ill-conditioned) reference."""
     idx, val = router(x, lw["gate"], top_k)
+    if force:
+        probs = softmax((x @ lw["gate"].T).astype(F32))
+        idx, val = idx.copy(), val.copy()
+        for row, ids in force.items():
+            ids = np.asarray(ids, dtype=idx.dtype)
+            pv = probs[row, ids]
+            idx[row] = ids
+            val[row] = (pv / np.sum(pv, dtype=F32)).astype(F32)
     out = np.zeros_like(x, dtype=F32)
     for e in range(lw["gate"].shape[0]):
         tok, slot = np.nonzero(idx == e)

@@ -63,11 +63,14 @@ def embed_rows(t, ids, seed):
     return out
 
 
-def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=False, margins=False):
+def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=False, margins=False, route_override=None,
+            keep_inputs=False, resume=None):
     """One causal forward over embeds [S, H] (positions 0..S-1) through layers 0..n_layers-1 + final norm + LM head.
     Returns dict(logits [S - logits_from, V], hidden {layer: [S, H]}, route [n_layers, S, 2] int32); margins=True adds
     margin [n_layers, S]: the router-logit distance between the 2nd and the 3rd expert (how far each top-2 decision is
-    from flipping)."""
+    from flipping).  route_override {layer: {row: (e_a, e_b)}}: follow a given expert pair at a TIED decision (om.moe force);
+    keep_inputs: also return inputs {layer: x at the layer's entry}; resume (layer, x): start at that layer from that state (the
+    rows of `route` / `margin` of the skipped layers are left unset)."""
     n_layers = t.num_hidden_layers if n_layers is None else n_layers
     S = embeds.shape[0]
     d, nq, nkv = t.head_dim, t.num_attention_heads, t.num_key_value_heads
@@ -76,8 +79,14 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
     x = embeds.astype(F32)
     hidden, route = {}, np.empty((n_layers, S, 2), np.int32)
     margin = np.empty((n_layers, S), F32) if margins else None
-    for l in range(n_layers):
+    inputs = {}
+    l_start = 0
+    if resume is not None:
+        l_start, x = int(resume[0]), np.asarray(resume[1], F32).copy()
+    for l in range(l_start, n_layers):
         t0 = time.time()
+        if keep_inputs:
+            inputs[l] = x.copy()
         L = bufs.load(t, l, seed)
         t1 = time.time()
         xn = om.rmsnorm(x, L["ln1"], t.rms_norm_eps)
@@ -88,7 +97,7 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
         a = om.attention(q, k, v, 0)
         x = (x + a @ L["o"].T).astype(F32)
         xn = om.rmsnorm(x, L["ln2"], t.rms_norm_eps)
-        y, idx, _ = om.moe(xn, L, t.num_experts_per_tok)
+        y, idx, _ = om.moe(xn, L, t.num_experts_per_tok, force=(route_override or {}).get(l))
         route[l] = idx
         if margins:
             rl = np.sort((xn @ L["gate"].T).astype(F32), axis=-1)
@@ -104,6 +113,8 @@ def forward(t, seed, embeds, n_layers=None, capture=(), logits_from=0, verbose=F
     out = dict(logits=logits, hidden=hidden, route=route)
     if margins:
         out["margin"] = margin
+    if keep_inputs:
+        out["inputs"] = inputs
     return out
 
 

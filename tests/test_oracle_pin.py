@@ -130,3 +130,24 @@ def test_torch_encoder_baseline_matches_the_checker():
         got_a = ot.whale_encoder(sd, cfg.audio, fb).numpy()
     assert_close("torch ViT + projector vs fp64 checker", got_v, oe.projector(sd, oe.internvit_tower(sd, cfg.vision, pix)), atol=2e-6)
     assert_close("torch Whale + adapter vs fp64 checker", got_a, oe.whale_encoder(sd, cfg.audio, fb)[0], atol=5e-6)
+
+
+def test_moe_forced_pair_is_the_routers_pair_when_they_agree():
+    """oracle/mixtral.py moe(force=...) (the tie-branch hook of tests/test_video_shape_gpu.py): forcing the pair the router picks anyway
+    changes nothing; forcing another pair changes that row only, with that pair's renormalised probabilities as weights."""
+    from oracle import mixtral as om
+    rng = np.random.default_rng(3)
+    H, I, E, S = 32, 48, 8, 6
+    lw = dict(gate=rng.standard_normal((E, H)).astype(np.float32), w1=rng.standard_normal((E, I, H)).astype(np.float32) * 0.1,
+              w3=rng.standard_normal((E, I, H)).astype(np.float32) * 0.1, w2=rng.standard_normal((E, H, I)).astype(np.float32) * 0.1)
+    x = rng.standard_normal((S, H)).astype(np.float32)
+    y0, idx0, val0 = om.moe(x, lw)
+    y1, idx1, val1 = om.moe(x, lw, force={2: tuple(int(v) for v in idx0[2])})
+    assert np.array_equal(idx0, idx1) and np.allclose(val0, val1, atol=1e-7) and np.allclose(y0, y1, atol=1e-6)
+    other = tuple(e for e in range(E) if e not in idx0[4])[:2]
+    y2, idx2, val2 = om.moe(x, lw, force={4: other})
+    assert tuple(idx2[4]) == other and abs(float(val2[4].sum()) - 1.0) < 1e-6
+    keep = np.arange(S) != 4
+    assert np.allclose(y2[keep], y0[keep], atol=1e-6) and not np.allclose(y2[4], y0[4], atol=1e-3)
+    p = om.softmax((x[4:5] @ lw["gate"].T).astype(np.float32))[0]
+    assert np.allclose(val2[4], p[list(other)] / p[list(other)].sum(), atol=1e-6)

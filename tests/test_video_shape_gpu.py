@@ -8,10 +8,12 @@ duplex demo feeds the same shape, web_demo/web_interactive_demo.py:284-366) at t
   the longest prefill any test runs) through VITA_VIDEO_LAYERS backbone layers (default 16; the 32-layer run of r06 is
   profiles/r06_video_shape_parity_32.txt), 6 greedy steps.
   ONE of the 37 504 router decisions of the first 16 layers — row 2272 at layer 10 — sits on a tie of the oracle's own 2nd / 3rd expert logits
-  (margin below fp32 re-association noise); the device takes the other expert there, that row's MoE output differs from layer 10 on, and from
-  layer 11 on every LATER row (they attend to its K / V) moves with it — by up to 1.7e-2 at layer 15.  The check below names the tie, requires the
-  oracle's margin to be one, and excuses exactly those rows from the hidden-state bar (it used to excuse the tied row alone); logits
-  of the last row and the greedy ids keep the north-star bar whatever happened upstream.
+  (margin 6.4e-06, below fp32 re-association noise); the device takes the other expert there, that row's MoE output differs from layer 10 on, and
+  from layer 11 on every LATER row (they attend to its K / V) moves with it — last row included (logits 1.3e-3 off the oracle's branch at 16
+  layers).  The reference is ill-conditioned at such a decision, so the test follows BOTH of its branches: a decision may differ only where the
+  oracle's margin is a tie, and the oracle is then re-run from that layer with the device's pair forced at that one decision (oracle/mixtral.py
+  moe force=, oracle/stream.py route_override / resume); against that pass nothing is excused — every other router decision, hidden states,
+  logits < 1e-3 and ids (the first form of this check excused the tied row alone).
 
 against the fp64 encoder restatements and the layer-streamed fp32 oracle: encoder outputs, spliced embeddings, every router
 decision, hidden states, logits < 1e-3, ids ==.  (n = 5 tiles: tests/test_assets_gpu.py; n = 1: tests/test_realgeom_gpu.py.)"""
@@ -82,37 +84,47 @@ def test_eight_frame_video_prompt_matches_oracle(dev):
 
     full = np.concatenate([o_emb, stream.embed_rows(t, toks[:-1], SEED)], 0)
     t0 = time.time()
-    ref = stream.forward(t, SEED, full, n_layers=L, capture=sorted(d_hid), logits_from=S - 1, margins=True)
+    ref = stream.forward(t, SEED, full, n_layers=L, capture=sorted(d_hid), logits_from=S - 1, margins=True, keep_inputs=True)
     print(f"[video] oracle backbone ({L} layers, {full.shape[0]} rows) in {time.time() - t0:.1f}s")
-    # Router decisions: 2344 rows x L layers of a DISCONTINUOUS choice.  A row is excused from the layer on where the ORACLE's own
-    # margin between its 2nd and 3rd expert is a tie at fp32 re-association noise (< TIE): the device then legitimately follows the
-    # other expert and that row's hidden state goes its own way (r05: at 16 layers one row of 37 504 decisions, row 2272 at layer 10).
-    # Every other decision must be the oracle's, and the last-row logits / greedy ids keep the north-star bar.
+    # Router decisions: 2344 rows x L layers of a DISCONTINUOUS choice.  Where the ORACLE's own margin between its 2nd and 3rd expert is a
+    # tie at fp32 re-association noise (< TIE) the device may legitimately take the other expert; that row's MoE output then differs,
+    # and from the next layer on every LATER row (they attend to its K / V) moves with it — last row and logits included (r06 at 16
+    # layers: row 2272 at layer 10, margin 6.4e-06, logits 1.3e-3 off the oracle's branch).  Both branches are "the reference": the
+    # oracle is re-run FROM THE TIED LAYER with the device's pair forced at that one decision (om.moe force), and everything — every
+    # other router decision, hidden states, logits < 1e-3, ids — must match THAT pass with no row excused.  A decision that differs
+    # where the margin is not a tie fails at once.
     TIE, MAX_TIES = 3e-4, 4
-    diff = (np.sort(route, -1) != np.sort(ref["route"][:, :S], -1)).any(-1)             # [L, S]
-    # a row that comes AFTER a tied row attends to it from the next layer on: its later decisions may legitimately differ too.  Only
-    # decisions that are not downstream of an earlier tie count as independent events; each must be a tie of the oracle itself.
-    ties = []                                                                          # (layer, row), in layer order
-    for l0 in range(diff.shape[0]):
-        for r in np.flatnonzero(diff[l0]):
-            downstream = any((lt < l0 and r >= rt) or (lt <= l0 and r == rt) for lt, rt in ties)
-            if downstream:
-                continue
+    S_full = full.shape[0]
+    dev_route = np.sort(route, -1)                                                     # [L, S]
+    override, n_ties = {}, 0
+    while True:
+        diff = (dev_route != np.sort(ref["route"][:, :S], -1)).any(-1)                 # [L, S]
+        if not diff.any():
+            break
+        l0 = int(np.argmax(diff.any(1)))                                               # first layer with a difference
+        rows = np.flatnonzero(diff[l0])
+        for r in rows:
             mg = float(ref["margin"][l0, r])
             print(f"  row {int(r)}: decision differs at layer {l0}, oracle margin (2nd - 3rd expert logit) {mg:.2e}")
             assert mg < TIE, f"row {int(r)} layer {l0}: the device took another expert where the oracle's margin is {mg:.2e} (not a tie)"
-            ties.append((l0, int(r)))
-    print(f"router top-2 sets: {route.shape[0] * S} decisions, {int(diff.sum())} differ, {len(ties)} independent tie(s) {ties}")
-    assert len(ties) <= MAX_TIES
+            override.setdefault(l0, {})[int(r)] = tuple(int(v) for v in route[l0, r])
+        n_ties += len(rows)
+        assert n_ties <= MAX_TIES, f"{n_ties} tied decisions"
+        t0 = time.time()
+        prev = ref
+        ref = stream.forward(t, SEED, full, n_layers=L, capture=sorted(d_hid), logits_from=S - 1, margins=True, keep_inputs=True,
+                             route_override=override, resume=(l0, prev["inputs"][l0]))
+        for l in range(l0):                                                            # the layers in front of the tie are unchanged
+            ref["route"][l], ref["margin"][l], ref["inputs"][l] = prev["route"][l], prev["margin"][l], prev["inputs"][l]
+        for l in prev["hidden"]:
+            if l < l0:
+                ref["hidden"][l] = prev["hidden"][l]
+        print(f"[video] oracle re-run from layer {l0} with the device's pair at {sorted(override[l0])} in {time.time() - t0:.1f}s")
+        assert S_full == full.shape[0]
+    print(f"router top-2 sets: {route.shape[0] * S} decisions identical" + (f" on the branch of {n_ties} tied decision(s) {override}" if n_ties else ""))
     for l in sorted(d_hid):
-        keep = np.ones(S, bool)
-        for lt, rt in ties:
-            if l >= lt:
-                keep[rt] = False              # the tied row itself: its MoE output of layer lt differs
-            if l > lt:
-                keep[rt:] = False             # every later row has attended to it since layer lt + 1
         h_ref = ref["hidden"][l][:S]
-        assert_close(f"hidden after layer {l} ({int(keep.sum())} of {S} rows)", d_hid[l][keep], h_ref[keep], atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
+        assert_close(f"hidden after layer {l}", d_hid[l], h_ref, atol=3e-4 * float(np.abs(h_ref).max()), rtol=1e-3)
     ref_ids = ref["logits"].argmax(-1).tolist()
     print("device ids", toks, "oracle ids", ref_ids)
     print(report(f"logits of the {T_NEW} steps", logits, ref["logits"]))

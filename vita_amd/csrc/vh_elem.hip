@@ -350,8 +350,8 @@ __global__ void k_rope_kv(const float* __restrict__ qkv, long ldqkv, float* __re
 // ---- the same, tile-wise, for a ONE-SHOT prefill whose attention is the flash kernel (k_attn_fa, vh_attn.hip): besides q_out
 // and the fp32 KV cache it writes K and V as the MFMA-ready bf16 hi/lo tile images that kernel keeps in LDS, converted ONCE where
 // they are produced (r04-r05: every block of k_attn_fa converted every tile it read from fp32 — a third of that kernel).
-// grid (64-row tiles, 2 nkv): y < nkv: K / V tile of KV head y (threads 256-511 K with RoPE, 0-255 V; the image is assembled in
-// LDS with k_attn_fa's staging arithmetic and copied out in 16-byte pieces); y >= nkv: the four query heads of KV head y - nkv.
+// grid (64-row tiles, nkv + nq): y < nkv: K / V tile of KV head y (threads 256-511 K with RoPE, 0-255 V; the image is assembled in
+// LDS with k_attn_fa's staging arithmetic and copied out in 16-byte pieces); y >= nkv: query head y - nkv.
 // Image layout (64 KB per (head, tile), = the LDS buffer of k_attn_fa): K planes [half][64 keys][128 B], 16-byte chunks
 // XOR-swizzled by (key >> 1) & 7; V planes TRANSPOSED [rho(col)][64 keys], rho(d) = 16 (d % 8) + d / 8, chunks swizzled by
 // (rho >> 1) & 7.  Rows past S are zeros (finite: their probabilities are 0).  Same fp32 values as k_rope_kv (same slab order).
@@ -380,15 +380,14 @@ __global__ __launch_bounds__(512) void k_rope_kv_img(const float* __restrict__ q
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * KVI_PL];
     const int t = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
     const int ns = nslab_dev ? *nslab_dev : 1;
-    if (y >= nkv) {                                        // ---- q rows of the four heads of KV head y - nkv
-        const int g = y - nkv;
-#pragma unroll 2
-        for (int i = 0; i < 8; ++i) {
+    if (y >= nkv) {                                        // ---- q rows of head y - nkv (one block per head and tile: 2 items per thread)
+        const int head = y - nkv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             const int item = tid + 512 * i;
-            const int c = item & 15, hh = (item >> 4) & 3, r = item >> 6;
+            const int c = item & 15, r = item >> 4;
             const int s = 64 * t + r;
             if (s >= S) continue;
-            const int head = 4 * g + hh;
             const float* src = qkv + (size_t)s * ldqkv + head * 128;
             const f32x4 a = kvi_sum4(src + 4 * c, ns, slab_stride), b = kvi_sum4(src + 64 + 4 * c, ns, slab_stride);
             const f32x4 cs = *reinterpret_cast<const f32x4*>(rope_cos + (size_t)s * 64 + 4 * c);
@@ -694,7 +693,7 @@ int vhk_rope_kv_img(hipStream_t st, const float* qkv, long ldqkv, float* q_out, 
     if (S == 0) return 0;
     const int tiles = (S + 63) / 64;
     if (nq != 4 * nkv || !img || tiles > img_tiles || (ldqkv % 4) != 0 || (slab_stride % 4) != 0) return -1;
-    hipLaunchKernelGGL(k_rope_kv_img, dim3(tiles, 2 * nkv), dim3(512), 0, st, qkv, ldqkv, q_out, kcache, vcache, rope_cos, rope_sin, S,
+    hipLaunchKernelGGL(k_rope_kv_img, dim3(tiles, nkv + nq), dim3(512), 0, st, qkv, ldqkv, q_out, kcache, vcache, rope_cos, rope_sin, S,
                        nq, nkv, max_ctx, table, nslab_dev, slab_stride, img, img_tiles);
     return 0;
 }
