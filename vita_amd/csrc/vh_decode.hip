@@ -500,20 +500,41 @@ __device__ __forceinline__ bool dec_attn_finish(const int h, const int sp, const
     __syncthreads();
     if (!last_s) return false;
     if (wid < G) {
+        // Merge of the nsplit partials of this head.  Every partial word is an L1-bypassing (sc1) load, ~0.7 us each when waited for
+        // one at a time — r06's first form of this loop did exactly that (a loop-carried max, then four loads per iteration) and a
+        // 9-split merge cost more than the tile's scores and PV together.  Now: lane s loads (m, l) of split s — ONE round trip for the
+        // statistics —, the output partials come eight loads at a time, and the sums run in the OLD order (ascending split,
+        // one fma chain) with the lane's values broadcast by readlane: same bits as r01-r05.
         const float* ml = part_ml + (size_t)head * max_splits * 2;
         const float* po = part_o + (size_t)head * max_splits * 128;
         float M = -INFINITY;
-        for (int sidx = 0; sidx < nsplit; ++sidx) M = fmaxf(M, part_load2(ml + sidx * 2).x);
+        for (int s0 = 0; s0 < nsplit; s0 += 64) {
+            const int sl = s0 + lane;
+            const float mv = sl < nsplit ? part_load2(ml + sl * 2).x : -INFINITY;
+            M = fmaxf(M, wave_max(mv));
+        }
         float den = 0.f;
         float2 num = make_float2(0.f, 0.f);
-#pragma unroll 4
-        for (int sidx = 0; sidx < nsplit; ++sidx) {
-            const float2 mlv = part_load2(ml + sidx * 2);
-            const float wgt = __expf(mlv.x - M);
-            den = fmaf(wgt, mlv.y, den);
-            const float2 ov = part_load2(po + (size_t)sidx * 128 + 2 * lane);
-            num.x = fmaf(wgt, ov.x, num.x);
-            num.y = fmaf(wgt, ov.y, num.y);
+        for (int s0 = 0; s0 < nsplit; s0 += 64) {
+            const int sl = s0 + lane;
+            const float2 mlv = sl < nsplit ? part_load2(ml + sl * 2) : make_float2(-INFINITY, 0.f);
+            const float wl = sl < nsplit ? __expf(mlv.x - M) : 0.f;
+            const int cnt = min(64, nsplit - s0);
+            for (int k0 = 0; k0 < cnt; k0 += 8) {
+                float2 ov[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ov[u] = part_load2(po + (size_t)(s0 + min(k0 + u, cnt - 1)) * 128 + 2 * lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + u < cnt) {                  // (wave-uniform)
+                        const float wgt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), k0 + u));
+                        const float lv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mlv.y), k0 + u));
+                        den = fmaf(wgt, lv, den);
+                        num.x = fmaf(wgt, ov[u].x, num.x);
+                        num.y = fmaf(wgt, ov[u].y, num.y);
+                    }
+                }
+            }
         }
         const float inv = 1.0f / den;
         if (GR) {
