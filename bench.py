@@ -609,9 +609,6 @@ def main():
     lay0 = packed["layers"][0]
     I_r = lay0["w1"].shape[1]
     gateup_bytes = 2 * 2 * I_r * t.hidden_size * 2 + t.num_local_experts * t.hidden_size * 2   # per launch, this rank
-    moe_fused = eng.decode_schedule().endswith("+moe")       # shards with <= 4096 expert columns: gate|up AND down are one launch (k_dec_moe)
-    if moe_fused:
-        gateup_bytes += 2 * I_r * t.hidden_size * 2
     k_ms = tot_ms / max(n_samp, 1)
     achieved = gateup_bytes / (k_ms * 1e-3) / 1e9 if n_samp else None
     ctx_mid = S + Wm + K // 2
@@ -643,7 +640,7 @@ def main():
                        # how the timed steps ran a layer's attention block: "fused-attention-block" = ONE launch (QKV rows, attention tiles
                        # and O rows as work items with granule hand-offs), "three-launches" = QKV, attention, O projection
                        "decode_schedule": eng.decode_schedule(),
-                       "launches_per_layer": {"fused-attention-block+moe": 2, "fused-attention-block": 3, "three-launches+moe": 4}.get(eng.decode_schedule(), 5)},
+                       "launches_per_layer": 3 if eng.decode_schedule() == "fused-attention-block" else 5},
             "prefill_ms": round(phase["prefill_ms"], 3), "vit_projector_ms": round(phase["vit_proj_ms"], 3),
             "audio_encoder_ms": round(phase["audio_ms"], 3),
             # time to first token of one request: encoders (concurrent) + projector + splice, then the prefill; `ttft_serial_ms` is the
@@ -659,8 +656,7 @@ def main():
                                          "(SURVEY 8(d)); MFMA floor is lower"},
             "decode_effective_GBps_per_gpu": round(eff, 1),
             "decode_effective_frac_of_8TBps": round(eff / HBM_PEAK_GBPS, 4),
-            "roofline": {"bound": "hbm", "kernel": ("k_dec_moe (router + gate|up + down GEMVs of the 2 routed experts, one launch)" if moe_fused else
-                                                    "k_dec_gateup (router + gate|up GEMV of the 2 routed experts)"),
+            "roofline": {"bound": "hbm", "kernel": "k_dec_gateup (router + gate|up GEMV of the 2 routed experts)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                          # the same fraction under its two clocks: live HIP events around the launch inside THIS run's timed steps (they

@@ -13,6 +13,7 @@ alg = {   # algorithmic bytes per launch, released geometr
     "k_dec_gateup": ("k_dec_gateup", 2 * 2 * I * H * 2 + E * H * 2),
     "k_dec_down": ("k_dec_down", 2 * H * I * 2),
     "k_dec_lmhead": ("k_dec_lmhead", V * H * 2),
+    "k_dec_ablk": ("k_dec_ablk<2, 2, 8>", (NQKV + H) * H * 2 + 2 * 8 * 128 * 4 * 600),       # r06: fused QKV + attention + O launch (+ ~600 keys of fp32 K / V)
     "k_dec_gemv_qkv": (("k_dec_gemv<2, 8, true,", "k_dec_gemv<2, 8, true>"), NQKV * H * 2),       # r05: a fourth template argument (granule I/O)
     "k_dec_gemv_oproj": (("k_dec_gemv<2, 8, false,", "k_dec_gemv<2, 8, false>"), H * H * 2),
     "k_gemm_ps_moe_gateup (prefill S=552)": (("k_gemm_sp<true", "k_gemm_ps<true"), E * 2 * I * H * 2),   # r04: the specialised kernel is the default

@@ -235,7 +235,7 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
     # the default decode schedule of a tensor-parallel rank is the attention block as ONE launch (k_dec_ablk); only ranks that SHARE a
     # device with the exchange FORCED into the kernels keep the three small launches (a waiting k_dec_ablk grid owns its CUs' register
     # files: the peer it waits for would find no CU).  The fused exchange INSIDE k_dec_ablk is covered by test_loopback_* below.
-    want = "three-launches" if ret[0][5] == "fused" else "fused-attention-block+moe"      # (tiny shards: the MoE is one launch too)
+    want = "three-launches" if ret[0][5] == "fused" else "fused-attention-block"
     assert ret[0][6] == ret[1][6] == want, (ret[0][5], ret[0][6], ret[1][6])
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
@@ -328,9 +328,7 @@ def test_tp_released_shard_shapes_match_oracle(dev, world, layers):
     assert len(names) == 1, dict((r, ret[r][0]) for r in range(world))
     _require_ipc(names, f"released-shape TP = {world}")
     assert all(ret[r][3] == 0 for r in range(world)) and all(ret[r][4] == "kernel" for r in range(world))
-    # TP = 8 / 4: attention block AND MoE as one launch each; TP = 2 (7168 expert columns): the attention block only
-    want = "fused-attention-block+moe" if world >= 4 else "fused-attention-block"
-    assert all(ret[r][5] == want for r in range(world)), {r: ret[r][5] for r in range(world)}
+    assert all(ret[r][5] == "fused-attention-block" for r in range(world)), {r: ret[r][5] for r in range(world)}
     cfg = VitaConfig()
     t = cfg.text
     ids = np.random.default_rng(11).integers(3, t.vocab_size, size=REAL_TP_S).tolist()
@@ -385,7 +383,7 @@ def test_loopback_exchange_is_bit_identical_to_no_exchange(dev, world, exchange)
             eng.close()
             if comm:
                 comm.destroy()
-    assert runs[0][2] == runs[1][2] == ("fused-attention-block+moe" if world >= 4 else "fused-attention-block")
+    assert runs[0][2] == runs[1][2] == "fused-attention-block"
     assert runs[1][3] == 0, f"exchange spin time-out (phase {runs[1][3]})"
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     # the vocab-sharded head: the loop-back run scores this rank's rows only; they must equal the same rows of ... the same run without

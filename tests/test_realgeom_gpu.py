@@ -245,6 +245,6 @@ def test_tp_full_depth_omni_matches_oracle(run, oracle_ref, tmp_path, world):
     err = float(np.abs(lg0 - ref_lg).max())
     print(f"TP = {world}, {L} layers, S = 552 omni request: ids {toks}, oracle {ref_ids}, TP = 1 device {run['toks'][:TP8_NEW]}, "
           f"max |logit diff| {err:.2e}, exchange form {ret[0][4]}, decode schedule {ret[0][7]}")
-    assert all(ret[r][7] == ("fused-attention-block+moe" if world >= 4 else "fused-attention-block") for r in range(world)), {r: ret[r][7] for r in range(world)}
+    assert all(ret[r][7] == "fused-attention-block" for r in range(world)), {r: ret[r][7] for r in range(world)}
     assert toks == ref_ids
     assert err < 1e-3

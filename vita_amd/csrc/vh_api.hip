@@ -423,8 +423,6 @@ struct vh_mixtral {
         counters = cv.take<int>(4);  // {pos, n_generated, attn_done (monotonic), device error flag}
         g_qkv = cv.take<unsigned long long>(nqkv);
         g_attn = cv.take<unsigned long long>(vh_gran_gemv_len(nq * hd));
-        g_h = cv.take<unsigned long long>(2 * vh_gran_gemv_len(I <= 4096 ? I : 8));   // fused MoE launch (shards with I <= 4096 only)
-        g_route = cv.take<unsigned long long>(256);
         // ---- everything whose size follows max_ctx / max_new / logit_rows: behind the fixed part ---------------------------
         out_tokens = cv.take<int>(c.max_new > 0 ? c.max_new : 1);
         part_o = cv.take<float>((size_t)nq * max_splits * hd);
@@ -470,9 +468,9 @@ struct vh_mixtral {
     }
     // ---- fused attention-block launch (k_dec_ablk): q|k|v and the attention output travel between its work items as
     // tagged granules; a tag is used once per (step, layer, vector)
-    unsigned long long *g_qkv = nullptr, *g_attn = nullptr, *g_h = nullptr, *g_route = nullptr;   // granule vectors (VhGranVec)
+    unsigned long long *g_qkv = nullptr, *g_attn = nullptr;   // granule vectors (VhGranVec)
     unsigned gran_epoch = 0;                         // last granule tag handed out (0 = never written)
-    int schedule_state = -1;                         // last decode call: -1 none yet, else bit 0 = fused attention-block launch, bit 1 = fused MoE launch
+    int schedule_state = -1;                         // attention block of the last decode call: -1 none yet, 0 three launches, 1 one fused launch
     unsigned next_tag() { if (++gran_epoch == 0) ++gran_epoch; return gran_epoch; }
     vh_comm_t* comm = nullptr;   // the library's IPC all-reduce (not owned)
     hipStream_t cs = nullptr;    // communication stream of the overlapped tensor-parallel prefill
@@ -1067,14 +1065,9 @@ int vh_mixtral_decode_schedule(const vh_mixtral_t* m) { return m ? m->schedule_s
 
 // Attention block of a decode layer as one fused launch (k_dec_ablk) or as three (QKV, attention, O projection): vh_tune("dec_fused").
 static bool fused_wanted(const vh_mixtral* m) {
-    const int want = vh_tuning()->dec_fused;        // -1 auto, 0 never, bit 0: wherever the kernel has an instantiation
-    if (want == 0 || (want > 0 && !(want & 1))) return false;
+    const int want = vh_tuning()->dec_fused;        // -1 auto, 0 never, 1 wherever the kernel has an instantiation
+    if (want == 0) return false;
     return vhk_dec_ablk_supported(m->H, m->nq, m->nkv) != 0;
-}
-static bool fused_moe_wanted(const vh_mixtral* m) {
-    const int want = vh_tuning()->dec_fused;        // bit 1 (auto: on): tensor-parallel shards (I <= 4096)
-    if (want == 0 || (want > 0 && !(want & 2))) return false;
-    return vhk_dec_moe_supported(m->H, m->I) != 0;
 }
 
 // One decode step (all layers + LM head + token select) enqueued on st.  Returns VH_OK or an error code; the host
@@ -1096,10 +1089,8 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
     // (ranks SHARING a device with the exchange forced into the kernels — tests — keep the three small launches: a resident k_dec_ablk
     // grid owns its CUs' whole register files, and one that waits for a peer's pushes would leave that peer's kernels no CU to run on)
-    const bool shared_fuse = fuse && vh_comm_ranks_per_device(m->comm) > 1;
-    const bool fused_attn = fused_wanted(m) && !shared_fuse;
-    const bool fused_moe = fused_moe_wanted(m) && !shared_fuse;
-    m->schedule_state = (fused_attn ? 1 : 0) | (fused_moe ? 2 : 0);
+    const bool fused_attn = fused_wanted(m) && !(fuse && vh_comm_ranks_per_device(m->comm) > 1);
+    m->schedule_state = fused_attn ? 1 : 0;
     int* err = m->counters + 3;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer
     bool have_xm = false;
@@ -1135,20 +1126,7 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
         const int xm_blocks = l + 1 < m->c.n_layers ? (fused_attn ? vhk_dec_ablk_qkv_blocks(m->nqkv, H) : vhk_dec_consumer_blocks(0, m->nqkv, H, I))
                                                      : m->lm_grid;
         if (prof) (void)hipEventRecord(m->prof_ev[m->prof_used], st);
-        if (fused_moe) {
-            if (fuse) {
-                if (vh_comm_xchg_next(m->comm, H, 1, xm_blocks, &xm, st) != VH_OK) return fail(VH_E_COMM, "fused exchange failed: %s", vh_comm_last_error());
-                have_xm = true;
-            }
-            VhDecMoe a{};
-            a.x_in = m->xb; a.delta = m->delta_attn; a.x_out = m->xa; a.norm_w = w.ffn_norm; a.eps = eps;
-            a.Wg = w.wrouter; a.E = E; a.W1 = w.w1; a.W3 = w.w3; a.W2 = w.w2; a.I = I; a.H = H;
-            a.route_out = m->route; a.out = m->delta_moe;
-            a.gh = VhGranVec{m->g_h, m->next_tag(), err}; a.gr = VhGranVec{m->g_route, m->next_tag(), err};
-            if (fuse) { a.cx = xa; a.px = xm; }
-            VH_TRY(vhk_dec_moe(st, a), "dec moe");
-            if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-        } else {
+        {
             VH_TRY(vhk_dec_gateup(st, m->xb, m->delta_attn, m->xa, w.ffn_norm, eps, w.wrouter, E, w.w1, w.w3, I, H,
                                   m->route, m->hbuf, 0, fuse ? &xa : nullptr), "dec gateup");
             if (prof) { (void)hipEventRecord(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }

@@ -652,16 +652,12 @@ __global__ __launch_bounds__(256, 4) void k_dec_ablk(const VhDecAblk a) {
 // loops over 2*RP-row groups (RP gate + RP up rows of one expert) and relies on the co-resident
 // blocks of its CU for the overlap of one block's reduction with another's loads (a second register
 // buffer per block measured slower, 91 vs 84 us: it costs two waves per SIMD of occupancy; r01, git history).
-// The body is shared with the fused MoE launch (k_dec_moe below): block `bi` of `gn` gate|up blocks; GR: h leaves as GEMV-layout
-// granules (gh: slot 0 then slot 1, vh_gran_gemv_len(I) granules each) and the route as granules (gr: 64 copies of {e0, e1, w0, w1}).
-#define DEC_ROUTE_COPIES 64
-template <int NJ, int RP, bool GR>
+template <int NJ, int RP>
 __device__ __forceinline__ void dec_gateup_body(const int bi, const int gn, const float* __restrict__ x_in,
                                                 const float* __restrict__ delta, float* __restrict__ x_out,
                                                 const float* __restrict__ norm_w, float eps, const uint16_t* __restrict__ Wg, int E,
                                                 const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W3, int I, int K,
-                                                int* __restrict__ route_out, float* __restrict__ hbuf, const VhXchg& cx,
-                                                const VhGranVec& gh, const VhGranVec& gr, float* red) {
+                                                int* __restrict__ route_out, float* __restrict__ hbuf, const VhXchg& cx, float* red) {
     float xr[NJ][8];
     float inv;
     int e0 = 0, e1 = 0;
@@ -692,18 +688,10 @@ __device__ __forceinline__ void dec_gateup_body(const int bi, const int gn, cons
         for (int e = 0; e < 8; ++e) if (e < E && pr[e] > b0) { b0 = pr[e]; e0 = e; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (e < E && e != e0 && pr[e] > b1) { b1 = pr[e]; e1 = e; }
-        if (bi == 0) {
+        if (bi == 0 && threadIdx.x == 0) {
             const float t = b0 + b1;
-            if (threadIdx.x == 0) {
-                route_out[0] = e0; route_out[1] = e1;
-                route_out[2] = __float_as_int(b0 / t); route_out[3] = __float_as_int(b1 / t);
-            }
-            if (GR && threadIdx.x < DEC_ROUTE_COPIES) {       // the down blocks of the same launch poll one of these copies each
-                gran_put(gr, (size_t)threadIdx.x * 4 + 0, __int_as_float(e0));
-                gran_put(gr, (size_t)threadIdx.x * 4 + 1, __int_as_float(e1));
-                gran_put(gr, (size_t)threadIdx.x * 4 + 2, b0 / t);
-                gran_put(gr, (size_t)threadIdx.x * 4 + 3, b1 / t);
-            }
+            route_out[0] = e0; route_out[1] = e1;
+            route_out[2] = __float_as_int(b0 / t); route_out[3] = __float_as_int(b1 / t);
         }
     }
 
@@ -723,7 +711,6 @@ __device__ __forceinline__ void dec_gateup_body(const int bi, const int gn, cons
     // (r06: issuing the NEXT group's loads right behind this group's FMAs — they would land under the block reduction — was measured
     // and lost: the kernel grew from 118 to 162 registers (hipcc keeps both weight sets live) and 78.5 -> 82.7 us at TP = 1,
     // 19.2 -> 20.3 at one rank's TP = 8 shard; the CU's other resident blocks already provide that overlap)
-    const size_t hlen = vh_gran_gemv_len(I);
     for (int it = bi; it < n_iter; it += gn) {
         uint4 w[2 * RP][NJ];
         rows_of(it, rows);
@@ -737,9 +724,7 @@ __device__ __forceinline__ void dec_gateup_body(const int bi, const int gn, cons
             for (int r = 0; r < RP; ++r) if (threadIdx.x == r) { g = acc[r]; u = acc[RP + r]; }
             const int slot = it / per_slot;
             const int i0 = (it - slot * per_slot) * RP;
-            const float hv = silu_f(g * inv) * (u * inv);
-            if (GR) gran_put(gh, (size_t)slot * hlen + gran_pos_gemv(i0 + threadIdx.x), hv);
-            else hbuf[(size_t)slot * I + i0 + threadIdx.x] = hv;
+            hbuf[(size_t)slot * I + i0 + threadIdx.x] = silu_f(g * inv) * (u * inv);
         }
     }
 }
@@ -752,35 +737,18 @@ __global__ __launch_bounds__(256) void k_dec_gateup(const float* __restrict__ x_
                                                     float* __restrict__ hbuf, const VhXchg cx) {
     __shared__ float red[4 * 9];
     xchg_reduce(cx);
-    dec_gateup_body<NJ, RP, false>(blockIdx.x, gridDim.x, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx,
-                                   VhGranVec{}, VhGranVec{}, red);
+    dec_gateup_body<NJ, RP>(blockIdx.x, gridDim.x, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K, route_out, hbuf, cx, red);
 }
 
 // ---- K_E: down GEMV of both experts, routing-weighted sum ---------------------------
-// Body shared with the fused MoE launch: rows [n0, n0 + R); GR: route and h arrive as granules from gate|up blocks of the same launch
-// that may still be running — the W2 rows are requested as soon as the route is known, BEFORE the wait for h.
-template <int NJ, int R, bool GR>
-__device__ __forceinline__ void dec_down_body(const int n0, const float* __restrict__ hbuf, const int* __restrict__ route,
-                                              const uint16_t* __restrict__ W2, int N, int I, float* __restrict__ out, const VhXchg& px,
-                                              const VhGranVec& gh, const VhGranVec& gr, float* red) {
-    __shared__ int rt_s[4];
-    int e0, e1; float w0, w1;
-    if (GR) {
-        // ONE wave polls one copy of the route (a different copy per block), the others wait at the barrier (polling discipline of gran_read_gemv)
-        if (threadIdx.x < 64) {
-            const int cp = (int)(blockIdx.x % DEC_ROUTE_COPIES) * 4;
-            const int idx[4] = {cp, cp + 1, cp + 2, cp + 3};
-            float rv[4];
-            gran_getn<4>(gr, idx, rv);
-            if (threadIdx.x == 0) { rt_s[0] = __float_as_int(rv[0]); rt_s[1] = __float_as_int(rv[1]); rt_s[2] = __float_as_int(rv[2]); rt_s[3] = __float_as_int(rv[3]); }
-        }
-        __syncthreads();
-        e0 = min(max(rt_s[0], 0), 7); e1 = min(max(rt_s[1], 0), 7);      // (clamped: a timed-out wait must not address outside the experts)
-        w0 = __int_as_float(rt_s[2]); w1 = __int_as_float(rt_s[3]);
-    } else {
-        e0 = route[0]; e1 = route[1];
-        w0 = __int_as_float(route[2]); w1 = __int_as_float(route[3]);
-    }
+template <int NJ, int R>
+__global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf, const int* __restrict__ route,
+                                                  const uint16_t* __restrict__ W2, int N, int I,
+                                                  float* __restrict__ out, const VhXchg px) {
+    __shared__ float red[4 * R];
+    const int e0 = route[0], e1 = route[1];
+    const float w0 = __int_as_float(route[2]), w1 = __int_as_float(route[3]);
+    const int n0 = blockIdx.x * R;
     const uint16_t* rows0[R];
     const uint16_t* rows1[R];
 #pragma unroll
@@ -794,8 +762,7 @@ __device__ __forceinline__ void dec_down_body(const int n0, const float* __restr
     float tot[R];
     {
         float xr[NJ][8];
-        if (GR) gran_read_gemv<NJ>(gh, I, xr);
-        else load_x<NJ>(hbuf, I, xr);
+        load_x<NJ>(hbuf, I, xr);
         float acc[R];
         gemv_fma<NJ, R>(wa, xr, acc);
 #pragma unroll
@@ -803,8 +770,7 @@ __device__ __forceinline__ void dec_down_body(const int n0, const float* __restr
     }
     {
         float xr[NJ][8];
-        if (GR) gran_read_gemv<NJ>(VhGranVec{gh.g + vh_gran_gemv_len(I), gh.tag, gh.err}, I, xr);
-        else load_x<NJ>(hbuf + (size_t)I, I, xr);
+        load_x<NJ>(hbuf + (size_t)I, I, xr);
         float acc[R];
         gemv_fma<NJ, R>(wb, xr, acc);
 #pragma unroll
@@ -820,35 +786,12 @@ __device__ __forceinline__ void dec_down_body(const int n0, const float* __restr
         else out[n0 + threadIdx.x] = v;
     }
 }
-template <int NJ, int R>
-__global__ __launch_bounds__(256) void k_dec_down(const float* __restrict__ hbuf, const int* __restrict__ route,
-                                                  const uint16_t* __restrict__ W2, int N, int I,
-                                                  float* __restrict__ out, const VhXchg px) {
-    __shared__ float red[4 * R];
-    dec_down_body<NJ, R, false>(blockIdx.x * R, hbuf, route, W2, N, I, out, px, VhGranVec{}, VhGranVec{}, red);
-}
 
-// ---- the MoE of a layer as ONE launch for a tensor-parallel shard's short matrices (r06): gate|up blocks, then down blocks ------------
-// At I = 1792 / 3584 (TP = 8 / 4) gate|up and down are 16 + 7 / 27 + 12 us of mostly latency: launch ramp, router prologue, one or two
-// rounds of one HBM round trip each, boundary, ramp, route load, W2 round trip.  Here the down blocks sit BEHIND the gate|up blocks in one
-// grid (block index order = dispatch order, waits only on lower indices: the rule of k_dec_ablk): they are resident while gate|up
-// streams, request their W2 rows the moment block 0 has published the route, and sweep h as tagged granules when the last gate|up
-// rows land.  Same arithmetic and reduction trees as the two kernels (block256_sum's tree per value does not depend on how many
-// values share the reduction), so the two forms are bit-identical.  Not for the full-size layer: h is 2 x 14336 values there — a
-// 229 KB granule sweep per down block — and both kernels already run at the copy ceiling.
-template <int NJ, int NJI, int RP, int RD>
-__global__ __launch_bounds__(256, NJI == 1 ? 4 : 3) void k_dec_moe(const VhDecMoe a) {
-    constexpr int NR = 9 > RD ? 9 : RD;
-    __shared__ float red[4 * NR];
-    const int b = blockIdx.x;
-    if (b < a.nG) {
-        xchg_reduce(a.cx);
-        dec_gateup_body<NJ, RP, true>(b, a.nG, a.x_in, a.delta, a.x_out, a.norm_w, a.eps, a.Wg, a.E, a.W1, a.W3, a.I, a.H, a.route_out,
-                                      nullptr, a.cx, a.gh, a.gr, red);
-    } else {
-        dec_down_body<NJI, RD, true>((b - a.nG) * RD, nullptr, nullptr, a.W2, a.H, a.I, a.out, a.px, a.gh, a.gr, red);
-    }
-}
+// (r06 experiment, removed: gate|up and down of a tensor-parallel shard as ONE launch — down blocks behind the gate|up blocks of one grid,
+// W2 rows requested once block 0 had published the route as granules, h read as tagged granules.  Bit-identical, and SLOWER: one rank's
+// TP = 8 shard 1.369 against 1.313 ms per token, TP = 4 2.233 against 1.808 — 512-1024 resident down blocks poll the route and then h for
+// ~10 us next to a gate|up phase that is pure streaming, and the 16-granule-per-thread sweeps of h cost more than the boundary and the W2
+// round trip they replace: profiles/EXPERIMENTS.md.)
 
 // ---- K_F: final RMSNorm + LM head GEMV + per-block argmax ---------------------------
 #define LM_R 8
@@ -1273,23 +1216,6 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
                            route_out, hbuf, cx);
         return 0;
     });
-}
-
-int vhk_dec_moe_supported(int H, int I) { return H <= 4096 && H % 8 == 0 && I >= 8 && I <= 4096 && I % 8 == 0; }
-int vhk_dec_moe(hipStream_t st, const VhDecMoe& a0) {
-    if (!vhk_dec_moe_supported(a0.H, a0.I) || a0.E > 8 || a0.E < 2 || !a0.gh.g || !a0.gr.g) return -1;
-    VhDecMoe a = a0;
-    a.nG = dec_gateup_grid(a.I);
-    auto launch = [&](auto nj, auto nji, auto rd) {
-        constexpr int RD = decltype(rd)::value;
-        hipLaunchKernelGGL((k_dec_moe<decltype(nj)::value, decltype(nji)::value, 4, RD>), dim3(a.nG + (a.H + RD - 1) / RD), dim3(256), 0, st, a);
-        return 0;
-    };
-    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using R8 = std::integral_constant<int, 8>; using R4 = std::integral_constant<int, 4>;
-    // down rows per block: 8 while a thread's two experts' rows fit 64 weight registers (I <= 2048), else 4
-    if (a.H <= 2048) return a.I <= 2048 ? launch(I1{}, I1{}, R8{}) : launch(I1{}, I2{}, R4{});
-    return a.I <= 2048 ? launch(I2{}, I1{}, R8{}) : launch(I2{}, I2{}, R4{});
 }
 
 int vhk_dec_down(hipStream_t st, const float* hbuf, const int* route, const uint16_t* W2, int N, int I, float* out,

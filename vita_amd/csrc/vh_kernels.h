@@ -30,10 +30,10 @@ struct VhTuning {
     int tp_fuse = 0;           // batch-1 decode under the library's IPC all-reduce: 0 = one 16-block all-reduce kernel per exchange,
                                // 1 = exchange fused into the producer / consumer kernels (VhXchg).  Chosen at bring-up by
                                // vita_amd.parallel (timed on the ranks' own devices; "kernel" whenever ranks share a device)
-    int dec_fused = -1;        // batch-1 decode: bit 0 = the attention block of a layer as ONE launch (k_dec_ablk: fused QKV GEMV -> split-KV attention
+    int dec_fused = -1;        // batch-1 decode: 1 = the attention block of a layer as ONE launch (k_dec_ablk: fused QKV GEMV -> split-KV attention
                                // -> O projection, q|k|v and the attention output handed over as tagged granules, a block's weights in flight
-                               // while it waits), bit 1 = the MoE as ONE launch (k_dec_moe: gate|up blocks, then down blocks; shards with
-                               // I <= 4096 only); 0 = five launches per layer; -1 = auto (both wherever the kernels have an instantiation)
+                               // while it waits), 0 = three launches (five per layer), -1 = auto (fused wherever the kernel has an instantiation:
+                               // H and the heads' width <= 4096, i.e. the released geometry at any TP degree)
     int attn_img = 1;          // one-shot prefills under the flash attention kernel: 1 = K / V as MFMA-ready tile images written by the RoPE pass
                                // (k_rope_kv_img -> LDS-DMA in k_attn_fa), 0 = fp32 K / V staged and converted by every attention block (r04-r05)
     int dec_gateup_grid = 0;   // debug: blocks of the batch-1 gate|up launch (0 = auto: 1.5 per CU, equal shares in few rounds for small shards)
@@ -138,18 +138,6 @@ int vhk_decb_attn(hipStream_t st, const VhDecBatchAttn& bt, int n, float* kcache
                   const float* rope_sin, int nq, int nkv, int max_ctx, int max_splits, float scale);
 int vhk_decb_lmhead(hipStream_t st, const VhDecBatchVec& bt, const float* norm_w, float eps, const uint16_t* W, int V, int K,
                     const VhDecBatchHead& hd, int grid, int v0);
-// The MoE of one decode layer as ONE launch (k_dec_moe, tensor-parallel shards: I <= 4096): gate|up blocks, then down blocks that request
-// their W2 rows once the route is published and read h as granules.  gh: 2 * vh_gran_gemv_len(I) granules (slot 0, slot 1), gr: 256.
-struct VhDecMoe {
-    const float* x_in; const float* delta; float* x_out; const float* norm_w; float eps;
-    const uint16_t* Wg; int E; const uint16_t* W1; const uint16_t* W3; const uint16_t* W2; int I, H;
-    int* route_out; float* out;
-    VhGranVec gh, gr;
-    int nG;                                   // gate|up blocks (set by the launcher)
-    VhXchg cx, px;
-};
-int vhk_dec_moe(hipStream_t st, const VhDecMoe& a);
-int vhk_dec_moe_supported(int H, int I);      // 1 when k_dec_moe has an instantiation for these widths
 int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float* x_out, const float* norm_w, float eps,
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid, const VhXchg* cx = nullptr);

@@ -185,15 +185,10 @@ class MixtralEngine:
         self.n_gen += int(n_steps)
 
     def decode_schedule(self):
-        """how the last decode call ran a layer: "fused-attention-block" (the attention block as ONE launch: fused QKV -> split-KV
-        attention -> O projection with granule hand-offs; gate|up and down as two launches — the full-size layer),
-        "fused-attention-block+moe" (additionally the MoE as one launch: tensor-parallel shards with <= 4096 expert columns),
-        "three-launches" (the attention block as QKV, attention, O projection: vh_tune("dec_fused", 0) or widths without an
-        instantiation; "three-launches+moe" with bit 1 alone) or "none" before the first decode call."""
-        v = int(self.lib.vh_mixtral_decode_schedule(self.h))
-        if v < 0:
-            return "none"
-        return ("fused-attention-block" if v & 1 else "three-launches") + ("+moe" if v & 2 else "")
+        """how the attention block of the last decode call ran: "fused-attention-block" (ONE launch per layer: fused QKV ->
+        split-KV attention -> O projection as blocks of one grid with granule hand-offs, the default), "three-launches"
+        (vh_tune("dec_fused", 0) or widths without an instantiation) or "none" before the first decode call."""
+        return {1: "fused-attention-block", 0: "three-launches"}.get(int(self.lib.vh_mixtral_decode_schedule(self.h)), "none")
 
     def reset(self):
         """forget the current request: position and generated-token counters to zero, every KV page back to the pool
