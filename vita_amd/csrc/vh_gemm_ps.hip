@@ -390,7 +390,8 @@ int vhk_gemm_ps(hipStream_t st, const VhGemmPsArgs& a0) {
     if (cfg == 2) {
         // auto = both (r06, profiles/r06_moe_xcd_ab.txt: down 258 -> 250 us, gate|up 505 -> 497 at uniform routing; 287 -> 286 / 537 -> 523 skewed)
         const int px = vh_tuning()->ps_xcd < 0 ? 3 : vh_tuning()->ps_xcd;
-        a.xcd_group = (a.W_up ? (px >> 1) : px) & 1;
+        // (grouped GEMMs only: the plain QKV / O projections measured 66.7 -> 70.6 and 52.2 -> 55.7 us with it, r06 calls 5 and 7)
+        a.xcd_group = a.group_off ? ((a.W_up ? (px >> 1) : px) & 1) : 0;
         return vhk_gemm_sp(st, a, grid, vh_tuning()->ps_nt > 0);
     }
     // non-temporal weight loads keep the activation planes in L2 (down projection: -7 %), but a run whose last
