@@ -36,6 +36,7 @@ struct VhTuning {
                                // H and the heads' width <= 4096, i.e. the released geometry at any TP degree)
     int attn_img = 1;          // one-shot prefills under the flash attention kernel: 1 = K / V as MFMA-ready tile images written by the RoPE pass
                                // (k_rope_kv_img -> LDS-DMA in k_attn_fa), 0 = fp32 K / V staged and converted by every attention block (r04-r05)
+    int dec_gateup_rp = 0;     // batch-1 gate|up: rows of each of gate / up per block and round: 0 = auto (7 for shards with I <= 7168, else 4), 4, 7
     int dec_gateup_grid = 0;   // debug: blocks of the batch-1 gate|up launch (0 = auto: 1.5 per CU, equal shares in few rounds for small shards)
     int comm_allow_coarse = 0; // vh_comm_create: 1 = a coarse-grained receive buffer is acceptable when the fine-grained allocation fails (only
                                // correct when every rank drives ONE device: same-device tests); 0 = fail loudly instead
