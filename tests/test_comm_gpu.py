@@ -203,7 +203,7 @@ def test_tp_engine_world_4_and_8_match_oracle(dev, world):
     for r in range(world):
         assert ret[r][1] == ref_ids, f"rank {r} tokens differ from the unsharded oracle: {ret[r][1]} vs {ref_ids}"
         assert np.array_equal(ret[r][2], ret[0][2]), f"rank {r} logits differ from rank 0's"
-        assert ret[r][6].startswith("fused-attention-block"), ret[r][6]      # the schedule a tensor-parallel rank runs by default
+        assert ret[r][6] == "three-launches", ret[r][6]      # ranks that SHARE a device never run launches whose blocks wait for other blocks
     assert float(np.abs(ret[0][2] - ref_lg).max()) < 1e-3
 
 
@@ -232,11 +232,11 @@ def test_tp2_engine_over_ipc_allreduce_matches_oracle(dev, overlap, fuse):
         assert ret[0][5] == ret[1][5] and ret[0][5] in ("fused", "kernel"), (ret[0][5], ret[1][5])
     else:
         assert ret[0][5] == ret[1][5] == {1: "fused", 0: "kernel", -1: "kernel"}[fuse]
-    # the default decode schedule of a tensor-parallel rank is the attention block as ONE launch (k_dec_ablk); only ranks that SHARE a
-    # device with the exchange FORCED into the kernels keep the three small launches (a waiting k_dec_ablk grid owns its CUs' register
-    # files: the peer it waits for would find no CU).  The fused exchange INSIDE k_dec_ablk is covered by test_loopback_* below.
-    want = "three-launches" if ret[0][5] == "fused" else "fused-attention-block"
-    assert ret[0][6] == ret[1][6] == want, (ret[0][5], ret[0][6], ret[1][6])
+    # A tensor-parallel rank that OWNS its GPU runs the attention block as ONE launch (k_dec_ablk); ranks that SHARE a device — every
+    # multi-process test here — keep its three launches: a launch whose blocks wait for other blocks can be starved by another process's
+    # waiting blocks (dispatch is in index order per XCD only: r06 saw it as an intermittent time-out with eight ranks on one GPU).
+    # The one-launch form with BOTH exchange forms is covered in one process by test_loopback_* below, at the released shard shapes.
+    assert ret[0][6] == ret[1][6] == "three-launches", (ret[0][5], ret[0][6], ret[1][6])
     V = cfg.text.vocab_size
     assert ret[0][3] == (0, (V + 1) // 2) and ret[1][3] == ((V + 1) // 2, V - (V + 1) // 2)    # the head IS sharded
     assert ret[0][1] == ret[1][1] == ref_ids
@@ -304,6 +304,10 @@ def _tp_real_worker(rank, world, port, ret, layers=2):
         dist.barrier()
         time.sleep(0.5)                          # gloo: a rank that leaves the barrier first must not close its sockets under the others
         eng.close()
+    except BaseException:
+        import traceback
+        ret[("error", rank)] = traceback.format_exc()
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -312,9 +316,9 @@ def _tp_real_worker(rank, world, port, ret, layers=2):
 @pytest.mark.parametrize("world,layers", [(8, 2), (4, 8), (2, 2)])
 def test_tp_released_shard_shapes_match_oracle(dev, world, layers):
     """world 8 / 4 / 2 (processes on ONE GPU) at the released per-rank shapes (1792 / 3584 / 7168 expert columns, 4 + 1 / 8 + 2 /
-    16 + 4 heads: each width picks its own instantiations of the decode kernels — k_dec_ablk<2, NJO, RQ>, k_dec_down<NJ, 2> — and
-    its own tilings of the prefill GEMMs), 2 or 8 layers, over the library's IPC all-reduce, the decode steps on the default
-    schedule of a tensor-parallel rank (fused attention-block launch): greedy ids == the layer-streamed fp32 oracle's
+    16 + 4 heads: each width picks its own instantiations of the decode kernels — k_dec_gemv<NJ, 8, .>, k_dec_down<NJ, 2> — and
+    its own tilings of the prefill GEMMs), 2 or 8 layers, over the library's IPC all-reduce (ranks sharing a device: the attention
+    block as three launches; its one-launch form at these widths is test_loopback_* below): greedy ids == the layer-streamed fp32 oracle's
     (oracle/stream.py, the unsharded arithmetic on the same generator's weights), logits within 1e-3, every rank bit-identical.
     TP = 2 is the degree both web demos deploy (web_demo/web_ability_demo.py:340-348), 2 x TP = 4 is BASELINE configs[4].
     Reference partition: web_demo/vllm_tools/vllm_file/mixtral.py:441-470 (QKVParallelLinear / RowParallelLinear head split),
@@ -323,12 +327,17 @@ def test_tp_released_shard_shapes_match_oracle(dev, world, layers):
     from oracle import stream
     from vita_amd.config import VitaConfig
     ret = mp.Manager().dict()
-    mp.spawn(_tp_real_worker, args=(world, _free_port(), ret, layers), nprocs=world, join=True)
+    try:
+        mp.spawn(_tp_real_worker, args=(world, _free_port(), ret, layers), nprocs=world, join=True)
+    except Exception:
+        for k in sorted(k for k in ret.keys() if isinstance(k, tuple)):
+            print(f"---- rank {k[1]} ----\n{ret[k]}")
+        raise
     names = {ret[r][0] for r in range(world)}
     assert len(names) == 1, dict((r, ret[r][0]) for r in range(world))
     _require_ipc(names, f"released-shape TP = {world}")
     assert all(ret[r][3] == 0 for r in range(world)) and all(ret[r][4] == "kernel" for r in range(world))
-    assert all(ret[r][5] == "fused-attention-block" for r in range(world)), {r: ret[r][5] for r in range(world)}
+    assert all(ret[r][5] == "three-launches" for r in range(world)), {r: ret[r][5] for r in range(world)}      # (shared device)
     cfg = VitaConfig()
     t = cfg.text
     ids = np.random.default_rng(11).integers(3, t.vocab_size, size=REAL_TP_S).tolist()

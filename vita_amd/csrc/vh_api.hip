@@ -60,7 +60,6 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "comm_ranks_per_device")) { g_tuning.comm_ranks_per_device = value; return VH_OK; }
     if (!strcmp(key, "dec_fused")) { g_tuning.dec_fused = value; return VH_OK; }
     if (!strcmp(key, "dec_gateup_grid")) { g_tuning.dec_gateup_grid = value; return VH_OK; }
-    if (!strcmp(key, "dec_gateup_rp")) { g_tuning.dec_gateup_rp = value; return VH_OK; }
     if (!strcmp(key, "attn_img")) { g_tuning.attn_img = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
@@ -1088,9 +1087,13 @@ static int decode_one_step(vh_mixtral* m, hipStream_t st) {
     const float eps = m->c.rms_eps;
     const bool fuse = m->comm != nullptr && m->exchanges() && vh_tuning()->tp_fuse != 0 && (H % 2) == 0 &&
                       (size_t)H <= vh_comm_capacity(m->comm) && H <= 32768 && !vh_tuning()->force_allreduce;
-    // (ranks SHARING a device with the exchange forced into the kernels — tests — keep the three small launches: a resident k_dec_ablk
-    // grid owns its CUs' whole register files, and one that waits for a peer's pushes would leave that peer's kernels no CU to run on)
-    const bool fused_attn = fused_wanted(m) && !(fuse && vh_comm_ranks_per_device(m->comm) > 1);
+    // Engine processes SHARING a device (ranks of the one-device tests, duplex replicas on one GPU) keep the three launches: a launch whose
+    // blocks wait for other blocks is safe only while nobody else's waiting blocks can occupy the slots its producers need — blocks are
+    // dispatched in index order PER XCD, so rank A's O blocks can fill one XCD while A's attention blocks queue on another behind rank B's
+    // O blocks, which wait for B's attention blocks queued behind A's: r06 saw exactly this as an intermittent 0.5 s time-out with eight
+    // ranks on one GPU.  A process that owns its device cannot starve itself (its own lower-index blocks are always dispatched first).
+    const bool shared_dev = vh_tuning()->comm_ranks_per_device > 1 || (m->comm && vh_comm_ranks_per_device(m->comm) > 1);
+    const bool fused_attn = fused_wanted(m) && !shared_dev;
     m->schedule_state = fused_attn ? 1 : 0;
     int* err = m->counters + 3;
     VhXchg xa{}, xm{};                           // attention / MoE exchange of the current layer

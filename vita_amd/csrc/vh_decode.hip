@@ -37,13 +37,6 @@
 #include "vh_common.h"
 #include "vh_kernels.h"
 
-#ifndef VH_GRAN_POLL_SLEEP
-#define VH_GRAN_POLL_SLEEP 8   // s_sleep argument (x 64 cycles) between two looks of a granule wait
-#endif
-#ifndef VH_GRAN_SENT_SLEEP
-#define VH_GRAN_SENT_SLEEP 8   // additional sleep of the ONE wave per block that polls a GEMV block's sentinel granule
-#endif
-
 namespace {
 
 // ---- tensor-parallel exchange fused into the kernels (VhXchg, vh_kernels.h) ---------------------------------------------
@@ -119,7 +112,7 @@ __device__ __forceinline__ bool gran_spin_fail(unsigned& spins, int* err) {
         __hip_atomic_store(err, 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
-    __builtin_amdgcn_s_sleep(VH_GRAN_POLL_SLEEP);
+    __builtin_amdgcn_s_sleep(8);
     return false;
 }
 // N granules per lane (positions idx[]), e.g. the two halves of a head's q row for the rotate-half RoPE
@@ -153,7 +146,7 @@ __device__ __forceinline__ void gran_read_gemv(const VhGranVec& gv, int K, float
         for (;;) {
             if ((unsigned)(gran_ld(gv, sent) >> 32) == gv.tag) break;
             if (gran_spin_fail(spins, gv.err)) break;
-            __builtin_amdgcn_s_sleep(VH_GRAN_SENT_SLEEP);   // + the sleep of gran_spin_fail: ~0.5 us between looks by default (<= ~1000 poller waves in all)
+            __builtin_amdgcn_s_sleep(8);              // + the 8 of gran_spin_fail: ~0.5 us between looks (<= ~1000 poller waves in all; s_sleep 2 + 1 measured no faster: r06 call 9)
         }
     }
     __syncthreads();
@@ -1129,16 +1122,10 @@ static int launch_dec_gemv(hipStream_t st, const float* x_in, const float* delta
 
 // rows per block of the QKV / O GEMVs.  8: r02 sweep with the transposing block reduction (4: -0.5 % of a token, 16: -1 %)
 constexpr int DEC_GEMV_R = 8;
-// rows per gate|up group (RP gate + RP up rows of one expert per block and round): 4 for the full-size layer (r01 tuning), 7 for a
-// tensor-parallel shard (I = 14336 / tp is a multiple of 7): at I = 1792 the 512 groups of 7 are ONE round on 512 blocks where groups
-// of 4 take 2-3 rounds of one HBM round trip each; vh_tune("dec_gateup_rp", 4 / 7) forces it
-static int dec_gateup_rp(int I, int K) {
-    const int want = vh_tuning()->dec_gateup_rp;
-    if (K > 4096 || I % 7 != 0) return 4;
-    if (want == 4 || want == 7) return want;
-    return I <= 7168 ? 7 : 4;
-}
-static int dec_gateup_grid(int I, int rp) {
+// (r06: groups of 7 + 7 rows for tensor-parallel shards — 512 groups = ONE round on 512 blocks at I = 1792 instead of 2-3 rounds of 4 + 4 —
+// measured SLOWER at every degree: one rank's TP = 8 / 4 / 2 shard 1.316 / 1.831 / 2.871 against 1.287 / 1.788 / 2.790 ms per token; removed)
+static int dec_gateup_grid(int I) {
+    constexpr int rp = 4;
     // 1.5 persistent blocks per CU: every block pays the router prologue (96 KB of L2 reads), so fewer, longer-lived
     // blocks win — r01: 79 us at 512 blocks vs 83 at 1024 and 82 at 1280; r02 (cheaper block reductions): whole-token rate
     // 196.6 / 205.7 / 210.5 / 207.6 / 207.0 / 208.7 / 207.4 tok/s at 256 / 320 / 384 / 448 / 512 / 768 / 1024 blocks
@@ -1157,7 +1144,7 @@ static int dec_gateup_grid(int I, int rp) {
 int vhk_dec_consumer_blocks(int which, int N, int K, int I) {
     (void)K;
     if (which == 0) return (N + DEC_GEMV_R - 1) / DEC_GEMV_R;
-    if (which == 1) return dec_gateup_grid(I, dec_gateup_rp(I, K));
+    if (which == 1) return dec_gateup_grid(I);
     if (which == 3) return N;   // fused attention block: at least the fused-QKV blocks (N = their count) come first
     return N;   // LM head: the caller's grid
 }
@@ -1221,20 +1208,12 @@ int vhk_dec_gateup(hipStream_t st, const float* x_in, const float* delta, float*
                    const uint16_t* Wg, int E, const uint16_t* W1, const uint16_t* W3, int I, int K, int* route_out,
                    float* hbuf, int grid, const VhXchg* cxp) {
     if (E > 8 || E < 2 || I % 4 != 0) return -1;
-    const int rp = dec_gateup_rp(I, K);
-    const int n_iter = 2 * (I / rp);
+    const int n_iter = 2 * (I / 4);
     const VhXchg cx = xchg_or_none(cxp);
-    if (grid <= 0) grid = dec_gateup_grid(I, rp);
+    if (grid <= 0) grid = dec_gateup_grid(I);
     if (grid > n_iter) grid = n_iter;
     return pick_nj(K, [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        if constexpr (NJ <= 2) {
-            if (rp == 7) {
-                hipLaunchKernelGGL((k_dec_gateup<NJ, 7>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
-                                   route_out, hbuf, cx);
-                return 0;
-            }
-        }
         hipLaunchKernelGGL((k_dec_gateup<NJ, 4>), dim3(grid), dim3(256), 0, st, x_in, delta, x_out, norm_w, eps, Wg, E, W1, W3, I, K,
                            route_out, hbuf, cx);
         return 0;

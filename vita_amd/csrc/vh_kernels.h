@@ -36,13 +36,14 @@ struct VhTuning {
                                // H and the heads' width <= 4096, i.e. the released geometry at any TP degree)
     int attn_img = 1;          // one-shot prefills under the flash attention kernel: 1 = K / V as MFMA-ready tile images written by the RoPE pass
                                // (k_rope_kv_img -> LDS-DMA in k_attn_fa), 0 = fp32 K / V staged and converted by every attention block (r04-r05)
-    int dec_gateup_rp = 0;     // batch-1 gate|up: rows of each of gate / up per block and round: 0 = auto (7 for shards with I <= 7168, else 4), 4, 7
     int dec_gateup_grid = 0;   // debug: blocks of the batch-1 gate|up launch (0 = auto: 1.5 per CU, equal shares in few rounds for small shards)
     int comm_allow_coarse = 0; // vh_comm_create: 1 = a coarse-grained receive buffer is acceptable when the fine-grained allocation fails (only
                                // correct when every rank drives ONE device: same-device tests); 0 = fail loudly instead
-    int comm_ranks_per_device = 1;   // vh_comm_create: ranks that drive THIS rank's device (vita_amd.parallel counts them from the devices' PCI
-                               // identities): the bulk all-reduce divides its resident-block cap by it, and ranks that share a device
-                               // never get the exchange fused into the decode kernels (a waiting consumer grid would hold the CUs a peer's producer needs)
+    int comm_ranks_per_device = 1;   // engine processes that drive THIS process's device (vita_amd.parallel counts the ranks from the devices' PCI
+                               // identities; vita_amd.duplex sets 2 for replicas on one GPU).  > 1: the bulk all-reduce divides its
+                               // resident-block cap by it, the decode exchange is never fused into the kernels, and the attention block of a
+                               // decode layer runs as three launches — any launch whose blocks WAIT for other blocks can be starved by another
+                               // process's waiting blocks (block dispatch is in index order per XCD only)
 };
 VhTuning* vh_tuning();
 

@@ -116,14 +116,21 @@ def worker_loop(llm_id, make_llm, sampling_params, inputs_queue, outputs_queue, 
                              "n_chunks": len(results), "error": error})
 
 
-def _engine_process(llm_id, llm_factory, factory_args, sampling_params, shared):
+def _engine_process(llm_id, llm_factory, factory_args, sampling_params, shared, engines_share_device=True):
+    if engines_share_device:
+        # two replicas on ONE GPU: launches whose blocks wait for other blocks (the fused decode attention block) can be starved by the
+        # other replica's waiting blocks — the library keeps the three-launch form for processes that share a device
+        from . import _lib
+        _lib.tune("comm_ranks_per_device", 2)
     worker_loop(llm_id, lambda: llm_factory(*factory_args), sampling_params, **shared)
 
 
 class DuplexServer:
     """Two engine processes + the shared queues / events of web_interactive_demo.py:914-1029."""
 
-    def __init__(self, llm_factory, factory_args=(), sampling_params=None, history_limit=0, ctx="spawn"):
+    def __init__(self, llm_factory, factory_args=(), sampling_params=None, history_limit=0, ctx="spawn", engines_share_device=True):
+        """engines_share_device: the two replicas drive the same GPU (the default assumption; pass False when the factory places
+        them on different devices, as the reference's demo does: cuda_devices "0,1" / "2,3", web_interactive_demo.py:958,981)."""
         self.mpc = mp.get_context(ctx)
         self.mgr = self.mpc.Manager()
         m = self.mgr
@@ -143,7 +150,7 @@ class DuplexServer:
                           start_event=start[i], other_start_event=start[1 - i], start_event_lock=self.lock,
                           interrupt_signal=self.interrupt, global_history=self.history,
                           shutdown_event=self.shutdown, stats_queue=self.stats, history_limit=history_limit)
-            p = self.mpc.Process(target=_engine_process, args=(i, llm_factory, factory_args, sampling_params, shared),
+            p = self.mpc.Process(target=_engine_process, args=(i, llm_factory, factory_args, sampling_params, shared, engines_share_device),
                                  daemon=True)
             p.start()
             self.procs.append(p)

@@ -336,6 +336,14 @@ def setup_tensor_parallel(engine, rank, world, device, backend="nccl", collectiv
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # how many ranks drive THIS rank's GPU: known to the library before any collective is chosen (ranks that share a device keep the
+    # decode attention block as three launches and never fuse the exchange into the kernels, whatever collective wins below)
+    try:
+        from . import _lib
+        mine, _most = ranks_on_my_device(dist, device, world)
+        _lib.tune("comm_ranks_per_device", mine)
+    except Exception as e:
+        print(f"[vita_amd.parallel] rank {rank}: could not count the ranks on this device: {e}", file=sys.stderr)
     if collective in ("auto", "ipc") and hasattr(engine, "attach_comm"):
         if ipc_allreduce(engine, rank, world, dist, device, backend):
             return "ipc"
