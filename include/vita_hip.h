@@ -37,9 +37,9 @@ extern "C" {
 
 int vh_version(void);
 const char* vh_last_error(void);
-/* Kernel-variant knobs (20 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
+/* Kernel-variant knobs (21 keys: "batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit",
  * "prefill_attn_gemm", "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse",
- * "comm_allow_coarse", "comm_ranks_per_device", "dec_fused", "dec_gateup_grid", "attn_img", "ps_xcd"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
+ * "comm_allow_coarse", "comm_ranks_per_device", "dec_fused", "dec_gateup_grid", "attn_img", "attn_xcd", "ps_xcd"; vita_amd/csrc/vh_kernels.h: VhTuning says what each selects); the defaults are the
  * measured-best variants, ids are identical across variants.  Unknown keys (e.g. of variants removed in r04) return VH_E_ARG. */
 int vh_tune(const char* key, int value);
 

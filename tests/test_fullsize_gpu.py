@@ -148,3 +148,31 @@ def test_fused_attention_block_equals_three_launches(full, dev):
         assert toks == runs[0][0]
         assert torch.equal(lg, runs[0][1])
     assert int(eng.counters[3].item()) == 0
+
+
+def test_prefill_attention_variants_are_bit_identical(full, dev):
+    """r06: the flash prefill attention's variants run the SAME arithmetic per query row: K / V as producer-written tile images or staged
+    by the kernel itself (attn_img), 16 or 32 query rows per wave (attn_rows: 32 is what S = 2344 takes by itself), q tiles of a KV head
+    dealt to one XCD or to all (attn_xcd).  Prompt logits and greedy ids bit-identical across all of them, at a length with tails in the
+    32-row blocks and the 64-key tiles.  (The default at this length is anchored to the fp32 oracle by tests/test_realgeom_gpu.py.)"""
+    from vita_amd import _lib
+    cfg, packed, eng = full
+    rng = np.random.default_rng(6)
+    emb = _emb(packed, rng.integers(3, cfg.text.vocab_size, size=250).tolist(), dev)      # one-shot (max_prefill 256): 128 flash blocks of 16 rows = half the chip
+    runs = []
+    try:
+        for img, rows, xcd in ((1, 0, 1), (1, 32, 1), (1, 32, 0), (0, 32, 1), (0, 16, 0), (1, 16, 1)):
+            _lib.tune("attn_img", img)
+            _lib.tune("attn_rows", rows)
+            _lib.tune("attn_xcd", xcd)
+            eng.prefill(emb)
+            eng.decode(4)
+            torch.cuda.synchronize()
+            runs.append((eng.generated(), eng.logits_all[:5].clone()))
+    finally:
+        _lib.tune("attn_img", 1)
+        _lib.tune("attn_rows", 0)
+        _lib.tune("attn_xcd", 1)
+    for toks, lg in runs[1:]:
+        assert toks == runs[0][0]
+        assert torch.equal(lg, runs[0][1])

@@ -247,17 +247,17 @@ def test_removed_knobs_are_rejected():
         with pytest.raises(_lib.VitaHipError):
             _lib.tune(key, 1)
     _lib.tune("attn_rows", 0)      # a live key is accepted (no GPU needed)
-    assert len(KNOBS) <= 20
+    assert len(KNOBS) <= 21
     for key in KNOBS:
         _lib.tune(key, {"batch_moe_min": 3, "batch_decode": 1, "prefill_fuse_rows": 1, "ps_cfg": -1, "ps_nt": -1, "tp_overlap": 1, "moe_ksplit": -4, "attn_fa": 1,
-                        "dec_fused": -1, "comm_ranks_per_device": 1, "attn_img": 1, "ps_xcd": -1}.get(key, 0))    # (every key back at its default)
+                        "dec_fused": -1, "comm_ranks_per_device": 1, "attn_img": 1, "attn_xcd": 1, "ps_xcd": -1}.get(key, 0))    # (every key back at its default)
 
 
 # r04's 15 keys + r06's dec_fused (the attention block of a decode layer as one launch; 0 = three launches) and comm_ranks_per_device
 # (r05's dec_overlap — the side-stream schedule — is gone with its machinery)
 KNOBS = ("batch_moe_min", "batch_decode", "attn_impl", "attn_fa", "attn_rows", "attn_ksplit", "prefill_attn_gemm",
          "prefill_fuse_rows", "ps_cfg", "ps_nt", "tp_overlap", "moe_ksplit", "force_allreduce", "tp_fuse", "comm_allow_coarse",
-         "comm_ranks_per_device", "dec_fused", "dec_gateup_grid", "attn_img", "ps_xcd")
+         "comm_ranks_per_device", "dec_fused", "dec_gateup_grid", "attn_img", "attn_xcd", "ps_xcd")
 
 
 def test_ctypes_structs_match_the_header(tmp_path):

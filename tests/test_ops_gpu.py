@@ -433,11 +433,13 @@ def test_attention_key_groups(dev, groups, impl):
 
 @pytest.mark.parametrize("nq,nkv,causal", [(8, 2, True), (4, 1, True), (8, 2, False)])
 @pytest.mark.parametrize("Sq,pos0", [(70, 0), (33, 45), (1, 99), (150, 170), (64, 64), (129, 0)])
-def test_attention_flash_form(dev, nq, nkv, causal, Sq, pos0):
+@pytest.mark.parametrize("rows,xcd", [(0, 1), (32, 1), (32, 0)], ids=["rows16", "rows32", "rows32-plain-grid"])
+def test_attention_flash_form(dev, nq, nkv, causal, Sq, pos0, rows, xcd):
     """k_attn_fa forced (attn_fa = 2; by default it runs when its blocks fill half the chip): d = 128, 4 : 1 head grouping (one block
     = the four query heads of a KV head on the same 16 rows, eight waves = heads x two 32-key halves merged at the end), causal with
     a query offset (chunked prefill) or a key pad mask, K / V in cache layout [nkv][max_ctx][d]; tails in the 16-row blocks, the
-    64-key tiles and their halves; rows past the context hold NaNs and must never reach a product."""
+    64-key tiles and their halves; rows past the context hold NaNs and must never reach a product.  r06: 32 query rows per wave
+    (attn_rows = 32, causal only: what long prompts take by themselves) and the XCD-aware block -> (q tile, KV head) mapping on / off."""
     from vita_amd import _lib, ops
     rng = np.random.default_rng(10 + Sq + nq)
     d, max_ctx = 128, 400
@@ -453,12 +455,16 @@ def test_attention_flash_form(dev, nq, nkv, causal, Sq, pos0):
         vc[:, klen:] = np.nan
     out = torch.full((Sq, nq * d), float("nan"), dtype=torch.float32, device=dev)
     _lib.tune("attn_fa", 2)
+    _lib.tune("attn_rows", rows)
+    _lib.tune("attn_xcd", xcd)
     try:
         ops.attention(_dev(q, dev), _dev(kc, dev), _dev(vc, dev), out, B=1, Hq=nq, Hkv=nkv, Sq=Sq, Sk=Sk, d=d, ldq=nq * d,
                       hsq=d, ldk=d, hsk=max_ctx * d, ldv=d, hsv=max_ctx * d, ldo=nq * d, scale=d ** -0.5, causal=causal, q_off=pos0,
                       klen=klen)
     finally:
         _lib.tune("attn_fa", 1)
+        _lib.tune("attn_rows", 0)
+        _lib.tune("attn_xcd", 1)
     mask = (np.arange(Sk)[None, :] <= (pos0 + np.arange(Sq))[:, None]) if causal else np.broadcast_to(np.arange(Sk)[None, :] < klen, (Sq, Sk))
     ref = _attn_ref(q.reshape(Sq, nq, d).transpose(1, 0, 2), np.nan_to_num(kc[:, :Sk]), np.nan_to_num(vc[:, :Sk]), d ** -0.5, mask)
     assert_close(f"flash form nq={nq} causal={causal} Sq={Sq} pos0={pos0}", to_np(out), ref, atol=ATTN_X3_ATOL)

@@ -61,6 +61,7 @@ int vh_tune(const char* key, int value) {
     if (!strcmp(key, "dec_fused")) { g_tuning.dec_fused = value; return VH_OK; }
     if (!strcmp(key, "dec_gateup_grid")) { g_tuning.dec_gateup_grid = value; return VH_OK; }
     if (!strcmp(key, "attn_img")) { g_tuning.attn_img = value; return VH_OK; }
+    if (!strcmp(key, "attn_xcd")) { g_tuning.attn_xcd = value; return VH_OK; }
     return fail(VH_E_ARG, "vh_tune: unknown key '%s'", key);
 }
 

@@ -30,6 +30,28 @@ __device__ __forceinline__ bool key_visible(const VhAttnArgs& p, int q, int key,
     return true;
 }
 
+
+// ---- block -> (q tile, head, batch), XCD-aware (r06) -----------------------------------------------------------------------------------
+// Hardware deals the blocks of a grid to the 8 XCDs round-robin in linear order (x fastest), and every XCD has its own 4 MB L2.  With the
+// plain decode (x = q tile, y = head, z = batch) the q tiles of ONE head — which all stream the same K / V — land on all 8 XCDs and each L2
+// fetches every head's K / V: at S = 2344 the flash kernel's 1176 blocks pulled 1.4 GB through the fabric for 19 MB of tile images.
+// xcd_map: linear block L of a chunk of 8 (head, batch) pairs takes pair L % 8 and q tile L / 8: all q tiles of a pair run on ONE XCD,
+// whose L2 then holds that pair's K / V only (2.4 MB of images per KV head at S = 2344).  Bijective for any grid (a last chunk of r < 8
+// pairs deals L % r); q tiles stay in dispatch order.
+__device__ __forceinline__ void at_block_coords(const int xcd_map, int& qx, int& hy, int& bz) {
+    qx = blockIdx.x; hy = blockIdx.y; bz = blockIdx.z;
+    if (!xcd_map) return;
+    const int nx = gridDim.x, ny = gridDim.y, np = ny * (int)gridDim.z;
+    const int L = qx + nx * (hy + ny * bz);
+    const int chunk = L / (8 * nx), base = chunk * 8;
+    const int r = min(8, np - base);
+    const int Lc = L - chunk * 8 * nx;
+    const int pair = base + Lc % r;
+    qx = Lc / r;
+    hy = pair % ny;
+    bz = pair / ny;
+}
+
 // ---- direct-operand variant (default) ----------------------------------------------------------------------------
 // One wave = 16 query rows x one share of the keys; NO LDS tiles and no block barriers in the loop.  The MFMA operand
 // layout of v_mfma_f32_16x16x4_f32 lets every lane fetch its B operands as 16-byte global loads when the reduction
@@ -54,9 +76,10 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     __shared__ __attribute__((aligned(16))) float Mg[(KS > 1 ? KS - 1 : 1) * 64 * MGW];
 
     const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int qx, h, b;
+    at_block_coords(p.xcd_map, qx, h, b);
     const int hk = h / (p.Hq / p.Hkv);
-    const int q0 = blockIdx.x * 16;
+    const int q0 = qx * 16;
     const int lr = lane & 15, lg = lane >> 4;
     float* ps = Ps[kg];
 
@@ -291,9 +314,10 @@ __global__ __launch_bounds__(64 * KS) __attribute__((amdgpu_waves_per_eu(WPE, WP
     __shared__ __attribute__((aligned(16))) float Mg[(KS > 1 ? KS - 1 : 1) * 64 * MGW];
 
     const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int qx, h, b;
+    at_block_coords(p.xcd_map, qx, h, b);
     const int hk = h / (p.Hq / p.Hkv);
-    const int q0 = blockIdx.x * 16 * RT;
+    const int q0 = qx * 16 * RT;
     const int lr = lane & 15, lg = lane >> 4;
 
     const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
@@ -548,14 +572,14 @@ __device__ __forceinline__ void fa_glds16(const unsigned char* base, uint32_t of
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
 }
-template <int MODE, bool IMG>
+template <int MODE, bool IMG, int RT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_attn_fa(const VhAttnArgs p) {
     constexpr bool CAUSAL = MODE >= 1, PAGED = MODE == 2;
     constexpr int D = 128, NC = D / 16, VQ = NC / 4, C32 = D / 32;
     constexpr int PL = 64 * D * 2;                 // bytes of one plane of one 64-key tile
     constexpr int MGW = 8 + NC * 4;
-    static_assert(4 * 64 * MGW * 4 <= 8 * PL, "merge area aliases the K / V buffers");
+    static_assert(4 * 64 * RT * MGW * 4 <= 8 * PL, "merge area aliases the K / V buffers");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * PL + 8 * 16 * AT_PSTR3 * 4];
     float* patches = reinterpret_cast<float*>(lds + 8 * PL);
 
@@ -563,23 +587,25 @@ void k_attn_fa(const VhAttnArgs p) {
     const int rg = w & 3, kg = w >> 2;                        // head of the KV group; key half
     const int ftid = tid & 255;                               // index inside the staging role
     const int lr = lane & 15, lg = lane >> 4;
-    const int b = blockIdx.z;
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;      // heaviest (latest rows under the causal mask) blocks first
-    const int hk = blockIdx.y, h = hk * 4 + rg, q0 = qb * 16;
-    const int qlast = min(q0 + 16, p.Sq) - 1;
+    int qx, hk, b;
+    at_block_coords(p.xcd_map, qx, hk, b);                    // (y = KV head here: the blocks of a KV head share its tile images)
+    const int qb = (int)gridDim.x - 1 - qx;                   // heaviest (latest rows under the causal mask) blocks first
+    const int h = hk * 4 + rg, q0 = qb * 16 * RT;
+    const int qlast = min(q0 + 16 * RT, p.Sq) - 1;
 
     const float* Qb = p.Q + (size_t)b * p.bsq + (size_t)h * p.hsq;
     const float* Kb = p.K + (size_t)b * p.bsk + (size_t)hk * p.hsk;
     const float* Vb = p.V + (size_t)b * p.bsk + (size_t)hk * p.hsv;
 
     const float qscale = p.scale * 1.44269504088896340736f;
-    bf16x8 qh[C32], ql[C32];
-    {
-        const int q = min(q0 + lr, p.Sq - 1);
+    bf16x8 qh[RT][C32], ql[RT][C32];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int q = min(q0 + 16 * rt + lr, p.Sq - 1);        // rows past Sq compute on a copy of the last row, never stored
 #pragma unroll
         for (int c = 0; c < C32; ++c) {
             const float* src = Qb + (size_t)q * p.ldq + 32 * c + 8 * lg;
-            at_split8(*reinterpret_cast<const f32x4*>(src) * qscale, *reinterpret_cast<const f32x4*>(src + 4) * qscale, qh[c], ql[c]);
+            at_split8(*reinterpret_cast<const f32x4*>(src) * qscale, *reinterpret_cast<const f32x4*>(src + 4) * qscale, qh[rt][c], ql[rt][c]);
         }
     }
 
@@ -587,12 +613,15 @@ void k_attn_fa(const VhAttnArgs p) {
     const int kloop = CAUSAL ? min(kend, qlast + p.q_off + 1) : kend;       // keys the block's rows can see
     const int ntiles = (kloop + 63) >> 6;
 
-    float m[4], l[4];
-    f32x4 o[NC];
+    float m[RT][4], l[RT][4];
+    f32x4 o[RT][NC];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+    for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-    for (int t = 0; t < NC; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) { m[rt][r] = -INFINITY; l[rt][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NC; ++t) o[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- staging by role (wave-uniform): group 1 = K, 8 x 16-byte pieces per thread: piece i = row 8 i + ftid / 32, floats
     // 4 (ftid % 32) ..+4 (a wave instruction = two whole rows); group 0 = V, two 4-key x 4-column blocks per thread ----------------
@@ -680,22 +709,27 @@ void k_attn_fa(const VhAttnArgs p) {
         if (IMG && more) dma_tile(t + 1, nbuf);                        // lands under this tile's products and softmax
         if (kt0 < kloop) {                                            // (wave-uniform) this half tile has a visible key
             // ---- S = Q K^T for the two 16-key sub-tiles ------------------------------------------------------------------------
-            f32x4 sacc[2];
+            f32x4 sacc[RT][2];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) sacc[rt][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int key = 32 * kg + 16 * jt + lr;
 #pragma unroll
                 for (int c = 0; c < C32; ++c) {
                     const int gc = 4 * c + lg;
                     const int off = (gc >> 3) * 8192 + key * 128 + (((gc & 7) ^ ((key >> 1) & 7)) << 4);
-                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);      // one fragment read serves every row tile of the wave
                     const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[c], kh, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[c], kl, a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[c], kh, a, 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 a = sacc[rt][jt];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[rt][c], kh, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kl, a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[rt][c], kh, a, 0, 0, 0);
+                        sacc[rt][jt] = a;
+                    }
                 }
-                sacc[jt] = a;
             }
             // conversion + LDS writes of the NEXT tile here, behind the 24 MFMAs of S that the matrix pipe is still working through, and the
             // reload for the tile after next right behind them: every load has a whole tile period to land.  (Splitting the staging in two
@@ -708,50 +742,56 @@ void k_attn_fa(const VhAttnArgs p) {
             }
             // ---- online softmax in D layout (the direct kernel's) --------------------------------------------------------------
             const bool full_tile = kt0 + AT_KT <= (CAUSAL ? min(kend, q0 + p.q_off + 1) : kend);
-            float alpha[4];
+            bf16x8 ph[RT], pl[RT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = q0 + lg * 4 + r;
-                float s0v = sacc[0][r], s1v = sacc[1][r];
-                if (!full_tile) {
-                    const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;
-                    s0v = (kt0 + lr < klim) ? s0v : -INFINITY;
-                    s1v = (kt0 + 16 + lr < klim) ? s1v : -INFINITY;
+            for (int rt = 0; rt < RT; ++rt) {                        // (the wave's ONE patch serves its row tiles in turn: LDS executes a wave's operations in order)
+                float alpha[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + 16 * rt + lg * 4 + r;
+                    float s0v = sacc[rt][0][r], s1v = sacc[rt][1][r];
+                    if (!full_tile) {
+                        const int klim = CAUSAL ? min(kend, q + p.q_off + 1) : kend;
+                        s0v = (kt0 + lr < klim) ? s0v : -INFINITY;
+                        s1v = (kt0 + 16 + lr < klim) ? s1v : -INFINITY;
+                    }
+                    const float mx = grp16_max(fmaxf(s0v, s1v));
+                    const float mn = fmaxf(m[rt][r], mx);
+                    const bool none = mn == -INFINITY;
+                    alpha[r] = none ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
+                    const float p0 = none ? 0.f : __builtin_amdgcn_exp2f(s0v - mn);
+                    const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1v - mn);
+                    l[rt][r] = l[rt][r] * alpha[r] + grp16_sum(p0 + p1);
+                    m[rt][r] = mn;
+                    ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
+                    ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
                 }
-                const float mx = grp16_max(fmaxf(s0v, s1v));
-                const float mn = fmaxf(m[r], mx);
-                const bool none = mn == -INFINITY;
-                alpha[r] = none ? 1.f : __builtin_amdgcn_exp2f(m[r] - mn);
-                const float p0 = none ? 0.f : __builtin_amdgcn_exp2f(s0v - mn);
-                const float p1 = none ? 0.f : __builtin_amdgcn_exp2f(s1v - mn);
-                l[r] = l[r] * alpha[r] + grp16_sum(p0 + p1);
-                m[r] = mn;
-                ps[(lg * 4 + r) * AT_PSTR3 + lr] = p0;
-                ps[(lg * 4 + r) * AT_PSTR3 + 16 + lr] = p1;
+#pragma unroll
+                for (int tt = 0; tt < NC; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[rt][tt][r] *= alpha[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                at_split8(*reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg), *reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg + 4), ph[rt], pl[rt]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // the patch is read before the next row tile (or the next key tile) rewrites it
             }
-#pragma unroll
-            for (int tt = 0; tt < NC; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[tt][r] *= alpha[r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- O += P V over the 32 keys -------------------------------------------------------------------------------------
-            bf16x8 ph, pl;
-            at_split8(*reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg), *reinterpret_cast<const f32x4*>(ps + lr * AT_PSTR3 + 8 * lg + 4), ph, pl);
 #pragma unroll
             for (int tt = 0; tt < NC; ++tt) {
                 const int row = 16 * tt + lr;
                 const int off = row * 128 + (((4 * kg + lg) ^ ((row >> 1) & 7)) << 4);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Vh + off);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Vl + off);
-                o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, bh, o[tt], 0, 0, 0);
-                o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bl, o[tt], 0, 0, 0);
-                o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, bh, o[tt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rt], bh, o[rt][tt], 0, 0, 0);
+                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bl, o[rt][tt], 0, 0, 0);
+                    o[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], bh, o[rt][tt], 0, 0, 0);
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else if (!IMG) {
             if (more) { store_part(0, nbuf); store_part(1, nbuf); }
             load_part(0, knext); load_part(1, knext);
@@ -763,39 +803,49 @@ void k_attn_fa(const VhAttnArgs p) {
     // ---- the second key half of every head merges into the first (every wave is past the last tile: the K / V buffers are free
     // and hold the hand-over) ---------------------------------------------------------------------------------------------------------
     {
-        float* mg = reinterpret_cast<float*>(lds) + (rg * 64 + lane) * MGW;
+        float* mg0 = reinterpret_cast<float*>(lds) + (size_t)(rg * 64 + lane) * RT * MGW;
         if (kg == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { mg[r] = m[r]; mg[4 + r] = l[r]; }
+            for (int rt = 0; rt < RT; ++rt) {
+                float* mg = mg0 + rt * MGW;
 #pragma unroll
-            for (int t = 0; t < NC; ++t)
+                for (int r = 0; r < 4; ++r) { mg[r] = m[rt][r]; mg[4 + r] = l[rt][r]; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mg[8 + t * 4 + r] = o[t][r];
+                for (int t = 0; t < NC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mg[8 + t * 4 + r] = o[rt][t][r];
+            }
         }
         __syncthreads();
         if (kg == 1) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m2 = mg[r], l2 = mg[4 + r];
-            const float mn = fmaxf(m[r], m2);
-            const float a1 = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[r] - mn);
-            const float a2 = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
-            l[r] = l[r] * a1 + l2 * a2;
-            m[r] = mn;
+        for (int rt = 0; rt < RT; ++rt) {
+            const float* mg = mg0 + rt * MGW;
 #pragma unroll
-            for (int t = 0; t < NC; ++t) o[t][r] = o[t][r] * a1 + mg[8 + t * 4 + r] * a2;
+            for (int r = 0; r < 4; ++r) {
+                const float m2 = mg[r], l2 = mg[4 + r];
+                const float mn = fmaxf(m[rt][r], m2);
+                const float a1 = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[rt][r] - mn);
+                const float a2 = (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+                l[rt][r] = l[rt][r] * a1 + l2 * a2;
+                m[rt][r] = mn;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) o[rt][t][r] = o[rt][t][r] * a1 + mg[8 + t * 4 + r] * a2;
+            }
         }
     }
 
     float* Ob = p.O ? p.O + (size_t)b * p.bso + (size_t)h * D : nullptr;
 #pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int q = q0 + lg * 4 + r;
+        const int q = q0 + 16 * rt + lg * 4 + r;
         if (q >= p.Sq) continue;
-        const float inv = (l[r] > 0.f) ? 1.0f / l[r] : 0.f;
+        const float inv = (l[rt][r] > 0.f) ? 1.0f / l[rt][r] : 0.f;
 #pragma unroll
         for (int j = 0; j < VQ; ++j) {
-            const f32x4 v = f32x4{o[4 * j][r] * inv, o[4 * j + 1][r] * inv, o[4 * j + 2][r] * inv, o[4 * j + 3][r] * inv};
+            const f32x4 v = f32x4{o[rt][4 * j][r] * inv, o[rt][4 * j + 1][r] * inv, o[rt][4 * j + 2][r] * inv, o[rt][4 * j + 3][r] * inv};
             if (Ob) *reinterpret_cast<f32x4*>(Ob + (size_t)q * p.ldo + lr * NC + 4 * j) = v;
             if (p.O_hi) {
                 uint32_t hi[2], lo[2];
@@ -819,7 +869,9 @@ int vhk_attn_fa_applies(const VhAttnArgs& a) {
     return (vh_tuning()->attn_fa == 2 || blocks * 2 >= vh_num_cus()) ? 1 : 0;
 }
 
-int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
+int vhk_attn(hipStream_t st, const VhAttnArgs& a_in) {
+    VhAttnArgs a = a_in;
+    a.xcd_map = vh_tuning()->attn_xcd != 0 ? 1 : 0;
     if (a.Sq <= 0 || a.Sk <= 0 || a.Hq % a.Hkv != 0) return -1;
     const bool rel = a.P != nullptr;
     const int want = vh_tuning()->attn_ksplit;
@@ -859,10 +911,18 @@ int vhk_attn(hipStream_t st, const VhAttnArgs& a) {
                     // producer-side K / V tile images: one-shot causal prefills only (every key of the call was written by this pass)
                     const bool img = a.kv_img != nullptr && mode >= 1 && a.q_off == 0 && a.Sk == a.Sq && a.B == 1 && a.klen >= a.Sk &&
                                      a.img_tiles >= (a.Sk + 63) / 64 && (reinterpret_cast<uintptr_t>(a.kv_img) & 15) == 0;
-                    if (img) hipLaunchKernelGGL((k_attn_fa<1, true>), gf, dim3(512), 0, st, a);
-                    else if (mode == 0) hipLaunchKernelGGL((k_attn_fa<0, false>), gf, dim3(512), 0, st, a);
-                    else if (mode == 1) hipLaunchKernelGGL((k_attn_fa<1, false>), gf, dim3(512), 0, st, a);
-                    else hipLaunchKernelGGL((k_attn_fa<2, false>), gf, dim3(512), 0, st, a);
+                    // 32 query rows per wave (r06: every K / V fragment read from LDS feeds two row tiles, half the tile DMA and half the block
+                    // barriers per query row; 2 waves per SIMD either way) when the launch still has two blocks per CU (S = 2344: 592 blocks;
+                    // S = 552 would have 144 and keeps 16 rows); attn_rows = 16 / 32 forces one or the other
+                    const dim3 gf2((a.Sq + 31) / 32, a.Hkv, a.B);
+                    const int rows = vh_tuning()->attn_rows;
+                    const bool two = mode == 1 && (rows == 32 || (rows == 0 && (long)gf2.x * gf2.y * gf2.z >= 2L * vh_num_cus()));
+                    if (img && two) hipLaunchKernelGGL((k_attn_fa<1, true, 2>), gf2, dim3(512), 0, st, a);
+                    else if (img) hipLaunchKernelGGL((k_attn_fa<1, true, 1>), gf, dim3(512), 0, st, a);
+                    else if (mode == 0) hipLaunchKernelGGL((k_attn_fa<0, false, 1>), gf, dim3(512), 0, st, a);
+                    else if (mode == 1 && two) hipLaunchKernelGGL((k_attn_fa<1, false, 2>), gf2, dim3(512), 0, st, a);
+                    else if (mode == 1) hipLaunchKernelGGL((k_attn_fa<1, false, 1>), gf, dim3(512), 0, st, a);
+                    else hipLaunchKernelGGL((k_attn_fa<2, false, 1>), gf, dim3(512), 0, st, a);
                     return 0;
                 }
             }

@@ -34,6 +34,7 @@ struct VhTuning {
                                // -> O projection, q|k|v and the attention output handed over as tagged granules, a block's weights in flight
                                // while it waits), 0 = three launches (five per layer), -1 = auto (fused wherever the kernel has an instantiation:
                                // H and the heads' width <= 4096, i.e. the released geometry at any TP degree)
+    int attn_xcd = 1;          // attention kernels: 1 = the q tiles of one (head, batch) pair all run on ONE XCD (its L2 holds that pair's K / V), 0 = plain x / y / z
     int attn_img = 1;          // one-shot prefills under the flash attention kernel: 1 = K / V as MFMA-ready tile images written by the RoPE pass
                                // (k_rope_kv_img -> LDS-DMA in k_attn_fa), 0 = fp32 K / V staged and converted by every attention block (r04-r05)
     int dec_gateup_grid = 0;   // debug: blocks of the batch-1 gate|up launch (0 = auto: 1.5 per CU, equal shares in few rounds for small shards)
@@ -228,6 +229,7 @@ struct VhAttnArgs {
     // V hi transposed | V lo transposed, 16-byte chunks XOR-swizzled; rows past Sk are zeros).  Used by the flash kernel for one-shot
     // causal prefills (q_off == 0, Sk == Sq, B == 1); ignored otherwise (K / V must always be valid too).
     const unsigned char* kv_img; int img_tiles;
+    int xcd_map;                          // set by vhk_attn (vh_tune "attn_xcd"): block -> (q tile, head, batch) with all q tiles of a head on one XCD
 };
 int vhk_attn(hipStream_t st, const VhAttnArgs& a);
 int vhk_attn_fa_applies(const VhAttnArgs& a);    // 1 when vhk_attn would run the flash kernel (k_attn_fa) for these arguments
