@@ -30,7 +30,7 @@ for path in sys.argv[1:]:
             continue
         name = " ".join(f[6:])
         for key, pat in (("k_dec_gateup", "k_dec_gateup<2, 4>"), ("k_dec_down", "k_dec_down<7, 2>"), ("k_dec_ablk", "k_dec_ablk<2, 2, 8>"),
-                         ("k_dec_lmhead", "k_dec_lmhead<2>"), ("k_gemm_sp_glu", "k_gemm_sp<true"), ("k_attn_fa", "k_attn_fa<1, true>")):
+                         ("k_dec_lmhead", "k_dec_lmhead<2>"), ("k_gemm_sp_glu", "k_gemm_sp<true"), ("k_attn_fa", "k_attn_fa<1, true, 1>")):
             if pat in name and key not in out:
                 out[key] = {"avg_us": float(f[3]), "calls": int(f[1]), "kernel": name[:70]}
 print(json.dumps(out, indent=1))
