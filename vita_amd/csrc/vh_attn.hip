@@ -34,7 +34,7 @@ __device__ __forceinline__ bool key_visible(const VhAttnArgs& p, int q, int key,
 // ---- block -> (q tile, head, batch), XCD-aware (r06) -----------------------------------------------------------------------------------
 // Hardware deals the blocks of a grid to the 8 XCDs round-robin in linear order (x fastest), and every XCD has its own 4 MB L2.  With the
 // plain decode (x = q tile, y = head, z = batch) the q tiles of ONE head — which all stream the same K / V — land on all 8 XCDs and each L2
-// fetches every head's K / V: at S = 2344 the flash kernel's 1176 blocks pulled 1.4 GB through the fabric for 19 MB of tile images.
+// fetches every head's K / V: at S = 2344 the flash kernel's FETCH_SIZE was 190 MB per launch for 19 MB of tile images + 38 MB of Q (65 MB now).
 // xcd_map: linear block L of a chunk of 8 (head, batch) pairs takes pair L % 8 and q tile L / 8: all q tiles of a pair run on ONE XCD,
 // whose L2 then holds that pair's K / V only (2.4 MB of images per KV head at S = 2344).  Bijective for any grid (a last chunk of r < 8
 // pairs deals L % r); q tiles stay in dispatch order.
